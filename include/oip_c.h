@@ -1,0 +1,191 @@
+/*
+ * oip_c.h -- C ABI of liboipgpu.so, the MI355X (gfx950) implementation of the
+ * arloan/OpticalImageProcessor hot path: per-column relative radiometric correction,
+ * cross-CCD / inter-band phase correlation, bicubic resampling and strip stitching.
+ *
+ * The reference has no FFI: the path sits behind header-only C++ classes with static
+ * methods (IMO, Stitcher, PreProcessor).  Each entry point below names the reference
+ * seam it replaces (file:line under OpticalImageProcessor/).  INTEGRATION.md shows the
+ * few lines a maintainer adds to the reference to call them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; `d_*` arguments are device (HBM) pointers, everything
+ *     else is host memory.  Rasters are headerless row-major uint16 (little endian), pitch ==
+ *     width, exactly the reference's RAW layout (oipshared.h:27-32).
+ *   - every call returns an oip_status; oip_last_error(ctx) gives the message.  The status
+ *     classes mirror the exception types the reference throws so a C++ shell can re-throw
+ *     them and keep the exit codes of main.cpp:320-343.
+ *   - kernels are enqueued on the context's stream and are asynchronous unless the
+ *     function returns host values (then it synchronises the stream itself).
+ *   - one oip_ctx per device; a context is not thread-safe, distinct contexts are independent.
+ *   - there is NO CPU fallback: without a gfx950 device oip_create fails.
+ */
+#ifndef OIP_C_H
+#define OIP_C_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oip_ctx oip_ctx;
+
+typedef enum oip_status {
+    OIP_OK = 0,
+    OIP_E_INVALID = 1,   /* std::invalid_argument in the reference                       */
+    OIP_E_RUNTIME = 2,   /* std::runtime_error                                           */
+    OIP_E_IO = 3,        /* errno_error (open/read/write/stat)                           */
+    OIP_E_DEVICE = 4,    /* HIP failure / no gfx950 device                               */
+    OIP_E_NOMEM = 5,
+    OIP_E_UNSUPPORTED = 6
+} oip_status;
+
+/* reference constants (oipshared.h:27-54, imageop.h:19-20); width is a run-time argument
+ * everywhere below, these are only the defaults */
+#define OIP_PIXELS_PER_LINE      12288
+#define OIP_MSS_BANDS            4
+#define OIP_CORRELATION_LINES    16000
+#define OIP_IBCV_DEF_THRESHOLD   0.4
+#define OIP_IBCV_MIN_COUNT       5
+#define OIP_IBCV_DEF_SECTIONS    5
+#define OIP_IBCV_DEF_SLICES      10
+#define OIP_IBCV_MIN_SLICES      8
+#define OIP_IBPA_DEFAULT_BATCHLINES  20000
+#define OIP_IBPA_DEFAULT_LINEOVERLAP 520
+#define OIP_IBPA_MAX_LINEOVERLAP     3000
+#define OIP_IBPA_MIN_PROCESSLINES    1500
+#define OIP_STT_DEF_SECTIONS     10
+#define OIP_STT_DEF_SECLINES     16000
+#define OIP_STT_DEF_OVERLAPPX    200
+#define OIP_STT_DEF_PHCTHRHLD    0.4
+#define OIP_REMAP_ROW_GUARD      32767
+#define OIP_REMAP_SECTION_ROWS   30000
+
+/* ---- context, stream, memory ------------------------------------------------------ */
+int         oip_version(void);                       /* 0x0101 == "1.1" (main.cpp:94)  */
+int         oip_create(int device, oip_ctx **out);
+void        oip_destroy(oip_ctx *ctx);
+const char *oip_last_error(const oip_ctx *ctx);
+int         oip_set_stream(oip_ctx *ctx, void *hip_stream);  /* borrow a hipStream_t (NULL: own) */
+void       *oip_get_stream(oip_ctx *ctx);
+int         oip_sync(oip_ctx *ctx);
+int         oip_malloc(oip_ctx *ctx, void **d_ptr, size_t bytes);
+int         oip_free(oip_ctx *ctx, void *d_ptr);
+int         oip_memset(oip_ctx *ctx, void *d_ptr, int value, size_t bytes);
+int         oip_memcpy_h2d(oip_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int         oip_memcpy_d2h(oip_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+int         oip_host_alloc(oip_ctx *ctx, void **ptr, size_t bytes);   /* pinned staging */
+int         oip_host_free(oip_ctx *ctx, void *ptr);
+
+/* ---- RRC --------------------------------------------------------------------------- */
+/* IMO::LoadRRCParamFile(path, expectedLines)  imageop.h:140-192.  kb_out receives
+ * expected_lines (k,b) pairs == RRCParam[expected_lines].  No context needed. */
+int oip_load_rrc_param_file(const char *path, int expected_lines, double *kb_out,
+                            char *err, int errlen);
+
+/* IMO::InplaceRRC(buff, w, h, rrcParam)  imageop.h:129-138; callers imageop.h:207,
+ * preproc.h:195, :215.  dst[y*w+x] = (uint16_t)(k[x]*src[y*w+x] + b[x]) in fp64 with two
+ * roundings and x86-64 truncate/wrap conversion; bit-exact.  d_dst may equal d_src
+ * (in place, as the reference).  d_kb: w (k,b) pairs in HBM. */
+int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, long h,
+                const double *d_kb);
+
+/* Host-buffer form of the same seam: `buff` is the reference's heap buffer, corrected in
+ * place through pinned, double-buffered line blocks (H2D || kernel || D2H). */
+int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb);
+
+/* PreProcessor::LoadMSS split (preproc.h:62-75) fused with DoRRC4MSS (preproc.h:202-222):
+ * one pass over the BIL MSS raster (each line = 4 bands x w/4 px) writing 4 planar,
+ * RRC-corrected bands (band b at d_planes + b*plane_stride).  d_kb4: 4 x (w/4) (k,b)
+ * pairs, band-major; NULL = split only (--no-rrc4mss). */
+int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16_t *d_planes,
+                          size_t plane_stride, int w, long lines, const double *d_kb4);
+
+/* ---- correlation ------------------------------------------------------------------- */
+/* cv::phaseCorrelate(src1, src2, noArray(), &response)  call sites stitcher.h:180,
+ * preproc.h:316.  d_a/d_b: continuous rows x cols f32.  Synchronises; host outputs. */
+int oip_phase_correlate_f32(oip_ctx *ctx, const float *d_a, const float *d_b, int rows,
+                            int cols, double *dx, double *dy, double *response);
+
+/* Mat1w.colRange -> Mat1f conversion (stitcher.h:175-176, preproc.h:258-293) */
+int oip_window_u16_to_f32(oip_ctx *ctx, const uint16_t *d_img, size_t pitch, long row0,
+                          int col0, int rows, int cols, float *d_out);
+
+/* cv::resize(f32, dsize, 0, 0, INTER_CUBIC)  call site preproc.h:302-307 */
+int oip_resize_cubic_f32(oip_ctx *ctx, const float *d_src, int sw, int sh, float *d_dst,
+                         int dw, int dh);
+
+/* Loop body of Stitcher::CalcSttParameters (stitcher.h:166-191) for all sections:
+ * out[s*3 + {0,1,2}] = dx, dy, response of section s (host).  d_pan1/d_pan2 hold global
+ * lines [row0, row0+nrows) of the W-wide rasters of L lines; sections not fully inside
+ * that range are skipped and reported as NaN (multi-GPU: each rank computes the sections
+ * it owns, results are all-gathered). */
+int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uint16_t *d_pan2, int W,
+                      long L, long row0, long nrows, int sections, int lines_per_section,
+                      int overlap_cols, int edge_cols, double *out);
+
+/* Loop body of PreProcessor::CalcInterBandCorrelation (preproc.h:251-329):
+ * out[((b*sections + sec)*slices + i)*4 + {0..3}] = dx, dy, rs, cx.  PAN lines
+ * [prow0, prow0+pn) and MSS band lines [mrow0, mrow0+mn) are resident; sections not fully
+ * inside are reported as NaN. */
+int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long Lp, long prow0, long pn,
+                            const uint16_t *d_planes, size_t plane_stride, long mrow0, long mn,
+                            int W, int slices, int sections, int corr_lines, double *out);
+
+/* FilterInterBandShiftValues + DoCorrelationPolynomialFitting (preproc.h:492-550), host.
+ * shifts: [4][n][4] (dx,dy,rs,cx).  cx_out[4][2], cy_out[4][3] ascending coefficients. */
+int oip_filter_and_fit(const double *shifts, int n, double threshold, int min_count,
+                       double *cx_out, double *cy_out, char *err, int errlen);
+/* nc::polynomial::Poly1d<double>::fit(x, y, deg): least squares, ascending coefficients */
+int oip_polyfit(const double *x, const double *y, int n, int deg, double *coeffs);
+
+/* ---- resampling -------------------------------------------------------------------- */
+/* Stitcher::PreStitch (stitcher.h:83-139) + IMO::SectionaryRemap (imageop.h:230-275) +
+ * cv::remap(INTER_CUBIC, BORDER_CONSTANT) (imageop.h:258): out(x,y) = bicubic(src, x+dx,
+ * y+dy) with OpenCV's 1/32-px quantisation, per-section borders and cuts.  The float maps
+ * are never materialised.  d_src holds global lines [src_row0, src_row0+src_rows) and
+ * d_dst receives output lines [out_row0, out_row0+out_rows) of the W x L raster (whole
+ * strip: 0, L, 0, L).  OIP_E_INVALID if L <= row_guard (imageop.h:242-244). */
+int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, long src_row0,
+                                long src_rows, uint16_t *d_dst, long out_row0, long out_rows,
+                                int W, long L, double dx, double dy, int section_rows,
+                                int row_guard);
+/* source lines [first, last) that output lines [out_row0, out_row0+out_rows) read: the halo
+ * a row-block shard has to hold (host arithmetic only) */
+int oip_remap_shift_src_range(long out_row0, long out_rows, long L, double dy,
+                              int section_rows, long *first, long *last);
+
+/* PreProcessor::DoInterBandAlignment outer (preproc.h:351-425) + inner (:428-468) incl.
+ * cv::remap and cv::merge: 4 planar bands -> interleaved 16UC4, polynomial maps evaluated
+ * in fp64 in the kernel.  cx[4][2], cy[4][3] host.  d_planes holds MSS lines [src_row0,
+ * src_row0+src_rows); d_dst receives output lines [out_row0, out_row0+out_rows) of the
+ * (Lm - line_offset - (keep?0:overlap)) x Wb x 4 result; skipped tail lines are zero.
+ * rows_valid (may be NULL): the reference's processedLines. */
+int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_planes, size_t plane_stride,
+                                long src_row0, long src_rows, uint16_t *d_dst, long out_row0,
+                                long out_rows, int Wb, long Lm, const double *cx,
+                                const double *cy, int lines_per_section, int line_offset,
+                                int overlap, int keep_leading, int min_lines, long *rows_valid);
+int oip_align_mss_src_range(long out_row0, long out_rows, long Lm, const double *cy, int Wb,
+                            int lines_per_section, int line_offset, int overlap,
+                            int keep_leading, int min_lines, long *first, long *last);
+
+/* IMO::StitchBigRaw line loop (imageop.h:340-351), RAW output: out line = left[0:W-fold] ||
+ * right[fold:W]; `fold` is the already-halved value (main.cpp:189). */
+int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_right,
+                        uint16_t *d_out, int W, long L, int fold);
+
+/* ---- instrumentation --------------------------------------------------------------- */
+/* name + accumulated device time of the kernels launched through this context since the
+ * last reset, measured with HIP events on the context's stream (off by default). */
+int oip_profile_enable(oip_ctx *ctx, int on);
+int oip_profile_reset(oip_ctx *ctx);
+int oip_profile_count(oip_ctx *ctx);
+int oip_profile_get(oip_ctx *ctx, int i, char *name, int namelen, double *total_ms, long *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OIP_C_H */

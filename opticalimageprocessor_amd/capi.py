@@ -1,0 +1,300 @@
+"""ctypes binding of include/oip_c.h.  No arithmetic here -- every method forwards device
+pointers to liboipgpu.so.  Anything that cannot reach the HIP library raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+_LIB = None
+
+STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "RUNTIME", 3: "IO", 4: "DEVICE", 5: "NOMEM", 6: "UNSUPPORTED"}
+# the exception classes the reference throws for each status (main.cpp:320-343 exit codes)
+_STATUS_EXC = {1: ValueError, 2: RuntimeError, 3: OSError, 4: RuntimeError, 5: MemoryError, 6: NotImplementedError}
+
+
+class OipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("oip status %s: %s" % (STATUS_NAMES.get(status, status), msg))
+        self.status = status
+
+
+def library_path() -> str:
+    return os.path.join(_PKG, "lib", "liboipgpu.so")
+
+
+def build(jobs: int = 8, quiet: bool = True) -> None:
+    """Compile liboipgpu.so (+ the oip CLI) for gfx950 with hipcc."""
+    subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-j%d" % jobs], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def declared_symbols():
+    """Every function name include/oip_c.h declares."""
+    text = open(os.path.join(_ROOT, "include", "oip_c.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oip_[a-z0-9_]+)\s*\(", text)))
+
+
+_vp, _i, _l, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_size_t
+_dp, _lp, _cp = C.POINTER(C.c_double), C.POINTER(C.c_long), C.c_char_p
+_SIGS = {
+    "oip_version": ([], _i),
+    "oip_create": ([_i, C.POINTER(_vp)], _i),
+    "oip_destroy": ([_vp], None),
+    "oip_last_error": ([_vp], _cp),
+    "oip_set_stream": ([_vp, _vp], _i),
+    "oip_get_stream": ([_vp], _vp),
+    "oip_sync": ([_vp], _i),
+    "oip_malloc": ([_vp, C.POINTER(_vp), _sz], _i),
+    "oip_free": ([_vp, _vp], _i),
+    "oip_memset": ([_vp, _vp, _i, _sz], _i),
+    "oip_memcpy_h2d": ([_vp, _vp, _vp, _sz], _i),
+    "oip_memcpy_d2h": ([_vp, _vp, _vp, _sz], _i),
+    "oip_host_alloc": ([_vp, C.POINTER(_vp), _sz], _i),
+    "oip_host_free": ([_vp, _vp], _i),
+    "oip_load_rrc_param_file": ([_cp, _i, _dp, _cp, _i], _i),
+    "oip_rrc_u16": ([_vp, _vp, _vp, _i, _l, _vp], _i),
+    "oip_rrc_u16_host": ([_vp, _vp, _i, _l, _dp], _i),
+    "oip_mss_split_rrc_u16": ([_vp, _vp, _vp, _sz, _i, _l, _vp], _i),
+    "oip_phase_correlate_f32": ([_vp, _vp, _vp, _i, _i, _dp, _dp, _dp], _i),
+    "oip_window_u16_to_f32": ([_vp, _vp, _sz, _l, _i, _i, _i, _vp], _i),
+    "oip_resize_cubic_f32": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
+    "oip_stt_correlate": ([_vp, _vp, _vp, _i, _l, _l, _l, _i, _i, _i, _i, _dp], _i),
+    "oip_interband_correlate": ([_vp, _vp, _l, _l, _l, _vp, _sz, _l, _l, _i, _i, _i, _i, _dp], _i),
+    "oip_filter_and_fit": ([_dp, _i, _d, _i, _dp, _dp, _cp, _i], _i),
+    "oip_polyfit": ([_dp, _dp, _i, _i, _dp], _i),
+    "oip_remap_shift_bicubic_u16": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
+    "oip_remap_shift_src_range": ([_l, _l, _l, _d, _i, _lp, _lp], _i),
+    "oip_align_mss_bicubic_u16x4": ([_vp, _vp, _sz, _l, _l, _vp, _l, _l, _i, _l, _dp, _dp, _i, _i, _i, _i, _i, _lp], _i),
+    "oip_align_mss_src_range": ([_l, _l, _l, _dp, _i, _i, _i, _i, _i, _i, _lp, _lp], _i),
+    "oip_stitch_rows_u16": ([_vp, _vp, _vp, _vp, _i, _l, _i], _i),
+    "oip_profile_enable": ([_vp, _i], _i),
+    "oip_profile_reset": ([_vp], _i),
+    "oip_profile_count": ([_vp], _i),
+    "oip_profile_get": ([_vp, _i, _cp, _i, _dp, _lp], _i),
+}
+
+
+def load_library() -> C.CDLL:
+    """dlopen liboipgpu.so (in-tree).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise OSError("liboipgpu.so not built at %s -- run __graft_entry__.build() "
+                          "(there is no CPU fallback)" % path)
+        lib = C.CDLL(path)
+        for name, (args, res) in _SIGS.items():
+            if os.environ.get("OIP_DEV_PARTIAL") and not hasattr(lib, name):   # TEMP (dev bring-up)
+                continue
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = res
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(t):
+    """device pointer of a torch tensor / raw int"""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _dbl(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if n is not None:
+        assert a.size == n, (a.size, n)
+    return a
+
+
+# ---- host-only entry points ---------------------------------------------------------------
+def load_rrc_param_file(path: str, expected: int) -> np.ndarray:
+    lib = load_library()
+    out = np.zeros((expected, 2), np.float64)
+    err = C.create_string_buffer(2048)
+    rc = lib.oip_load_rrc_param_file(os.fsencode(path), expected, out.ctypes.data_as(_dp), err, 2048)
+    if rc:
+        raise _STATUS_EXC.get(rc, OipError)(err.value.decode())
+    return out
+
+
+def polyfit(x, y, deg: int) -> np.ndarray:
+    lib = load_library()
+    x, y = _dbl(x), _dbl(y)
+    out = np.zeros(deg + 1)
+    rc = lib.oip_polyfit(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), x.size, deg, out.ctypes.data_as(_dp))
+    if rc:
+        raise _STATUS_EXC.get(rc, OipError)("oip_polyfit failed (%s)" % STATUS_NAMES.get(rc))
+    return out
+
+
+def filter_and_fit(shifts, threshold=0.4, min_count=5):
+    lib = load_library()
+    s = _dbl(shifts)
+    assert s.ndim == 3 and s.shape[0] == 4 and s.shape[2] == 4
+    cx, cy = np.zeros((4, 2)), np.zeros((4, 3))
+    err = C.create_string_buffer(1024)
+    rc = lib.oip_filter_and_fit(s.ctypes.data_as(_dp), s.shape[1], threshold, min_count,
+                                cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), err, 1024)
+    if rc:
+        raise _STATUS_EXC.get(rc, OipError)(err.value.decode())
+    return cx, cy
+
+
+def remap_shift_src_range(out_row0, out_rows, L, dy, section_rows=30000):
+    lib = load_library()
+    a, b = C.c_long(), C.c_long()
+    rc = lib.oip_remap_shift_src_range(out_row0, out_rows, L, dy, section_rows, C.byref(a), C.byref(b))
+    if rc:
+        raise ValueError("oip_remap_shift_src_range: bad argument")
+    return a.value, b.value
+
+
+def align_mss_src_range(out_row0, out_rows, Lm, cy, Wb, lines_per_section=20000, line_offset=0,
+                        overlap=520, keep_leading=False, min_lines=1500):
+    lib = load_library()
+    cy = _dbl(cy, 12)
+    a, b = C.c_long(), C.c_long()
+    rc = lib.oip_align_mss_src_range(out_row0, out_rows, Lm, cy.ctypes.data_as(_dp), Wb, lines_per_section,
+                                     line_offset, overlap, int(keep_leading), min_lines, C.byref(a), C.byref(b))
+    if rc:
+        raise ValueError("oip_align_mss_src_range: bad argument")
+    return a.value, b.value
+
+
+# ---- device context -------------------------------------------------------------------------
+class Context:
+    """One oip_ctx (one GPU).  Methods take torch CUDA tensors (or raw device pointers)."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.oip_create(device, C.byref(h))
+        if rc:
+            raise OipError(rc, "oip_create(%d) failed: no gfx950 device (no CPU fallback)" % device)
+        self.h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.oip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            msg = self.lib.oip_last_error(self.h).decode()
+            exc = _STATUS_EXC.get(rc, OipError)
+            raise exc(msg) if exc is not OipError else OipError(rc, msg)
+
+    def set_stream(self, stream):
+        """stream: torch.cuda.Stream, raw hipStream_t int, or None for the context's own."""
+        s = getattr(stream, "cuda_stream", stream)
+        self._ck(self.lib.oip_set_stream(self.h, s))
+
+    def sync(self):
+        self._ck(self.lib.oip_sync(self.h))
+
+    # -- RRC
+    def upload_kb(self, kb):
+        import torch
+        kb = _dbl(kb)
+        return torch.from_numpy(kb.reshape(-1, 2)).to("cuda:%d" % self.device)
+
+    def rrc_u16(self, src, dst, w, h, d_kb):
+        self._ck(self.lib.oip_rrc_u16(self.h, _ptr(src), _ptr(dst), w, h, _ptr(d_kb)))
+
+    def rrc_u16_host(self, buff: np.ndarray, kb):
+        assert buff.dtype == np.uint16 and buff.flags.c_contiguous and buff.ndim == 2
+        kb = _dbl(kb, buff.shape[1] * 2)
+        self._ck(self.lib.oip_rrc_u16_host(self.h, buff.ctypes.data, buff.shape[1], buff.shape[0],
+                                           kb.ctypes.data_as(_dp)))
+
+    def mss_split_rrc_u16(self, bil, planes, plane_stride, w, lines, d_kb4):
+        self._ck(self.lib.oip_mss_split_rrc_u16(self.h, _ptr(bil), _ptr(planes), plane_stride, w, lines, _ptr(d_kb4)))
+
+    # -- correlation
+    def phase_correlate_f32(self, a, b, rows, cols):
+        dx, dy, r = _d(), _d(), _d()
+        self._ck(self.lib.oip_phase_correlate_f32(self.h, _ptr(a), _ptr(b), rows, cols, C.byref(dx), C.byref(dy), C.byref(r)))
+        return (dx.value, dy.value), r.value
+
+    def window_u16_to_f32(self, img, pitch, row0, col0, rows, cols, out):
+        self._ck(self.lib.oip_window_u16_to_f32(self.h, _ptr(img), pitch, row0, col0, rows, cols, _ptr(out)))
+
+    def resize_cubic_f32(self, src, sw, sh, dst, dw, dh):
+        self._ck(self.lib.oip_resize_cubic_f32(self.h, _ptr(src), sw, sh, _ptr(dst), dw, dh))
+
+    def stt_correlate(self, pan1, pan2, W, L, row0, nrows, sections=10, lines_per_section=16000,
+                      overlap_cols=200, edge_cols=0):
+        out = np.zeros((sections, 3))
+        self._ck(self.lib.oip_stt_correlate(self.h, _ptr(pan1), _ptr(pan2), W, L, row0, nrows, sections,
+                                            lines_per_section, overlap_cols, edge_cols, out.ctypes.data_as(_dp)))
+        return out
+
+    def interband_correlate(self, pan, Lp, prow0, pn, planes, plane_stride, mrow0, mn, W, slices=10,
+                            sections=5, corr_lines=16000):
+        out = np.zeros((4, sections * slices, 4))
+        self._ck(self.lib.oip_interband_correlate(self.h, _ptr(pan), Lp, prow0, pn, _ptr(planes), plane_stride,
+                                                  mrow0, mn, W, slices, sections, corr_lines,
+                                                  out.ctypes.data_as(_dp)))
+        return out
+
+    # -- resampling
+    def remap_shift_bicubic_u16(self, src, dst, W, L, dx, dy, section_rows=30000, row_guard=32767,
+                                src_row0=0, src_rows=None, out_row0=0, out_rows=None):
+        src_rows = L if src_rows is None else src_rows
+        out_rows = L if out_rows is None else out_rows
+        self._ck(self.lib.oip_remap_shift_bicubic_u16(self.h, _ptr(src), src_row0, src_rows, _ptr(dst), out_row0,
+                                                      out_rows, W, L, dx, dy, section_rows, row_guard))
+
+    def align_mss_bicubic_u16x4(self, planes, plane_stride, dst, Wb, Lm, cx, cy, lines_per_section=20000,
+                                line_offset=0, overlap=520, keep_leading=False, min_lines=1500,
+                                src_row0=0, src_rows=None, out_row0=0, out_rows=None):
+        cx, cy = _dbl(cx, 8), _dbl(cy, 12)
+        src_rows = Lm if src_rows is None else src_rows
+        total = Lm - line_offset - (0 if keep_leading else overlap)
+        out_rows = total if out_rows is None else out_rows
+        valid = C.c_long()
+        self._ck(self.lib.oip_align_mss_bicubic_u16x4(self.h, _ptr(planes), plane_stride, src_row0, src_rows,
+                                                      _ptr(dst), out_row0, out_rows, Wb, Lm,
+                                                      cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp),
+                                                      lines_per_section, line_offset, overlap, int(keep_leading),
+                                                      min_lines, C.byref(valid)))
+        return valid.value
+
+    def stitch_rows_u16(self, left, right, out, W, L, fold):
+        self._ck(self.lib.oip_stitch_rows_u16(self.h, _ptr(left), _ptr(right), _ptr(out), W, L, fold))
+
+    # -- instrumentation
+    def profile_enable(self, on=True):
+        self._ck(self.lib.oip_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.lib.oip_profile_reset(self.h))
+
+    def profile(self):
+        out = {}
+        n = self.lib.oip_profile_count(self.h)
+        for i in range(n):
+            name = C.create_string_buffer(128)
+            ms, cnt = _d(), _l()
+            self._ck(self.lib.oip_profile_get(self.h, i, name, 128, C.byref(ms), C.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out

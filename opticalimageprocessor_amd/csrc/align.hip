@@ -1,0 +1,264 @@
+// align.hip -- inter-band (PAN<->MSS) bicubic alignment of the 4 MSS bands on gfx950.
+//
+// Replaces PreProcessor::DoInterBandAlignment, outer (preproc.h:351-425) and inner
+// (preproc.h:428-468): per 20000-line section and per band the reference builds two float
+// maps from the fitted polynomials, calls cv::remap(INTER_CUBIC, BORDER_CONSTANT), merges
+// the four planes with cv::merge and memcpy's the section minus its leading overlap into
+// the final 16UC4 image.  Here one kernel does all of it per output pixel:
+//   mapX = (float)((cX1*xx + cX0 + xx)/4)                     xx = 4x   (fp64, left to right)
+//   mapY = (float)((cY2*xx*xx + cY1*xx + cY0 + yy)/4)         yy = 4y, y section relative
+// evaluated in fp64 in registers (never stored), OpenCV's 1/32-px bicubic on each planar
+// band, and one 8-byte interleaved store (B0,B1,B2,B3) -- 4 x 2 B read + 8 B written per
+// output pixel.  Lines of skipped tail sections are written as zeros (the reference leaves
+// them uninitialised, SURVEY App.B-6).
+#include "oip_bicubic.h"
+#include "oip_geom.h"
+#include "oip_internal.h"
+
+#include <cmath>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct AlignRow {
+    int valid;      // 0: line of a skipped section -> zeros
+    int yrel;       // section-relative line
+    int base;       // section's first MSS line relative to d_planes' first line
+    int lines;      // section's line count (cv::remap source height)
+};
+
+struct AlignCoef {
+    double cx[4][2];
+    double cy[4][3];
+};
+
+__global__ void align_rows_kernel(AlignRow *rows, OipAlignGeom g, long out_row0, long out_rows, long src_row0)
+{
+    long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= out_rows) return;
+    AlignRow a;
+    int sec;
+    long yrel, off, lines;
+    if (oip_align_row(g, out_row0 + r, &sec, &yrel, &off, &lines)) {
+        a.valid = 1; a.yrel = (int)yrel; a.base = (int)(off - src_row0); a.lines = (int)lines;
+    } else {
+        a.valid = 0; a.yrel = 0; a.base = 0; a.lines = 0;
+    }
+    rows[r] = a;
+}
+
+__global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
+                                                           long src_rows, uint16_t *__restrict__ dst,
+                                                           const AlignRow *__restrict__ rows, int Wb, long out_rows,
+                                                           AlignCoef co, const float *__restrict__ tab1d,
+                                                           int rows_per_block)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= Wb) return;
+    const int xx = x * 4;
+    const double dxx = (double)xx;
+    // per band: column-only part of the maps (preproc.h:447-448)
+    int ix[4], fx[4];
+    double coly[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        double mx = __dadd_rn(__dadd_rn(__dmul_rn(co.cx[b][1], dxx), co.cx[b][0]), dxx) * 0.25;
+        int sx = oip_cvround((float)mx * 32.0f);
+        ix[b] = oip_sat_short(sx >> 5) - 1;
+        fx[b] = sx & 31;
+        coly[b] = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(co.cy[b][2], dxx), dxx), __dmul_rn(co.cy[b][1], dxx)), co.cy[b][0]);
+    }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    for (long r = r0; r < r1; ++r) {
+        const AlignRow a = rows[r];
+        unsigned short res[4] = {0, 0, 0, 0};
+        if (a.valid) {
+            const double yy = (double)((long)a.yrel * 4);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                double my = __dadd_rn(coly[b], yy) * 0.25;
+                int sy = oip_cvround((float)my * 32.0f);
+                int iy = oip_sat_short(sy >> 5) - 1;
+                int fy = sy & 31;
+                const int cix = ix[b];
+                float sum;
+                if (cix >= Wb || cix + 4 <= 0 || iy >= a.lines || iy + 4 <= 0) {
+                    sum = 0.f;
+                } else {
+                    float wx[4], wy[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { wx[j] = tab1d[fx[b] * 4 + j]; wy[j] = tab1d[fy * 4 + j]; }
+                    unsigned xmask = 0, ymask = 0;
+                    float v[4][4];
+                    const uint16_t *pl = planes + (size_t)b * plane_stride;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        int rr = iy + t;
+                        long lr = (long)a.base + rr;
+                        bool yok = rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows;
+                        if (yok) ymask |= 1u << t;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            int cj = cix + j;
+                            bool xok = cj >= 0 && cj < Wb;
+                            if (t == 0 && xok) xmask |= 1u << j;
+                            v[t][j] = (yok && xok) ? (float)pl[lr * Wb + cj] : 0.f;
+                        }
+                    }
+                    const bool inside = (unsigned)cix < (unsigned)(Wb - 3 > 0 ? Wb - 3 : 0) &&
+                                        (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0);
+                    sum = inside ? oip_bicubic_interior(v, wx, wy) : oip_bicubic_border(v, wx, wy, xmask, ymask);
+                }
+                res[b] = (unsigned short)oip_sat_u16(sum);
+            }
+        }
+        uint2 o;
+        o.x = (unsigned)res[0] | ((unsigned)res[1] << 16);
+        o.y = (unsigned)res[2] | ((unsigned)res[3] << 16);
+        *reinterpret_cast<uint2 *>(dst + ((size_t)r * Wb + x) * 4) = o;
+    }
+}
+
+// host mirror of the kernel's first-tap line for one band/column/line (range queries)
+inline int host_iy(const double *cy3, int x, long yrel)
+{
+    double dxx = (double)(x * 4);
+    double coly = ((cy3[2] * dxx) * dxx + cy3[1] * dxx) + cy3[0];
+    double my = (coly + (double)(yrel * 4)) * 0.25;
+    int sy = (int)rintf((float)my * 32.0f);
+    int iy = sy >> 5;
+    iy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+    return iy - 1;
+}
+
+}  // namespace
+
+// MSS source lines needed by a window of output lines.  mapY is quadratic in the column, so
+// its extremes over a line are at the ends or at the vertex; they are evaluated per band and
+// widened by one line for the f32 rounding of the map.
+extern "C" int oip_align_mss_src_range(long out_row0, long out_rows, long Lm, const double *cy, int Wb,
+                                       int lines_per_section, int line_offset, int overlap, int keep_leading,
+                                       int min_lines, long *first, long *last)
+{
+    if (!cy || Wb <= 0 || out_rows < 0 || out_row0 < 0) return OIP_E_INVALID;
+    OipAlignGeom g = oip_align_geom(Wb, Lm, lines_per_section, line_offset, overlap, keep_leading, min_lines);
+    if (out_row0 + out_rows > g.out_rows) return OIP_E_INVALID;
+    long lo = -1, hi = -1;
+    // candidate columns: ends and the vertex of each band's parabola
+    int cand[4][3];
+    for (int b = 0; b < 4; ++b) {
+        const double *c = cy + b * 3;
+        cand[b][0] = 0;
+        cand[b][1] = Wb - 1;
+        int xv = 0;
+        if (c[2] != 0.0) {
+            double v = -c[1] / (2.0 * c[2]) / 4.0;
+            xv = v < 0 ? 0 : (v > Wb - 1 ? Wb - 1 : (int)v);
+        }
+        cand[b][2] = xv;
+    }
+    auto accum = [&](long orow) {
+        int sec;
+        long yrel, off, lines;
+        if (!oip_align_row(g, orow, &sec, &yrel, &off, &lines)) return;
+        for (int b = 0; b < 4; ++b)
+            for (int k = 0; k < 3; ++k)
+                for (int dxc = -1; dxc <= 1; ++dxc) {
+                    int x = cand[b][k] + dxc;
+                    if (x < 0 || x >= Wb) continue;
+                    int iy = host_iy(cy + b * 3, x, yrel);
+                    long r_lo = iy - 1, r_hi = iy + 4 + 1;          // widened by one line each side
+                    if (r_lo < 0) r_lo = 0;
+                    if (r_hi > lines) r_hi = lines;
+                    if (r_lo >= r_hi) continue;
+                    if (lo < 0 || off + r_lo < lo) lo = off + r_lo;
+                    if (off + r_hi > hi) hi = off + r_hi;
+                }
+    };
+    // tap lines are monotone in the output line inside one section: end points suffice
+    long a = out_row0, bnd = out_row0 + out_rows;
+    long r = a;
+    while (r < bnd) {
+        int sec;
+        long yrel, off, lines;
+        if (!oip_align_row(g, r, &sec, &yrel, &off, &lines)) break;   // zero tail from here on
+        long sec_end = r + (lines - yrel);                             // first output line of the next section
+        if (g.keep_leading && sec == 0 && r < g.overlap) sec_end = g.overlap + (lines - g.overlap);
+        long e = sec_end < bnd ? sec_end : bnd;
+        accum(r);
+        accum(e - 1);
+        r = e;
+    }
+    if (lo < 0) lo = hi = 0;
+    if (first) *first = lo;
+    if (last) *last = hi;
+    return OIP_OK;
+}
+
+extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_planes, size_t plane_stride, long src_row0,
+                                           long src_rows, uint16_t *d_dst, long out_row0, long out_rows, int Wb,
+                                           long Lm, const double *cx, const double *cy, int lines_per_section,
+                                           int line_offset, int overlap, int keep_leading, int min_lines,
+                                           long *rows_valid)
+{
+    OIP_CHECK_CTX(ctx);
+    if (!d_planes || !d_dst || !cx || !cy || Wb <= 0 || Lm <= 0)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_align_mss_bicubic_u16x4: bad argument");
+    // preproc.h:355-367
+    if (overlap > OIP_IBPA_MAX_LINEOVERLAP)
+        return oip_fail(ctx, OIP_E_INVALID, "Overlap value %d exceeds maximum allowed value(%d)", overlap, OIP_IBPA_MAX_LINEOVERLAP);
+    if (lines_per_section > 32767) return oip_fail(ctx, OIP_E_INVALID, "Row number exceeds OpenCV allowed value");
+    if (lines_per_section < overlap * 2 || overlap < 0 || lines_per_section <= overlap)
+        return oip_fail(ctx, OIP_E_INVALID, "Lines per section too small or section overlapped lines too large");
+    if (Lm - line_offset < min_lines || line_offset < 0)
+        return oip_fail(ctx, OIP_E_INVALID, "Too few image lines left to process");
+    if (Wb > 32767) return oip_fail(ctx, OIP_E_INVALID, "cv::remap cannot address more than 32767 columns");
+    for (int i = 0; i < 8; ++i) if (!(cx[i] == cx[i])) return oip_fail(ctx, OIP_E_INVALID, "NaN polynomial coefficient");
+    for (int i = 0; i < 12; ++i) if (!(cy[i] == cy[i])) return oip_fail(ctx, OIP_E_INVALID, "NaN polynomial coefficient");
+    OipAlignGeom g = oip_align_geom(Wb, Lm, lines_per_section, line_offset, overlap, keep_leading, min_lines);
+    if (rows_valid) *rows_valid = g.rows_valid;
+    if (out_row0 < 0 || out_rows < 0 || out_row0 + out_rows > g.out_rows || src_row0 < 0 || src_rows < 0 ||
+        src_row0 + src_rows > Lm)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_align_mss_bicubic_u16x4: row window outside the raster");
+    if (plane_stride < (size_t)src_rows * Wb) return oip_fail(ctx, OIP_E_INVALID, "plane_stride too small");
+    if (out_rows == 0) return OIP_OK;
+    if (src_row0 != 0 || src_rows != Lm) {
+        long first = 0, last = 0;
+        int rc = oip_align_mss_src_range(out_row0, out_rows, Lm, cy, Wb, lines_per_section, line_offset, overlap,
+                                         keep_leading, min_lines, &first, &last);
+        if (rc) return oip_fail(ctx, rc, "oip_align_mss_bicubic_u16x4: bad row window");
+        if (first < src_row0 || last > src_row0 + src_rows)
+            return oip_fail(ctx, OIP_E_INVALID,
+                            "oip_align_mss_bicubic_u16x4: source window [%ld,%ld) lacks halo lines, need [%ld,%ld)",
+                            src_row0, src_row0 + src_rows, first, last);
+    }
+    void *ws = nullptr;
+    int rc = oip_workspace(ctx, (size_t)out_rows * sizeof(AlignRow), &ws);
+    if (rc) return rc;
+    AlignRow *rows = reinterpret_cast<AlignRow *>(ws);
+    {
+        OipProfScope prof(ctx, "align_mss_rows");
+        int blocks = (int)((out_rows + 255) / 256);
+        hipLaunchKernelGGL(align_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, g, out_row0, out_rows, src_row0);
+    }
+    AlignCoef co;
+    memcpy(co.cx, cx, sizeof co.cx);
+    memcpy(co.cy, cy, sizeof co.cy);
+    {
+        OipProfScope prof(ctx, "align_mss_bicubic_u16x4");
+        int gx = (Wb + kBlock - 1) / kBlock;
+        long want = (long)ctx->cu_count * 16 / gx;
+        if (want < 1) want = 1;
+        long rpb = (out_rows + want - 1) / want;
+        if (rpb < 8) rpb = 8;
+        long gy = (out_rows + rpb - 1) / rpb;
+        if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
+        hipLaunchKernelGGL(align_mss_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
+                           src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpb);
+    }
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}

@@ -1,0 +1,101 @@
+// oip_internal.h -- shared by the translation units of liboipgpu.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "oip_c.h"
+
+struct oip_prof_entry {
+    std::string name;
+    double total_ms = 0.0;
+    long launches = 0;
+};
+struct oip_prof_pending {
+    int entry;
+    hipEvent_t e0, e1;
+};
+
+struct oip_fft_state;   // fft.hip
+
+struct oip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    char err[1024] = {0};
+    int cu_count = 256;
+
+    // bicubic 1-D coefficient table (32 phases x 4 taps, f32) in HBM
+    float *d_tab1d = nullptr;
+
+    // scratch for small host<->device results
+    void *d_small = nullptr;       // 64 KiB device scratch
+    void *h_small = nullptr;       // 64 KiB pinned host scratch
+
+    // growable device workspace (FFT planes, windows)
+    void *d_work = nullptr;
+    size_t work_bytes = 0;
+
+    // pinned staging for oip_rrc_u16_host
+    void *h_stage[2] = {nullptr, nullptr};
+    void *d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipStream_t stage_stream[2] = {nullptr, nullptr};
+
+    oip_fft_state *fft = nullptr;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<oip_prof_entry> prof;
+    std::vector<oip_prof_pending> prof_pending;
+};
+
+int oip_fail(oip_ctx *ctx, int code, const char *fmt, ...);
+int oip_prof_begin(oip_ctx *ctx, const char *name);   // returns pending index or -1
+void oip_prof_end(oip_ctx *ctx, int pending);
+int oip_workspace(oip_ctx *ctx, size_t bytes, void **out);   // grow-only workspace
+void oip_fft_destroy(oip_ctx *ctx);
+
+#define OIP_HIP(ctx, call)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess)                                                          \
+            return oip_fail((ctx), OIP_E_DEVICE, "%s failed: %s (%s:%d)", #call,        \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                \
+    } while (0)
+
+#define OIP_CHECK_CTX(ctx)                                                              \
+    do {                                                                                \
+        if (!(ctx)) return OIP_E_INVALID;                                               \
+    } while (0)
+
+// scoped profiling region around one or more launches
+struct OipProfScope {
+    oip_ctx *ctx;
+    int id;
+    OipProfScope(oip_ctx *c, const char *name) : ctx(c), id(oip_prof_begin(c, name)) {}
+    ~OipProfScope() { oip_prof_end(ctx, id); }
+};
+
+// ---- device helpers shared by the resampling kernels -----------------------------------
+// OpenCV cvRound(float): round half to even; v_rndne_f32 + v_cvt_i32_f32
+__device__ __forceinline__ int oip_cvround(float v) { return (int)__builtin_rintf(v); }
+
+__device__ __forceinline__ int oip_sat_short(int v)
+{
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}
+
+// saturate_cast<ushort>(float) = clamp(cvRound(v), 0, 65535)
+__device__ __forceinline__ unsigned oip_sat_u16(float v)
+{
+    int iv = oip_cvround(v);
+    iv = iv < 0 ? 0 : (iv > 65535 ? 65535 : iv);
+    return (unsigned)iv;
+}

@@ -1,0 +1,329 @@
+// rrc.hip -- relative radiometric correction on gfx950.
+//
+// Replaces IMO::InplaceRRC (imageop.h:129-138) and, fused with the BIL split of
+// PreProcessor::LoadMSS (preproc.h:62-75), PreProcessor::DoRRC4MSS (preproc.h:202-222).
+//
+//   dst = (uint16_t)(k[x] * src + b[x])            -- fp64, two roundings, no FMA
+//
+// Layout / mapping.  HBM-bound: 2 B read + 2 B written per pixel.  A lane owns V
+// consecutive columns (V=8: one 16-byte access, V=4: one 8-byte access), keeps their V
+// (k,b) pairs in VGPRs and walks down the rows of its row block, ROWS_IN_FLIGHT rows at a
+// time so every lane has that many independent 16-byte loads outstanding.  A wave touches
+// 64*V*2 B = 1 KiB of contiguous line per row; a 256-thread block 4 KiB.  blockIdx.x runs
+// along the line, blockIdx.y over row blocks; the grid is sized to several blocks per CU.
+// No LDS: there is no reuse beyond the LUT, which lives in registers.
+//
+// Conversion.  The reference's double->uint16_t cast is what x86-64 compilers emit for it:
+// cvttsd2si (32-bit, truncating; 0x80000000 when out of range or NaN) followed by a 16-bit
+// truncation.  v_cvt_i32_f64 truncates the same way but saturates, so only the positive
+// overflow case needs a select (negative overflow and NaN already give low half 0).
+#include "oip_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRowsInFlight = 4;
+
+__device__ __forceinline__ unsigned rrc_px(double k, double b, unsigned s)
+{
+    double v = __dadd_rn(__dmul_rn(k, (double)s), b);
+    int t = (v < 2147483648.0) ? (int)v : 0;      // NaN compares false -> 0
+    return (unsigned)t & 0xffffu;
+}
+
+template <int V> struct Vec;
+template <> struct Vec<8> { using type = uint4; };
+template <> struct Vec<4> { using type = uint2; };
+
+template <int V>
+__device__ __forceinline__ typename Vec<V>::type rrc_vec(typename Vec<V>::type in, const double *k, const double *b)
+{
+    unsigned w[V / 2];
+    const unsigned *p = reinterpret_cast<const unsigned *>(&in);
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) {
+        unsigned lo = rrc_px(k[2 * i], b[2 * i], p[i] & 0xffffu);
+        unsigned hi = rrc_px(k[2 * i + 1], b[2 * i + 1], p[i] >> 16);
+        w[i] = lo | (hi << 16);
+    }
+    typename Vec<V>::type out;
+    unsigned *q = reinterpret_cast<unsigned *>(&out);
+#pragma unroll
+    for (int i = 0; i < V / 2; ++i) q[i] = w[i];
+    return out;
+}
+
+// planar raster, column-owned.  src may alias dst (in-place, as the reference).
+template <int V>
+__global__ __launch_bounds__(kBlock) void rrc_u16_kernel(const uint16_t *src, uint16_t *dst, int w, long h,
+                                                         const double2 *__restrict__ kb, long rows_per_block)
+{
+    using VT = typename Vec<V>::type;
+    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * V;
+    if (x0 >= w) return;
+    double k[V], b[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        double2 p = kb[x0 + i];
+        k[i] = p.x;
+        b[i] = p.y;
+    }
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > h) r1 = h;
+    const uint16_t *s = src + r0 * (long)w + x0;
+    uint16_t *d = dst + r0 * (long)w + x0;
+    long r = r0;
+    for (; r + kRowsInFlight <= r1; r += kRowsInFlight) {
+        VT v[kRowsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) v[u] = *reinterpret_cast<const VT *>(s + (long)u * w);
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) *reinterpret_cast<VT *>(d + (long)u * w) = rrc_vec<V>(v[u], k, b);
+        s += (long)kRowsInFlight * w;
+        d += (long)kRowsInFlight * w;
+    }
+    for (; r < r1; ++r) {
+        VT v = *reinterpret_cast<const VT *>(s);
+        *reinterpret_cast<VT *>(d) = rrc_vec<V>(v, k, b);
+        s += w;
+        d += w;
+    }
+}
+
+// any width / alignment: one pixel per lane over the flat raster
+__global__ __launch_bounds__(kBlock) void rrc_u16_scalar_kernel(const uint16_t *src, uint16_t *dst, int w, long n,
+                                                                const double2 *__restrict__ kb)
+{
+    long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; i < n; i += stride) {
+        int x = (int)(i % w);
+        double2 p = kb[x];
+        dst[i] = (uint16_t)rrc_px(p.x, p.y, src[i]);
+    }
+}
+
+// BIL MSS line (4 bands x bw px) -> 4 planar bands, RRC applied on the way (kb indexed by
+// BIL column == band*bw + column-in-band).  A lane owns 8 BIL columns; each 4-pixel half
+// lies inside one band because bw % 4 == 0, and goes out as one 8-byte store.
+template <bool RRC>
+__global__ __launch_bounds__(kBlock) void mss_split_rrc_kernel(const uint16_t *__restrict__ bil,
+                                                               uint16_t *__restrict__ planes, size_t plane_stride,
+                                                               int w, int bw, long lines,
+                                                               const double2 *__restrict__ kb, long rows_per_block)
+{
+    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (x0 >= w) return;
+    double k[8], b[8];
+    if (RRC) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double2 p = kb[x0 + i];
+            k[i] = p.x;
+            b[i] = p.y;
+        }
+    }
+    const int band0 = x0 / bw, band1 = (x0 + 4) / bw;
+    uint16_t *d0 = planes + (size_t)band0 * plane_stride + (x0 - band0 * bw);
+    uint16_t *d1 = planes + (size_t)band1 * plane_stride + (x0 + 4 - band1 * bw);
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > lines) r1 = lines;
+    const uint16_t *s = bil + r0 * (long)w + x0;
+    d0 += r0 * (long)bw;
+    d1 += r0 * (long)bw;
+    long r = r0;
+    for (; r + kRowsInFlight <= r1; r += kRowsInFlight) {
+        uint4 v[kRowsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) v[u] = *reinterpret_cast<const uint4 *>(s + (long)u * w);
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+            uint4 o = RRC ? rrc_vec<8>(v[u], k, b) : v[u];
+            *reinterpret_cast<uint2 *>(d0 + (long)u * bw) = make_uint2(o.x, o.y);
+            *reinterpret_cast<uint2 *>(d1 + (long)u * bw) = make_uint2(o.z, o.w);
+        }
+        s += (long)kRowsInFlight * w;
+        d0 += (long)kRowsInFlight * bw;
+        d1 += (long)kRowsInFlight * bw;
+    }
+    for (; r < r1; ++r) {
+        uint4 v = *reinterpret_cast<const uint4 *>(s);
+        uint4 o = RRC ? rrc_vec<8>(v, k, b) : v;
+        *reinterpret_cast<uint2 *>(d0) = make_uint2(o.x, o.y);
+        *reinterpret_cast<uint2 *>(d1) = make_uint2(o.z, o.w);
+        s += w;
+        d0 += bw;
+        d1 += bw;
+    }
+}
+
+template <bool RRC>
+__global__ __launch_bounds__(kBlock) void mss_split_rrc_scalar_kernel(const uint16_t *__restrict__ bil,
+                                                                      uint16_t *__restrict__ planes,
+                                                                      size_t plane_stride, int w, int bw, long n,
+                                                                      const double2 *__restrict__ kb)
+{
+    long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; i < n; i += stride) {
+        long row = i / w;
+        int x = (int)(i - row * w);
+        int band = x / bw;
+        if (band > 3) continue;             // w % 4 != 0: trailing pixels belong to no band
+        unsigned v = bil[i];
+        if (RRC) {
+            double2 p = kb[x];
+            v = rrc_px(p.x, p.y, v);
+        }
+        planes[(size_t)band * plane_stride + row * bw + (x - band * bw)] = (uint16_t)v;
+    }
+}
+
+// grid.y so that the launch has ~16 blocks per CU while each block keeps >= 64 rows
+inline void row_blocks(const oip_ctx *ctx, int gx, long h, long *rows_per_block, int *gy)
+{
+    long want = (long)ctx->cu_count * 16 / (gx > 0 ? gx : 1);
+    if (want < 1) want = 1;
+    long rpb = (h + want - 1) / want;
+    if (rpb < 64) rpb = 64;
+    rpb = (rpb + kRowsInFlight - 1) / kRowsInFlight * kRowsInFlight;
+    long g = (h + rpb - 1) / rpb;
+    if (g < 1) g = 1;
+    if (g > 65535) { g = 65535; rpb = (h + g - 1) / g; rpb = (rpb + kRowsInFlight - 1) / kRowsInFlight * kRowsInFlight; g = (h + rpb - 1) / rpb; }
+    *rows_per_block = rpb;
+    *gy = (int)g;
+}
+
+}  // namespace
+
+extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, long h, const double *d_kb)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16: bad argument");
+    if (h == 0) return OIP_OK;
+    OipProfScope prof(ctx, "rrc_u16");
+    const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
+    const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
+    if (w % 8 == 0 && (align & 15) == 0) {
+        int gx = (w / 8 + kBlock - 1) / kBlock, gy;
+        long rpb;
+        row_blocks(ctx, gx, h, &rpb, &gy);
+        hipLaunchKernelGGL(rrc_u16_kernel<8>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, h, kb, rpb);
+    } else if (w % 4 == 0 && (align & 7) == 0) {
+        int gx = (w / 4 + kBlock - 1) / kBlock, gy;
+        long rpb;
+        row_blocks(ctx, gx, h, &rpb, &gy);
+        hipLaunchKernelGGL(rrc_u16_kernel<4>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, h, kb, rpb);
+    } else {
+        long n = (long)w * h;
+        long blocks = (n + kBlock - 1) / kBlock;
+        long cap = (long)ctx->cu_count * 32;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(rrc_u16_scalar_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, n, kb);
+    }
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
+
+extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16_t *d_planes, size_t plane_stride,
+                                     int w, long lines, const double *d_kb4)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || lines < 0 || !d_bil || !d_planes) return oip_fail(ctx, OIP_E_INVALID, "oip_mss_split_rrc_u16: bad argument");
+    const int bw = w / OIP_MSS_BANDS;
+    if (bw <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_mss_split_rrc_u16: line narrower than 4 pixels");
+    if (plane_stride < (size_t)bw * (size_t)lines) return oip_fail(ctx, OIP_E_INVALID, "oip_mss_split_rrc_u16: plane_stride too small");
+    if (lines == 0) return OIP_OK;
+    OipProfScope prof(ctx, "mss_split_rrc_u16");
+    const double2 *kb = reinterpret_cast<const double2 *>(d_kb4);
+    const bool fast = (w % 8 == 0) && (bw % 4 == 0) && (w == bw * 4) && (((uintptr_t)d_bil & 15) == 0) &&
+                      (((uintptr_t)d_planes & 7) == 0) && (plane_stride % 4 == 0);
+    if (fast) {
+        int gx = (w / 8 + kBlock - 1) / kBlock, gy;
+        long rpb;
+        row_blocks(ctx, gx, lines, &rpb, &gy);
+        if (kb)
+            hipLaunchKernelGGL(mss_split_rrc_kernel<true>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_bil, d_planes,
+                               plane_stride, w, bw, lines, kb, rpb);
+        else
+            hipLaunchKernelGGL(mss_split_rrc_kernel<false>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_bil, d_planes,
+                               plane_stride, w, bw, lines, kb, rpb);
+    } else {
+        long n = (long)w * lines;
+        long blocks = (n + kBlock - 1) / kBlock;
+        long cap = (long)ctx->cu_count * 32;
+        if (blocks > cap) blocks = cap;
+        if (kb)
+            hipLaunchKernelGGL(mss_split_rrc_scalar_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                               d_bil, d_planes, plane_stride, w, bw, n, kb);
+        else
+            hipLaunchKernelGGL(mss_split_rrc_scalar_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream,
+                               d_bil, d_planes, plane_stride, w, bw, n, kb);
+    }
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
+
+// Host-buffer form of InplaceRRC: the caller's heap buffer is corrected in place through
+// two pinned staging blocks and two device blocks on two streams, so the H2D copy of block
+// i+1, the kernel of block i and the D2H copy of block i-1 overlap.
+extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb_host)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || h < 0 || !buff || !kb_host) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16_host: bad argument");
+    if (h == 0) return OIP_OK;
+    OIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t row_bytes = (size_t)w * 2;
+    size_t block_bytes = (size_t)64 << 20;
+    long rows_per_chunk = (long)(block_bytes / row_bytes);
+    if (rows_per_chunk < 1) rows_per_chunk = 1;
+    if (rows_per_chunk > h) rows_per_chunk = h;
+    block_bytes = (size_t)rows_per_chunk * row_bytes;
+    if (ctx->stage_bytes < block_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_stage[i]) OIP_HIP(ctx, hipHostFree(ctx->h_stage[i]));
+            if (ctx->d_stage[i]) OIP_HIP(ctx, hipFree(ctx->d_stage[i]));
+            ctx->h_stage[i] = ctx->d_stage[i] = nullptr;
+            OIP_HIP(ctx, hipHostMalloc(&ctx->h_stage[i], block_bytes, hipHostMallocDefault));
+            OIP_HIP(ctx, hipMalloc(&ctx->d_stage[i], block_bytes));
+            if (!ctx->stage_stream[i]) OIP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stage_stream[i], hipStreamNonBlocking));
+        }
+        ctx->stage_bytes = block_bytes;
+    }
+    double *d_kb = nullptr;
+    OIP_HIP(ctx, hipMalloc((void **)&d_kb, (size_t)w * 16));
+    OIP_HIP(ctx, hipMemcpy(d_kb, kb_host, (size_t)w * 16, hipMemcpyHostToDevice));
+    hipStream_t saved = ctx->stream;
+    int rc = OIP_OK;
+    long nchunks = (h + rows_per_chunk - 1) / rows_per_chunk;
+    // chunk c uses slot c&1; before reusing a slot, drain it back into the caller's buffer
+    for (long c = 0; c < nchunks + 2 && rc == OIP_OK; ++c) {
+        int slot = (int)(c & 1);
+        if (c >= 2) {
+            long pc = c - 2;
+            long r0 = pc * rows_per_chunk;
+            long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
+            if (hipStreamSynchronize(ctx->stage_stream[slot]) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "stage sync failed"); break; }
+            memcpy(buff + r0 * (long)w, ctx->h_stage[slot], (size_t)n * row_bytes);
+        }
+        if (c < nchunks) {
+            long r0 = c * rows_per_chunk;
+            long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
+            memcpy(ctx->h_stage[slot], buff + r0 * (long)w, (size_t)n * row_bytes);
+            hipStream_t st = ctx->stage_stream[slot];
+            if (hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], (size_t)n * row_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "H2D failed"); break; }
+            ctx->stream = st;
+            rc = oip_rrc_u16(ctx, (uint16_t *)ctx->d_stage[slot], (uint16_t *)ctx->d_stage[slot], w, n, d_kb);
+            ctx->stream = saved;
+            if (rc != OIP_OK) break;
+            if (hipMemcpyAsync(ctx->h_stage[slot], ctx->d_stage[slot], (size_t)n * row_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H failed"); break; }
+        }
+    }
+    ctx->stream = saved;
+    hipStreamSynchronize(ctx->stage_stream[0]);
+    hipStreamSynchronize(ctx->stage_stream[1]);
+    hipFree(d_kb);
+    return rc;
+}

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """The CPU checker (oracle/).  Built on demand; tests are the only importer besides
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+    import oracle
+    oracle.lib()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One oip context on cuda:0 through the C ABI.  Fails (does not skip) when the HIP
+    library is missing: GPU tests must never pass on a fallback."""
+    import torch
+    import opticalimageprocessor_amd as oip
+    assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
+    c = oip.Context(0)
+    yield c
+    c.close()

@@ -1,0 +1,328 @@
+"""GPU parity: RRC, MSS split, constant-shift remap, inter-band align, RAW stitch.
+
+Every test drives liboipgpu.so through the C ABI (opticalimageprocessor_amd.Context) on
+cuda:0 and compares with the CPU oracle on the same seeded inputs.
+
+Bars
+  * RRC / MSS split / stitch: integer work, bit-exact.
+  * remap / align (the float resampling path): the north star allows 1 ULP per pixel; the
+    kernels reproduce OpenCV's f32 operation order, so the tests demand bit-exact output
+    and only report the tolerance (MAX_DN = 0) in one place.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MAX_DN = 0   # allowed |GPU - oracle| in digital numbers for the resampling kernels
+
+
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _u16(t):
+    # torch has no uint16 arithmetic but can carry the bytes
+    return t.cpu().numpy()
+
+
+def _rng(seed):
+    return np.random.default_rng(0x0A11CE + seed)
+
+
+def _lut(rng, w):
+    k = np.round(rng.uniform(0.9, 1.1, w), 6)
+    b = np.round(rng.uniform(-8, 8, w), 4)
+    return np.stack([k, b], 1)
+
+
+# ------------------------------------------------------------------------------------ RRC
+@pytest.mark.parametrize("w,h", [(4096, 64), (30000, 37), (7500, 33), (12288, 8), (1001, 17), (8, 1), (3, 5)])
+def test_rrc_matches_oracle(ctx, oracle_mod, w, h):
+    import torch
+    rng = _rng(w * 131 + h)
+    img = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    kb = _lut(rng, w)
+    # adversarial columns: wrap, negative, huge, NaN, truncation boundary
+    special = [(1.5015, 0.0), (-1.0, 0.0), (1.0, -90.0), (1.0, 70000.0), (3e5, 0.0), (1e9, 0.0), (-1e9, 0.0),
+               (float("nan"), 0.0), (1.0, 0.999999999), (0.0, 65535.99999), (0.0, 2147483647.5), (0.0, 2147483648.0),
+               (0.0, -2147483648.5), (0.0, -2147483649.0), (1.0, float("inf")), (0.0, -0.9999)]
+    for i, (k, b) in enumerate(special[: max(0, min(len(special), w))]):
+        kb[i] = (k, b)
+    want = oracle_mod.rrc(img, kb)
+    d_kb = ctx.upload_kb(kb)
+    src = _cuda(img)
+    dst = torch.empty_like(src)
+    ctx.rrc_u16(src, dst, w, h, d_kb)      # out of place
+    ctx.sync()
+    assert np.array_equal(_u16(dst), want)
+    ctx.rrc_u16(src, src, w, h, d_kb)      # in place, as IMO::InplaceRRC
+    ctx.sync()
+    assert np.array_equal(_u16(src), want)
+
+
+def test_rrc_golden_fixture(ctx):
+    import os
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rrc_reference.npz"))
+    src = _cuda(g["src"])
+    dst = torch.empty_like(src)
+    h, w = g["src"].shape
+    ctx.rrc_u16(src, dst, w, h, ctx.upload_kb(g["kb"]))
+    ctx.sync()
+    assert np.array_equal(_u16(dst), g["dst"])
+
+
+def test_rrc_unaligned_views(ctx, oracle_mod):
+    """sub-buffers that are only 2-byte aligned take the scalar kernel"""
+    import torch
+    rng = _rng(5)
+    w, h = 1000, 9
+    img = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    kb = _lut(rng, w)
+    base = torch.zeros(h * w + 8, dtype=torch.uint16, device="cuda")
+    view = base[1:1 + h * w]
+    view.copy_(_cuda(img).reshape(-1))
+    ctx.rrc_u16(view, view, w, h, ctx.upload_kb(kb))
+    ctx.sync()
+    assert np.array_equal(_u16(view).reshape(h, w), oracle_mod.rrc(img, kb))
+
+
+def test_rrc_host_buffer(ctx, oracle_mod):
+    rng = _rng(6)
+    w, h = 4096, 20000     # 160 MB -> 3 staged blocks
+    img = rng.integers(0, 4096, (h, w), dtype=np.uint16)
+    kb = _lut(rng, w)
+    want = oracle_mod.rrc(img, kb, threads=8)
+    buf = img.copy()
+    ctx.rrc_u16_host(buf, kb)
+    assert np.array_equal(buf, want)
+
+
+def test_rrc_idempotent_lut_full_size(ctx):
+    """BASELINE config 2 size (30000 x 65536): k=1,b=0 is the identity, k=0,b=c a constant --
+    size-independent properties, no oracle run at this size."""
+    import torch
+    w, h = 30000, 65536
+    g = torch.Generator(device="cuda").manual_seed(7)
+    src = torch.randint(-32768, 32768, (h, w), device="cuda", generator=g, dtype=torch.int32).to(torch.int16).view(torch.uint16)
+    dst = torch.empty_like(src)
+    kb = np.zeros((w, 2)); kb[:, 0] = 1.0
+    ctx.rrc_u16(src, dst, w, h, ctx.upload_kb(kb)); ctx.sync()
+    assert torch.equal(dst.view(torch.int16), src.view(torch.int16))
+    kb[:, 0] = 0.0; kb[:, 1] = np.arange(w) % 65536 + 0.75
+    ctx.rrc_u16(src, dst, w, h, ctx.upload_kb(kb)); ctx.sync()
+    want = torch.from_numpy((np.arange(w) % 65536).astype(np.uint16)).cuda()
+    assert torch.equal(dst.view(torch.int16), want.view(torch.int16).expand(h, w))
+
+
+# ------------------------------------------------------------------------------ MSS split
+@pytest.mark.parametrize("w,lines,rrc", [(12288, 40, True), (30000, 21, True), (30000, 21, False), (4000, 7, True), (1004, 9, True), (1002, 5, True)])
+def test_mss_split_rrc(ctx, oracle_mod, w, lines, rrc):
+    import torch
+    rng = _rng(w + lines)
+    bil = rng.integers(0, 65536, (lines, w), dtype=np.uint16)
+    bw = w // 4
+    kbs = [_lut(rng, bw) for _ in range(4)]
+    bands = oracle_mod.split_mss(bil)
+    if rrc:
+        bands = [oracle_mod.rrc(b, kb) for b, kb in zip(bands, kbs)]
+    stride = bw * lines + 12            # deliberately not the tight size (multiple of 4)
+    planes = torch.zeros(4 * stride, dtype=torch.uint16, device="cuda")
+    d_kb = ctx.upload_kb(np.concatenate(kbs, 0)) if rrc else None
+    ctx.mss_split_rrc_u16(_cuda(bil), planes, stride, w, lines, d_kb)
+    ctx.sync()
+    got = _u16(planes)
+    for b in range(4):
+        assert np.array_equal(got[b * stride:b * stride + bw * lines].reshape(lines, bw), bands[b]), b
+
+
+# ---------------------------------------------------------------------------------- stitch
+@pytest.mark.parametrize("W,L,fold", [(12288, 33, 100), (30000, 17, 100), (1000, 21, 25), (1000, 21, 24), (999, 7, 3), (64, 5, 0), (200, 9, 1)])
+def test_stitch_rows(ctx, oracle_mod, W, L, fold):
+    import torch
+    rng = _rng(W + fold)
+    left = rng.integers(0, 65536, (L, W), dtype=np.uint16)
+    right = rng.integers(0, 65536, (L, W), dtype=np.uint16)
+    want = oracle_mod.stitch_raw(left, right, fold)
+    out = torch.zeros(L, 2 * (W - fold), dtype=torch.uint16, device="cuda")
+    ctx.stitch_rows_u16(_cuda(left), _cuda(right), out, W, L, fold)
+    ctx.sync()
+    assert np.array_equal(_u16(out), want)
+
+
+# ------------------------------------------------------------------- constant-shift remap
+def _scene(rng, L, W):
+    img = rng.integers(64, 4096, (L, W)).astype(np.uint16)
+    img[::97] = 65535      # saturating rows exercise the clamp at bicubic overshoot
+    img[::89] = 0
+    return img
+
+
+SHIFT_CASES = [
+    # W,   L,    dx,      dy,     section_rows, row_guard
+    (96,  700,  3.37,   -1.62,   300, 327),      # negative dy: upper cut
+    (96,  700,  -2.25,  2.4,     300, 327),      # positive dy: bottom cut, short last section (stale tail)
+    (64,  900,  0.0,    0.0,     300, 300),      # identity except seams
+    (80,  601,  5.999,  7.03125, 300, 327),      # phase rounding near integer; last section 1 line over
+    (33,  1000, -40.5,  -12.49,  256, 300),      # big negative shift: left border, large ucut
+    (200, 640,  197.3,  3.0,     320, 327),      # almost everything right of the image
+    (128, 35000, 1.53,  -0.77,   30000, 32767),  # the reference's real constants
+]
+
+
+@pytest.mark.parametrize("W,L,dx,dy,sr,guard", SHIFT_CASES)
+def test_remap_shift_matches_oracle(ctx, oracle_mod, W, L, dx, dy, sr, guard):
+    import torch
+    rng = _rng(int(W * 7 + L))
+    src = _scene(rng, L, W)
+    want, row_off = oracle_mod.prestitch(src, dx, dy, sr, guard)
+    dst = torch.zeros(L, W, dtype=torch.uint16, device="cuda")
+    ctx.remap_shift_bicubic_u16(_cuda(src), dst, W, L, dx, dy, sr, guard)
+    ctx.sync()
+    got = _u16(dst).astype(np.int32)
+    diff = np.abs(got - want.astype(np.int32))
+    assert diff.max() <= MAX_DN, (diff.max(), np.argwhere(diff > MAX_DN)[:5])
+
+
+def test_remap_shift_too_few_rows(ctx):
+    import torch
+    src = torch.zeros(100, 64, dtype=torch.uint16, device="cuda")
+    with pytest.raises(ValueError, match="too few data rows"):
+        ctx.remap_shift_bicubic_u16(src, src.clone(), 64, 100, 1.0, 1.0)   # imageop.h:242-244
+
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_remap_shift_row_shards_equal_whole(ctx, oracle_mod, nshards):
+    """scan-line-block sharding: every shard computes from [halo] lines only and the
+    concatenation equals the unsharded result."""
+    import torch
+    import opticalimageprocessor_amd as oip
+    W, L, dx, dy, sr, guard = 96, 1500, 2.6, 3.3, 300, 327
+    src = _scene(_rng(99), L, W)
+    want, _ = oracle_mod.prestitch(src, dx, dy, sr, guard)
+    got = np.zeros_like(want)
+    for k in range(nshards):
+        o0, o1 = L * k // nshards, L * (k + 1) // nshards
+        s0, s1 = oip.remap_shift_src_range(o0, o1 - o0, L, dy, sr)
+        assert 0 <= s0 <= s1 <= L
+        part = torch.zeros(o1 - o0, W, dtype=torch.uint16, device="cuda")
+        ctx.remap_shift_bicubic_u16(_cuda(src[s0:s1]), part, W, L, dx, dy, sr, guard, src_row0=s0, src_rows=s1 - s0,
+                                    out_row0=o0, out_rows=o1 - o0)
+        ctx.sync()
+        got[o0:o1] = _u16(part)
+    assert np.array_equal(got, want)
+    # a shard without its halo must be refused, not silently wrong
+    with pytest.raises(ValueError, match="halo"):
+        o0, o1 = L // 2, L
+        part = torch.zeros(o1 - o0, W, dtype=torch.uint16, device="cuda")
+        ctx.remap_shift_bicubic_u16(_cuda(src[o0:o1]), part, W, L, dx, dy, sr, guard, src_row0=o0, src_rows=o1 - o0,
+                                    out_row0=o0, out_rows=o1 - o0)
+
+
+def test_remap_integer_shift_is_copy(ctx):
+    """known answer: integer shift == shifted copy with zero border (per section)"""
+    import torch
+    W, L = 64, 400                              # section_rows 390, guard 399: L just passes the guard
+    rng = _rng(3)
+    src = rng.integers(0, 65536, (L, W), dtype=np.uint16)
+    dst = torch.zeros(L, W, dtype=torch.uint16, device="cuda")
+    ctx.remap_shift_bicubic_u16(_cuda(src), dst, W, L, 5.0, 0.0, 390, 399)
+    ctx.sync()
+    got = _u16(dst)
+    assert np.array_equal(got[:380, :W - 5], src[:380, 5:])
+    assert (got[:380, W - 5:] == 0).all()
+
+
+# ------------------------------------------------------------------------ inter-band align
+ALIGN_CASES = [
+    # Wb,  Lm,   lps,  off, ovl, keep, min_lines
+    (75,   900,  400,  0,   52,  False, 150),
+    (75,   900,  400,  0,   52,  True,  150),
+    (64,   1000, 300,  17,  40,  False, 100),
+    (96,   650,  300,  0,   30,  False, 200),     # last section shorter than min_lines: zero tail
+    (3072, 1600, 20000, 0,  520, False, 1500),    # reference constants, single section
+]
+
+
+def _coef(rng, Wb, big=False):
+    W = Wb * 4
+    cx = np.zeros((4, 2)); cy = np.zeros((4, 3))
+    for b in range(4):
+        cx[b] = (rng.uniform(-6, 6), rng.uniform(-2e-4, 2e-4))
+        # dy = c0 + c1*x + c2*x^2, a few PAN pixels of curvature across the line
+        c2 = rng.uniform(-8, 8) / (W * W)
+        cy[b] = (rng.uniform(-9, 9), rng.uniform(-4, 4) / W, c2)
+    if big:
+        cx[0, 0] = -3.0 * W      # band 0 mapped completely off the left edge
+        cy[1, 0] = 5000.0        # band 1 far below its section
+    return cx, cy
+
+
+@pytest.mark.parametrize("Wb,Lm,lps,off,ovl,keep,minl", ALIGN_CASES)
+def test_align_mss_matches_oracle(ctx, oracle_mod, Wb, Lm, lps, off, ovl, keep, minl):
+    import torch
+    rng = _rng(Wb + Lm + int(keep))
+    bands = [_scene(rng, Lm, Wb) for _ in range(4)]
+    cx, cy = _coef(rng, Wb)
+    want, nvalid = oracle_mod.align_mss(bands, cx, cy, lps, off, ovl, keep, minl)
+    planes = _cuda(np.stack(bands, 0))
+    dst = torch.full(want.shape, 7, dtype=torch.uint16, device="cuda")
+    got_valid = ctx.align_mss_bicubic_u16x4(planes, Wb * Lm, dst, Wb, Lm, cx, cy, lps, off, ovl, keep, minl)
+    ctx.sync()
+    assert got_valid == nvalid
+    diff = np.abs(_u16(dst).astype(np.int32) - want.astype(np.int32))
+    assert diff.max() <= MAX_DN, (diff.max(), np.argwhere(diff > MAX_DN)[:5])
+
+
+def test_align_mss_out_of_image_bands(ctx, oracle_mod):
+    import torch
+    Wb, Lm = 80, 500
+    rng = _rng(11)
+    bands = [_scene(rng, Lm, Wb) for _ in range(4)]
+    cx, cy = _coef(rng, Wb, big=True)
+    want, _ = oracle_mod.align_mss(bands, cx, cy, 300, 0, 40, False, 100)
+    dst = torch.zeros(want.shape, dtype=torch.uint16, device="cuda")
+    ctx.align_mss_bicubic_u16x4(_cuda(np.stack(bands, 0)), Wb * Lm, dst, Wb, Lm, cx, cy, 300, 0, 40, False, 100)
+    ctx.sync()
+    assert np.array_equal(_u16(dst), want)
+
+
+def test_align_argument_errors(ctx):
+    import torch
+    planes = torch.zeros(4 * 64 * 2000, dtype=torch.uint16, device="cuda")
+    dst = torch.zeros(2000 * 64 * 4, dtype=torch.uint16, device="cuda")
+    z2, z3 = np.zeros((4, 2)), np.zeros((4, 3))
+    with pytest.raises(ValueError, match="exceeds maximum"):       # preproc.h:355-358
+        ctx.align_mss_bicubic_u16x4(planes, 64 * 2000, dst, 64, 2000, z2, z3, 20000, 0, 3001)
+    with pytest.raises(ValueError, match="OpenCV allowed"):        # preproc.h:359-361
+        ctx.align_mss_bicubic_u16x4(planes, 64 * 2000, dst, 64, 2000, z2, z3, 40000, 0, 520)
+    with pytest.raises(ValueError, match="too small"):             # preproc.h:362-364
+        ctx.align_mss_bicubic_u16x4(planes, 64 * 2000, dst, 64, 2000, z2, z3, 1000, 0, 520)
+    with pytest.raises(ValueError, match="Too few"):               # preproc.h:365-367
+        ctx.align_mss_bicubic_u16x4(planes, 64 * 2000, dst, 64, 2000, z2, z3, 20000, 600, 520)
+
+
+@pytest.mark.parametrize("nshards", [2, 5])
+def test_align_row_shards_equal_whole(ctx, oracle_mod, nshards):
+    import torch
+    import opticalimageprocessor_amd as oip
+    Wb, Lm, lps, ovl, minl = 75, 1200, 400, 52, 150
+    rng = _rng(21)
+    bands = [_scene(rng, Lm, Wb) for _ in range(4)]
+    cx, cy = _coef(rng, Wb)
+    want, _ = oracle_mod.align_mss(bands, cx, cy, lps, 0, ovl, False, minl)
+    R = want.shape[0]
+    got = np.zeros_like(want)
+    stack = np.stack(bands, 0)
+    for k in range(nshards):
+        o0, o1 = R * k // nshards, R * (k + 1) // nshards
+        s0, s1 = oip.align_mss_src_range(o0, o1 - o0, Lm, cy, Wb, lps, 0, ovl, False, minl)
+        sub = np.ascontiguousarray(stack[:, s0:s1])
+        part = torch.zeros(o1 - o0, Wb, 4, dtype=torch.uint16, device="cuda")
+        ctx.align_mss_bicubic_u16x4(_cuda(sub), Wb * (s1 - s0), part, Wb, Lm, cx, cy, lps, 0, ovl, False, minl,
+                                    src_row0=s0, src_rows=s1 - s0, out_row0=o0, out_rows=o1 - o0)
+        ctx.sync()
+        got[o0:o1] = _u16(part)
+    assert np.array_equal(got, want)

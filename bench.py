@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X OpticalImageProcessor hot path.
+
+Metric (BASELINE.json): Mpix/s end-to-end RRC + align/stitch on a 30000 x 100000 x 4 strip,
+with the dominant kernel's fraction of the HBM roofline.
+
+One "step" = one pass of the reference's default action (main.cpp:288-317, with --do-rrc4pan)
+over one synthetic 4-band strip already resident in HBM:
+    RRC of PAN (30000 x L)                          IMO::InplaceRRC           imageop.h:129
+    BIL split + RRC of the 4 MSS bands (7500 x L/4) LoadMSS + DoRRC4MSS       preproc.h:56,202
+    inter-band phase correlation, 5 x 10 x 4 units  CalcInterBandCorrelation  preproc.h:224
+    shift filter + polynomial fit (host)            preproc.h:492-550
+    4-band bicubic alignment -> 16UC4               DoInterBandAlignment      preproc.h:351
+pixels per step = PAN pixels + MSS pixels of all bands = 1.25 * W * L.
+
+N GPUs (`--gpus N`, one rank per GPU under torch.distributed.run): weak scaling -- every rank
+owns a 100000-line block of an N x 100000-line strip (scan-line blocks), correlation
+windows and align halos move point-to-point over RCCL, results are all-gathered.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=30000)
+    ap.add_argument("--lines", type=int, default=100000, help="PAN lines per GPU")
+    ap.add_argument("--slices", type=int, default=10)
+    ap.add_argument("--sections", type=int, default=5)
+    ap.add_argument("--ibc-threshold", type=float, default=0.4)
+    ap.add_argument("--workload", choices=["default", "rrc"], default="default",
+                    help="default: the full 4-band path; rrc: BASELINE config 2 (RRC kernel only, 30000x65536)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+# algorithmic HBM bytes per launch of each kernel, keyed by the name the
+# library's profiler and rocprofv3 both report
+def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
+    mb, Wb = pb // 4, W // 4
+    MN = M * N
+    win = base_rows * base_cols
+    return {
+        "rrc_u16_kernel": 4.0 * W * pb,                       # 2 B read + 2 B written per pixel
+        "mss_split_rrc_kernel": 4.0 * W * mb,
+        "fft_pass_kernel": 16.0 * MN,                         # 8 B read + 8 B written per point
+        "pack_kernel": (8.0 * win * (5.0 / 6.0)) + 8.0 * MN,  # 2,2,1 f32 planes in -> 1 complex out
+        "cross_power_kernel": 8.0 * MN * 3.5,                 # 2 or 3 spectra in, 1 out
+        "peak_partial_kernel": 4.0 * MN,
+        "window_u16_to_f32_kernel": None,                     # mixed sizes: reported as time only
+        "resize_cubic_f32_kernel": 4.0 * win + 4.0 * win / 16.0,
+        "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
+    }
+
+
+def optimal_dft_size(n):
+    best = None
+    p5 = 1
+    while p5 < 2 * n + 1:
+        p35 = p5
+        while p35 < 2 * n + 1:
+            v = p35
+            while v < n:
+                v *= 2
+            best = v if best is None or v < best else best
+            p35 *= 3
+        p5 *= 5
+    return best
+
+
+def cpu_baseline(W, L, slices, sections):
+    """The oracle (CPU restatement; RRC leg through the reference's own loop when oracle/_ref is
+    present) timed on a bounded sample of the same workload and scaled to the full step."""
+    import oracle
+    from oracle import phasecorr as pc
+    from opticalimageprocessor_amd import synth
+    t_all = time.time()
+    rng = np.random.default_rng(1)
+    kb = synth.lut(W)
+    # 1. PAN RRC, 1 thread (the reference as shipped) on W x 4096
+    hs = 4096
+    img = rng.integers(64, 4096, (hs, W), dtype=np.uint16)
+    use_ref = oracle.ref_lib() is not None
+    f = oracle.rrc_reference if use_ref else oracle.rrc
+    best = 1e9
+    for _ in range(3):
+        t = time.time(); f(img, kb); best = min(best, time.time() - t)
+    t_rrc = best * (L / hs)
+    rrc_mpix_1t = W * hs / best / 1e6
+    cores = os.cpu_count() or 1
+    best_mt = 1e9
+    for _ in range(3):
+        t = time.time(); oracle.rrc(img, kb, threads=cores); best_mt = min(best_mt, time.time() - t)
+    rrc_mpix_mt = W * hs / best_mt / 1e6
+    # 2. MSS split + RRC on W x 1024 BIL lines
+    ms = 1024
+    bil = rng.integers(64, 4096, (ms, W), dtype=np.uint16)
+    kb4 = [synth.lut(W // 4, 10 + b) for b in range(4)]
+    t = time.time()
+    bands = oracle.split_mss(bil)
+    bands = [oracle.rrc(b, k) for b, k in zip(bands, kb4)]
+    t_mss = (time.time() - t) * ((L // 4) / ms)
+    # 3. one (section, slice, band) correlation unit at full size
+    base_rows, base_cols = min(L, 16000), W // slices
+    pan = rng.integers(64, 4096, (base_rows, base_cols), dtype=np.uint16)
+    band = rng.integers(64, 4096, (base_rows // 4, base_cols // 4), dtype=np.uint16)
+    t = time.time()
+    a = oracle.window_u16_to_f32(pan, 0, 0, base_rows, base_cols)
+    b = oracle.resize_cubic(oracle.window_u16_to_f32(band, 0, 0, base_rows // 4, base_cols // 4), base_cols, base_rows)
+    pc.phase_correlate(a, b)
+    t_unit = time.time() - t
+    t_corr = t_unit * slices * sections * 4
+    # 4. align on 2048 MSS lines
+    al = 2048
+    bands = [rng.integers(64, 4096, (al, W // 4), dtype=np.uint16) for _ in range(4)]
+    cx = np.tile([2.0, 1e-5], (4, 1)); cy = np.tile([-1.0, 1e-5, -1e-10], (4, 1))
+    t = time.time()
+    oracle.align_mss(bands, cx, cy, 20000, 0, 520, False, 1500)
+    t_align = (time.time() - t) * ((L // 4 - 520) / (al - 520))
+    total = t_rrc + t_mss + t_corr + t_align
+    mpix = 1.25 * W * L / 1e6
+    return {
+        "value": mpix / total, "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": ("oracle (CPU restatement) timed per stage on a bounded sample and scaled to the step: "
+                   "PAN RRC %dx%d via %s, MSS split+RRC %dx%d BIL lines, 1 of %d correlation units at %dx%d "
+                   "(window+resize+phaseCorrelate, numpy FFT), align %d MSS lines; %.1f s of CPU work"
+                   % (W, hs, "oracle/_ref (the reference's own InplaceRRC)" if use_ref else "the restatement", W, ms,
+                      slices * sections * 4, base_rows, base_cols, al, time.time() - t_all)),
+        "stage_seconds_full_step": {"rrc_pan": t_rrc, "mss_split_rrc": t_mss, "correlation": t_corr, "align": t_align},
+        "rrc_reference_1thread_Mpix_s": rrc_mpix_1t,
+        "rrc_all_cores_Mpix_s": rrc_mpix_mt, "rrc_all_cores": cores,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import opticalimageprocessor_amd as oip
+    from opticalimageprocessor_amd import synth
+    from opticalimageprocessor_amd.dist import HipBackend, ShardBuffers, StripPlan, default_action_step
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    ctx = oip.Context(local_rank)
+    # one stream for everything: the library's kernels, torch's copies and RCCL's ordering
+    # (RCCL synchronises against torch's CURRENT stream, so make that the context's stream)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream)
+
+    W = args.width
+    if args.workload == "rrc":
+        pb = 65536
+    else:
+        pb = args.lines
+    Lp = pb * world
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    kb_pan = synth.lut(W)
+    kb_mss = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
+    d_kb_pan, d_kb_mss = ctx.upload_kb(kb_pan), ctx.upload_kb(kb_mss)
+    raw_pan = synth.pan_strip(rank * pb, pb, W, kb_pan, device=dev)
+    threshold = args.ibc_threshold
+    info = {}
+
+    if args.workload == "rrc":
+        dst = torch.empty_like(raw_pan)
+
+        def step():
+            ctx.rrc_u16(raw_pan, dst, W, pb, d_kb_pan)
+        pix_per_rank = W * pb
+        plan = None
+        M = N = base_rows = base_cols = 1
+        out_local = 0
+        workload = "RRC kernel only, %dx%d u16 per GPU (BASELINE config 2)" % (W, pb)
+    else:
+        plan = StripPlan(W, Lp, world, args.slices, args.sections)
+        bufs = ShardBuffers(plan, rank, dev)
+        raw_mss = synth.mss_strip(rank * plan.mb, plan.mb, W, kb_mss, device=dev)
+        o0, o1 = plan.align_out_rows(rank)
+        out = torch.zeros(max(o1 - o0, 1), W // 4, 4, dtype=torch.uint16, device=dev)
+        backend = HipBackend(ctx, plan)
+
+        def step():
+            cx, cy, _ = default_action_step(backend, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, rank,
+                                            threshold=threshold)
+            info["cx"], info["cy"] = cx, cy
+        pix_per_rank = W * pb + W * plan.mb
+        base_rows, base_cols = plan.base_rows, W // args.slices
+        M, N = optimal_dft_size(base_rows), optimal_dft_size(base_cols)
+        out_local = o1 - o0
+        workload = ("default action (--do-rrc4pan): PAN %dx%d + MSS 4x(%dx%d) per GPU; RRC + %dx%dx4 inter-band phase "
+                    "correlations (%dx%d FFT) + polyfit + bicubic align to 16UC4" %
+                    (W, pb, W // 4, plan.mb, args.sections, args.slices, M, N))
+        # the synthetic scene is not guaranteed to clear the reference's default response
+        # threshold in every slice: fall back to a lower --ibc-threshold once, and say so
+        try:
+            step()
+        except RuntimeError as e:
+            if "Not enough valid correlation values" not in str(e):
+                raise
+            threshold = 0.05
+            step()
+    ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pix_per_rank * world * args.steps / elapsed / 1e6
+        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local)
+        kernels = {}
+        for name, (ms, n) in prof.items():
+            avg = ms / max(n, 1)
+            e = {"launches_per_step": n / args.steps, "avg_ms": avg, "total_ms_per_step": ms / args.steps}
+            if ab.get(name):
+                e["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
+            kernels[name] = e
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
+        roof = None
+        if dom and ab.get(dom):
+            avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+            achieved = ab[dom] / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": avg_s * 1e3}
+        line = {
+            "metric": "Mpix/s end-to-end RRC+stitch on 30000x100000x4 strip; % HBM roofline",
+            "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u16 rasters; fp64 RRC/maps, f32 bicubic and FFT", "data": "synthetic",
+            "config": {"workload": workload, "width": W, "pan_lines_per_gpu": pb, "parallelism": "rowblock%d" % world,
+                       "ibc_threshold": threshold, "inputs": "resident in HBM"},
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if "rrc_u16_kernel" in kernels and "algorithmic_GBs" in kernels["rrc_u16_kernel"]:
+            g = kernels["rrc_u16_kernel"]["algorithmic_GBs"]
+            line["rrc_kernel"] = {"GBs_read_plus_write": g, "frac_of_8TBs": g / HBM_PEAK_GBS,
+                                  "GBs_read_only": g / 2, "Mpix_s": g / 4 * 1e3}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "default":
+            line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
+        elif world == 1 and not args.no_cpu_baseline:
+            import oracle
+            img = np.random.default_rng(1).integers(64, 4096, (4096, W), dtype=np.uint16)
+            use_ref = oracle.ref_lib() is not None
+            f = oracle.rrc_reference if use_ref else oracle.rrc
+            best = 1e9
+            for _ in range(5):
+                t1 = time.time(); f(img, kb_pan); best = min(best, time.time() - t1)
+            line["cpu_baseline"] = {"value": W * 4096 / best / 1e6, "unit": "Mpix/s", "cores": 1,
+                                    "kind": "reference" if use_ref else "port",
+                                    "sample": "InplaceRRC on %dx4096 u16, best of 5" % W}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

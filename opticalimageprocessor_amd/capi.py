@@ -91,8 +91,6 @@ def load_library() -> C.CDLL:
                           "(there is no CPU fallback)" % path)
         lib = C.CDLL(path)
         for name, (args, res) in _SIGS.items():
-            if os.environ.get("OIP_DEV_PARTIAL") and not hasattr(lib, name):   # TEMP (dev bring-up)
-                continue
             fn = getattr(lib, name)          # AttributeError if the symbol is missing
             fn.argtypes = args
             fn.restype = res

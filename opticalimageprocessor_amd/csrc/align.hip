@@ -240,7 +240,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
     if (rc) return rc;
     AlignRow *rows = reinterpret_cast<AlignRow *>(ws);
     {
-        OipProfScope prof(ctx, "align_mss_rows");
+        OipProfScope prof(ctx, "align_rows_kernel");
         int blocks = (int)((out_rows + 255) / 256);
         hipLaunchKernelGGL(align_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, g, out_row0, out_rows, src_row0);
     }
@@ -248,7 +248,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
     memcpy(co.cx, cx, sizeof co.cx);
     memcpy(co.cy, cy, sizeof co.cy);
     {
-        OipProfScope prof(ctx, "align_mss_bicubic_u16x4");
+        OipProfScope prof(ctx, "align_mss_kernel");
         int gx = (Wb + kBlock - 1) / kBlock;
         long want = (long)ctx->cu_count * 16 / gx;
         if (want < 1) want = 1;

@@ -217,13 +217,13 @@ extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, 
     if (rc) return rc;
     RowInfo *rows = reinterpret_cast<RowInfo *>(ws);
     {
-        OipProfScope prof(ctx, "remap_shift_rows");
+        OipProfScope prof(ctx, "shift_rows_kernel");
         int blocks = (int)((out_rows + 255) / 256);
         hipLaunchKernelGGL(shift_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, g, out_row0, out_rows,
                            src_row0, src_rows);
     }
     {
-        OipProfScope prof(ctx, "remap_shift_bicubic_u16");
+        OipProfScope prof(ctx, "remap_shift_kernel");
         int gx = (W + kBlock - 1) / kBlock;
         long want = (long)ctx->cu_count * 16 / gx;
         if (want < 1) want = 1;

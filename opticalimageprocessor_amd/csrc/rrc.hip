@@ -203,7 +203,7 @@ extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst,
     OIP_CHECK_CTX(ctx);
     if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16: bad argument");
     if (h == 0) return OIP_OK;
-    OipProfScope prof(ctx, "rrc_u16");
+    OipProfScope prof(ctx, "rrc_u16_kernel");
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
     const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
     if (w % 8 == 0 && (align & 15) == 0) {
@@ -236,7 +236,7 @@ extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16
     if (bw <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_mss_split_rrc_u16: line narrower than 4 pixels");
     if (plane_stride < (size_t)bw * (size_t)lines) return oip_fail(ctx, OIP_E_INVALID, "oip_mss_split_rrc_u16: plane_stride too small");
     if (lines == 0) return OIP_OK;
-    OipProfScope prof(ctx, "mss_split_rrc_u16");
+    OipProfScope prof(ctx, "mss_split_rrc_kernel");
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb4);
     const bool fast = (w % 8 == 0) && (bw % 4 == 0) && (w == bw * 4) && (((uintptr_t)d_bil & 15) == 0) &&
                       (((uintptr_t)d_planes & 7) == 0) && (plane_stride % 4 == 0);

@@ -100,7 +100,7 @@ extern "C" int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const u
     if (!d_left || !d_right || !d_out || W <= 0 || L < 0 || fold < 0 || fold >= W)
         return oip_fail(ctx, OIP_E_INVALID, "oip_stitch_rows_u16: bad argument");
     if (L == 0) return OIP_OK;
-    OipProfScope prof(ctx, "stitch_rows_u16");
+    OipProfScope prof(ctx, "stitch_rows_kernel");
     const int half = W - fold;
     const int ow = 2 * half;
     const bool fast = (ow % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && (((uintptr_t)d_left & 3) == 0) &&

@@ -214,8 +214,9 @@ def test_remap_shift_row_shards_equal_whole(ctx, oracle_mod, nshards):
         got[o0:o1] = _u16(part)
     assert np.array_equal(got, want)
     # a shard without its halo must be refused, not silently wrong
+    # (dy > 0: the taps of the first half reach below its last line)
     with pytest.raises(ValueError, match="halo"):
-        o0, o1 = L // 2, L
+        o0, o1 = 0, L // 2
         part = torch.zeros(o1 - o0, W, dtype=torch.uint16, device="cuda")
         ctx.remap_shift_bicubic_u16(_cuda(src[o0:o1]), part, W, L, dx, dy, sr, guard, src_row0=o0, src_rows=o1 - o0,
                                     out_row0=o0, out_rows=o1 - o0)

@@ -89,6 +89,13 @@ def load_library() -> C.CDLL:
         if not os.path.exists(path):
             raise OSError("liboipgpu.so not built at %s -- run __graft_entry__.build() "
                           "(there is no CPU fallback)" % path)
+        # torch wheels bundle their own ROCm runtime; whichever HIP runtime is loaded first
+        # in a process must be torch's, or the second one finds no devices.  (The oip CLI
+        # links the system runtime and never meets torch.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, (args, res) in _SIGS.items():
             fn = getattr(lib, name)          # AttributeError if the symbol is missing

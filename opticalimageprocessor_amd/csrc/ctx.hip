@@ -14,17 +14,6 @@ int oip_fail(oip_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-// OpenCV imgwarp.cpp interpolateCubic, evaluated on the host in f32 exactly as OpenCV's
-// initInterTab1D does (x86-64, no contraction: this TU is built with -ffp-contract=off).
-static void interpolate_cubic(float x, float *coeffs)
-{
-    const float A = -0.75f;
-    coeffs[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
-    coeffs[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
-    coeffs[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
-    coeffs[3] = 1.f - coeffs[0] - coeffs[1] - coeffs[2];
-}
-
 extern "C" int oip_version(void) { return 0x0101; }
 
 extern "C" int oip_create(int device, oip_ctx **out)
@@ -53,7 +42,7 @@ extern "C" int oip_create(int device, oip_ctx **out)
         return OIP_E_DEVICE;
     }
     float tab[32 * 4];
-    for (int i = 0; i < 32; ++i) interpolate_cubic(i * (1.f / 32), tab + i * 4);
+    for (int i = 0; i < 32; ++i) oip_interpolate_cubic_host(i * (1.f / 32), tab + i * 4);
     if (hipMalloc(&ctx->d_tab1d, sizeof tab) != hipSuccess ||
         hipMemcpy(ctx->d_tab1d, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->d_small, 65536) != hipSuccess ||
@@ -71,6 +60,7 @@ extern "C" void oip_destroy(oip_ctx *ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     oip_fft_destroy(ctx);
+    for (auto &t : ctx->resize_tabs) { hipFree(t.d_xofs); hipFree(t.d_alpha); hipFree(t.d_yofs); hipFree(t.d_beta); }
     for (auto &p : ctx->prof_pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     if (ctx->d_tab1d) hipFree(ctx->d_tab1d);
     if (ctx->d_small) hipFree(ctx->d_small);

@@ -10,20 +10,29 @@
 //     the per-image spectra are separated algebraically inside the cross-power kernel
 //     (phasecorr.hip).  5 real images -> 3 complex FFTs, 4 real correlation surfaces -> 2.
 //   * every axis length L is split into factors F1*F2(*F3).  One "pass" kernel does all
-//     F-point sub-transforms of one factor with a Stockham radix-{2,3,4,5} network in LDS,
-//     for a tile of V independent transforms that are ADJACENT IN MEMORY, so global loads
-//     and stores are V*8-byte (128..256 B) contiguous segments whatever the axis:
-//        mode A  (strided points, contiguous lanes): column passes and the leading row passes
-//        mode B  (contiguous points):                the last row pass (whole F-point rows)
-//   * decimation in frequency forward / decimation in time inverse: the forward transform
-//     leaves each axis in digit-scrambled order (position p = k1*F2 + k2 holds frequency
-//     k1 + F1*k2), the point-wise kernels work on that order, and the inverse consumes it and
-//     returns natural order.  No transposes, no bit-reversal passes: a 16000 x 3000 transform
-//     is 3 passes over HBM (row, column x2), each pass 8 B read + 8 B written per point.
-//   * twiddles come from fp64-computed tables (per sub-length in LDS, per pass in HBM/L2).
+//     F-point sub-transforms of one factor with a Stockham network in LDS, for a tile of V
+//     independent transforms that are ADJACENT IN MEMORY, so global loads and stores are
+//     V*8-byte (256 B) contiguous segments whatever the axis:
+//        mode A  (strided points, contiguous lanes): column passes
+//        mode B  (contiguous points):                the row pass (whole F-point rows)
+//   * forward = columns then rows, decimation in frequency; inverse = rows then columns,
+//     decimation in time.  The forward transform leaves each axis in digit-scrambled order
+//     (position p = k1*F2 + k2 holds frequency k1 + F1*k2), the point-wise kernel works on
+//     that order and the inverse consumes it and returns natural order: no transposes, no
+//     reordering passes.  A 16000 x 3000 transform is 3 passes over HBM (column x2, row),
+//     each 8 B read + 8 B written per point.
+//   * fusions: the first forward pass reads the two real f32 images directly (zero padding
+//     included) instead of a packed complex array; the last inverse pass does not store the
+//     correlation surface at all -- it reduces it to per-tile maxima (the arg-max of the
+//     fftShift-ed surface), and the 5x5 window around the winner is recomputed from 25 tiles.
+//   * the shapes of the reference geometry run compile-time specialised kernels (radices,
+//     tile and strides are constants: no integer division in the butterfly loops, one LDS
+//     buffer with register staging, 4-5 workgroups per CU); everything else runs the generic
+//     kernel with run-time radices.
+//   * twiddles come from fp64-computed tables.
 // The inverse is unnormalised, like cv::idft without DFT_SCALE (phasecorr.cpp).
-#include "oip_internal.h"
 #include "oip_fft.h"
+#include "oip_internal.h"
 
 #include <cmath>
 #include <map>
@@ -31,7 +40,7 @@
 namespace {
 
 constexpr int kFftBlock = 256;
-constexpr int kMaxTileElems = 5120;       // F * (V+1) complex elements per LDS buffer
+constexpr int kMaxTileElems = 5120;       // generic kernel: F * (V+1) complex elements per LDS buffer
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
@@ -84,7 +93,163 @@ __device__ __forceinline__ void bf5(float2 *x)
     x[2] = cadd(m2, u2);
     x[3] = csub(m2, u2);
 }
+__device__ __forceinline__ void bf8(float2 *x)
+{
+    const float h = 0.70710678118654752440f;
+    float2 e[4] = {x[0], x[2], x[4], x[6]};
+    float2 o[4] = {x[1], x[3], x[5], x[7]};
+    bf4(e);
+    bf4(o);
+    o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));      // * w8
+    o[2] = cmuli_neg(o[2]);                                                // * w8^2
+    o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));     // * w8^3
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = cadd(e[k], o[k]);
+        x[k + 4] = csub(e[k], o[k]);
+    }
+}
+template <int R> __device__ __forceinline__ void butterfly(float2 *x)
+{
+    if (R == 2) bf2(x);
+    else if (R == 3) bf3(x);
+    else if (R == 4) bf4(x);
+    else if (R == 5) bf5(x);
+    else bf8(x);
+}
 
+// ---- tile addressing shared by the generic and the specialised kernels -------------------------
+struct Tile {
+    long base;      // element offset of (point 0, lane 0)
+    int nv;         // live vectors in the tile
+    int lane0;      // mode 0: first lane
+    int o1;         // mode 0: outer index 1
+    int o2;         // mode 0: outer index 2
+    long vec0;      // mode 1: first vector
+};
+
+__device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
+{
+    Tile t;
+    const int V = 1 << p.vshift;
+    if (p.mode == 0) {
+        const int lt = (int)(bid % p.lane_tiles);
+        const long rest = bid / p.lane_tiles;
+        t.o1 = (int)(rest % p.O1);
+        t.o2 = (int)(rest / p.O1);
+        t.lane0 = lt << p.vshift;
+        t.nv = p.lanes - t.lane0 < V ? (int)(p.lanes - t.lane0) : V;
+        t.base = (long)t.o2 * p.o2_stride + (long)t.o1 * p.o1_stride + t.lane0;
+        t.vec0 = 0;
+    } else {
+        t.vec0 = bid << p.vshift;
+        t.nv = p.lanes - t.vec0 < V ? (int)(p.lanes - t.vec0) : V;
+        t.base = t.vec0 * p.F;
+        t.lane0 = t.o1 = t.o2 = 0;
+    }
+    return t;
+}
+
+// (row, column) of tile element (point n, vector v) in the M x N array
+__device__ __forceinline__ void elem_coord(const OipFftPass &p, const Tile &t, int n, int v, int *y, int *x)
+{
+    if (p.mode == 0) {
+        if (p.axis == 1) { *y = t.o2 * p.T + t.o1 + n * p.S; *x = t.lane0 + v; }
+        else { *y = t.o2; *x = t.o1 * p.T + t.lane0 + v + n * p.S; }
+    } else {
+        const int per_row = p.N / p.F;
+        const long vec = t.vec0 + v;
+        *y = (int)(vec / per_row);
+        *x = (int)(vec - (long)(*y) * per_row) * p.F + n;
+    }
+}
+
+__device__ __forceinline__ float2 load_elem(const float2 *__restrict__ data, const OipFftPass &p, const OipFftIo &io,
+                                            const Tile &t, int n, int v, long off)
+{
+    if (io.load_kind == 0) return data[off];
+    int y, x;
+    elem_coord(p, t, n, v, &y, &x);
+    float2 z = make_float2(0.f, 0.f);
+    if (y < io.rows && x < io.cols) {
+        const size_t i = (size_t)y * io.cols + x;
+        if (io.re) z.x = io.re[i];
+        else if (io.re16) z.x = (float)io.re16[(size_t)y * io.pitch_re16 + x];
+        if (io.im) z.y = io.im[i];
+        else if (io.im16) z.y = (float)io.im16[(size_t)y * io.pitch_im16 + x];
+    }
+    return z;
+}
+
+__device__ __forceinline__ bool peak_better(float v, long k, float bv, long bk) { return v > bv || (v == bv && k < bk); }
+
+// Reduce the tile to its maximum (first occurrence in the fftShift-ed scan order) for the
+// real and the imaginary part; one partial per workgroup and part.
+__device__ void store_peak(const float2 *__restrict__ buf, int Vp, const OipFftPass &p, const OipFftIo &io,
+                           const Tile &t, float *sval, long *skey)
+{
+    const int V = 1 << p.vshift;
+    const int total = p.F << p.vshift;
+    const int ym = p.M >> 1, xm = p.N >> 1;
+    float bv[2] = {-INFINITY, -INFINITY};
+    long bk[2] = {(long)p.M * p.N, (long)p.M * p.N};
+    for (int e = threadIdx.x; e < total; e += kFftBlock) {
+        const int v = p.mode == 0 ? (e & (V - 1)) : e / p.F;
+        const int n = p.mode == 0 ? (e >> p.vshift) : e - v * p.F;
+        if (v >= t.nv) continue;
+        float2 z = buf[n * Vp + v];
+        z.y = -z.y;                              // inverse = conj(forward(conj))
+        int y, x;
+        elem_coord(p, t, n, v, &y, &x);
+        int ys = y + ym; if (ys >= p.M) ys -= p.M;
+        int xs = x + xm; if (xs >= p.N) xs -= p.N;
+        const long key = (long)ys * p.N + xs;
+        if (peak_better(z.x, key, bv[0], bk[0])) { bv[0] = z.x; bk[0] = key; }
+        if (peak_better(z.y, key, bv[1], bk[1])) { bv[1] = z.y; bk[1] = key; }
+    }
+    for (int part = 0; part < 2; ++part) {
+        __syncthreads();
+        sval[threadIdx.x] = bv[part];
+        skey[threadIdx.x] = bk[part];
+        __syncthreads();
+        for (int s = kFftBlock / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s && peak_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
+                sval[threadIdx.x] = sval[threadIdx.x + s];
+                skey[threadIdx.x] = skey[threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            OipPeakPartial &o = io.partials[(size_t)part * gridDim.x + blockIdx.x];
+            o.val = sval[0];
+            o.key = skey[0];
+        }
+    }
+}
+
+// store_kind 2: which tile holds window element w of the 5x5 window around the peak
+__device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo &io, int w, Tile *t, int *n0, int *v0)
+{
+    const long key = *io.peak_key;
+    const int py = (int)(key / p.N), px = (int)(key - (long)py * p.N);
+    const int ys = py - 2 + w / 5, xs = px - 2 + w % 5;
+    if (ys < 0 || ys >= p.M || xs < 0 || xs >= p.N) return false;     // weightedCentroid clamps the window
+    int yo = ys - (p.M >> 1); if (yo < 0) yo += p.M;
+    int xo = xs - (p.N >> 1); if (xo < 0) xo += p.N;
+    // the last inverse pass is a column pass over the whole axis: T == M, O2 == 1
+    const int V = 1 << p.vshift;
+    t->o2 = 0;
+    t->o1 = yo % p.S;
+    *n0 = yo / p.S;
+    t->lane0 = (xo >> p.vshift) << p.vshift;
+    *v0 = xo - t->lane0;
+    t->nv = p.lanes - t->lane0 < V ? (int)(p.lanes - t->lane0) : V;
+    t->base = (long)t->o1 * p.o1_stride + t->lane0;
+    t->vec0 = 0;
+    return true;
+}
+
+// ---- generic kernel: run-time radices, ping-pong LDS buffers --------------------------------------
 template <int R>
 __device__ __forceinline__ void stockham_stage(const float2 *__restrict__ in, float2 *__restrict__ out,
                                                const float2 *__restrict__ tw, int F, int Ns, int vshift, int Vp)
@@ -104,71 +269,53 @@ __device__ __forceinline__ void stockham_stage(const float2 *__restrict__ in, fl
 #pragma unroll
             for (int m = 1; m < R; ++m) x[m] = cmul(x[m], tw[k * m * twstep]);
         }
-        if (R == 2) bf2(x);
-        else if (R == 3) bf3(x);
-        else if (R == 4) bf4(x);
-        else bf5(x);
+        butterfly<R>(x);
         const int j0 = (b - k) * R + k;    // (b / Ns) * Ns * R + k
 #pragma unroll
         for (int m = 0; m < R; ++m) out[(j0 + m * Ns) * Vp + v] = x[m];
     }
 }
 
-__global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict__ data, OipFftPass p,
+__global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
                                                              const float2 *__restrict__ twF,
                                                              const float2 *__restrict__ twT)
 {
     extern __shared__ float2 smem[];
+    __shared__ float sval[kFftBlock];
+    __shared__ long skey[kFftBlock];
     const int F = p.F;
     const int V = 1 << p.vshift;
     const int Vp = p.Vp;
     float2 *bufA = smem;
     float2 *bufB = smem + F * Vp;
     float2 *tw = smem + 2 * F * Vp;
-    for (int i = threadIdx.x; i < F; i += kFftBlock) tw[i] = twF[i];
 
-    const long bid = blockIdx.x;
-    long base;
-    int nv, lane0 = 0, o1 = 0;
-    if (p.mode == 0) {
-        const int lt = (int)(bid % p.lane_tiles);
-        const long rest = bid / p.lane_tiles;
-        o1 = (int)(rest % p.O1);
-        const long o2 = rest / p.O1;
-        lane0 = lt << p.vshift;
-        nv = p.lanes - lane0 < V ? p.lanes - lane0 : V;
-        base = o2 * p.o2_stride + (long)o1 * p.o1_stride + lane0;
-        const int total = F << p.vshift;
-        for (int e = threadIdx.x; e < total; e += kFftBlock) {
-            const int v = e & (V - 1), n = e >> p.vshift;
-            float2 z = make_float2(0.f, 0.f);
-            if (v < nv) {
-                z = data[base + (long)n * p.nstride + v];
-                if (p.inverse) {
-                    z.y = -z.y;
-                    if (p.tw_mode) {
-                        const int j = p.tw_mode == 1 ? lane0 + v : o1;
-                        z = cmul(z, twT[(long)j * n]);
-                    }
-                }
-            }
-            bufA[n * Vp + v] = z;
+    Tile t;
+    int wn0 = 0, wv0 = 0;
+    if (io.store_kind == 2) {
+        if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
+            if (threadIdx.x == 0) io.window[blockIdx.x] = NAN;
+            return;
         }
     } else {
-        const long vec0 = bid << p.vshift;
-        nv = p.lanes - vec0 < V ? (int)(p.lanes - vec0) : V;
-        base = vec0 * F;
-        const int total = nv * F;
-        for (int e = threadIdx.x; e < total; e += kFftBlock) {
-            const int v = e / F, n = e - v * F;
-            float2 z = data[base + e];
-            if (p.inverse) z.y = -z.y;
-            bufA[n * Vp + v] = z;
+        t = decode_tile(p, blockIdx.x);
+    }
+    for (int i = threadIdx.x; i < F; i += kFftBlock) tw[i] = twF[i];
+
+    const int total = F << p.vshift;
+    for (int e = threadIdx.x; e < total; e += kFftBlock) {
+        const int v = p.mode == 0 ? (e & (V - 1)) : e / F;
+        const int n = p.mode == 0 ? (e >> p.vshift) : e - v * F;
+        float2 z = make_float2(0.f, 0.f);
+        if (v < t.nv) {
+            const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+            z = load_elem(data, p, io, t, n, v, off);
+            if (p.inverse) {
+                z.y = -z.y;
+                if (p.tw_mode) z = cmul(z, twT[(long)(p.tw_mode == 1 ? t.lane0 + v : t.o1) * n]);
+            }
         }
-        for (int e = total + threadIdx.x; e < (F << p.vshift); e += kFftBlock) {
-            const int v = e / F, n = e - v * F;
-            bufA[n * Vp + v] = make_float2(0.f, 0.f);
-        }
+        bufA[n * Vp + v] = z;
     }
     __syncthreads();
 
@@ -178,36 +325,209 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         if (r == 4) stockham_stage<4>(bufA, bufB, tw, F, Ns, p.vshift, Vp);
         else if (r == 5) stockham_stage<5>(bufA, bufB, tw, F, Ns, p.vshift, Vp);
         else if (r == 2) stockham_stage<2>(bufA, bufB, tw, F, Ns, p.vshift, Vp);
+        else if (r == 8) stockham_stage<8>(bufA, bufB, tw, F, Ns, p.vshift, Vp);
         else stockham_stage<3>(bufA, bufB, tw, F, Ns, p.vshift, Vp);
         __syncthreads();
-        float2 *t = bufA; bufA = bufB; bufB = t;
+        float2 *tmp = bufA; bufA = bufB; bufB = tmp;
         Ns *= r;
     }
 
-    if (p.mode == 0) {
-        const int total = F << p.vshift;
-        for (int e = threadIdx.x; e < total; e += kFftBlock) {
-            const int v = e & (V - 1), n = e >> p.vshift;
-            if (v >= nv) continue;
-            float2 z = bufA[n * Vp + v];
-            if (p.inverse) {
-                z.y = -z.y;
-            } else if (p.tw_mode) {
-                const int j = p.tw_mode == 1 ? lane0 + v : o1;
-                z = cmul(z, twT[(long)j * n]);
-            }
-            data[base + (long)n * p.nstride + v] = z;
+    if (io.store_kind == 1) { store_peak(bufA, Vp, p, io, t, sval, skey); return; }
+    if (io.store_kind == 2) {
+        if (threadIdx.x == 0) {
+            float2 z = bufA[wn0 * Vp + wv0];
+            io.window[blockIdx.x] = io.part ? -z.y : z.x;
         }
-    } else {
-        const int total = nv * F;
-        for (int e = threadIdx.x; e < total; e += kFftBlock) {
-            const int v = e / F, n = e - v * F;
-            float2 z = bufA[n * Vp + v];
-            if (p.inverse) z.y = -z.y;
-            data[base + e] = z;
-        }
+        return;
+    }
+    for (int e = threadIdx.x; e < total; e += kFftBlock) {
+        const int v = p.mode == 0 ? (e & (V - 1)) : e / F;
+        const int n = p.mode == 0 ? (e >> p.vshift) : e - v * F;
+        if (v >= t.nv) continue;
+        float2 z = bufA[n * Vp + v];
+        if (p.inverse) z.y = -z.y;
+        else if (p.tw_mode) z = cmul(z, twT[(long)(p.tw_mode == 1 ? t.lane0 + v : t.o1) * n]);
+        const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+        data[off] = z;
     }
 }
+
+// ---- specialised kernels: compile-time F, radices, tile; one LDS buffer ---------------------------
+template <int... Rs> struct RadixList {};
+
+template <int F, int First, int... Rest> struct TwTable {          // entries of w_F^t the stages need
+    static constexpr int rest_max(int acc) { return acc; }
+    static constexpr int value()
+    {
+        int m = 1;
+        const int r[] = {Rest..., 0};
+        for (int i = 0; r[i]; ++i) m = (F / r[i]) > m ? (F / r[i]) : m;
+        return m;
+    }
+};
+
+template <int F, int VS, int Ns, int R>
+__device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 *__restrict__ tw)
+{
+    constexpr int V = 1 << VS;
+    constexpr int Vp = VS ? V + 1 : 1;
+    constexpr int NB = F / R;
+    constexpr int ITEMS = NB << VS;
+    constexpr int PER = (ITEMS + kFftBlock - 1) / kFftBlock;
+    constexpr int TWSTEP = F / (Ns * R);
+    float2 x[PER][R];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int item = threadIdx.x + i * kFftBlock;
+        if (ITEMS % kFftBlock == 0 || item < ITEMS) {
+            const int v = item & (V - 1), b = item >> VS;
+#pragma unroll
+            for (int m = 0; m < R; ++m) x[i][m] = buf[(b + m * NB) * Vp + v];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int item = threadIdx.x + i * kFftBlock;
+        if (ITEMS % kFftBlock == 0 || item < ITEMS) {
+            const int v = item & (V - 1), b = item >> VS;
+            const int k = b % Ns;
+            if (Ns > 1) {
+                // w^(k m) from w^k by repeated products: one table look-up per butterfly
+                const float2 w1 = tw[k * TWSTEP];
+                float2 w = w1;
+#pragma unroll
+                for (int m = 1; m < R; ++m) {
+                    x[i][m] = cmul(x[i][m], w);
+                    if (m + 1 < R) w = cmul(w, w1);
+                }
+            }
+            butterfly<R>(x[i]);
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int m = 0; m < R; ++m) buf[(j0 + m * Ns) * Vp + v] = x[i][m];
+        }
+    }
+    __syncthreads();
+}
+
+template <int F, int VS, int Ns, int... Rs> struct Stages;
+template <int F, int VS, int Ns> struct Stages<F, VS, Ns> {
+    static __device__ __forceinline__ void run(float2 *, const float2 *) {}
+};
+template <int F, int VS, int Ns, int R, int... Rest> struct Stages<F, VS, Ns, R, Rest...> {
+    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw)
+    {
+        stage_ct<F, VS, Ns, R>(buf, tw);
+        Stages<F, VS, Ns * R, Rest...>::run(buf, tw);
+    }
+};
+
+template <int F, int VS, int MODE, int... Rs>
+__global__ __launch_bounds__(kFftBlock) void fft_pass_ct_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
+                                                                const float2 *__restrict__ twF,
+                                                                const float2 *__restrict__ twT)
+{
+    constexpr int V = 1 << VS;
+    constexpr int Vp = VS ? V + 1 : 1;
+    constexpr int TWN = TwTable<F, Rs...>::value();
+    __shared__ float2 buf[F * Vp];
+    __shared__ float2 tw[TWN];
+    __shared__ float2 twj[MODE == 0 ? F : 1];       // inter-pass twiddles of this tile (column passes)
+    __shared__ float sval[kFftBlock];
+    __shared__ long skey[kFftBlock];
+
+    Tile t;
+    int wn0 = 0, wv0 = 0;
+    if (io.store_kind == 2) {
+        if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
+            if (threadIdx.x == 0) io.window[blockIdx.x] = NAN;
+            return;
+        }
+    } else {
+        t = decode_tile(p, blockIdx.x);
+    }
+    for (int i = threadIdx.x; i < TWN; i += kFftBlock) tw[i] = twF[i];
+    const bool tile_tw = MODE == 0 && p.tw_mode == 2;
+    if (tile_tw)
+        for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = twT[(long)t.o1 * i];
+    if (tile_tw && p.inverse) __syncthreads();
+
+    constexpr int TOTAL = F << VS;
+    constexpr int NLD = (TOTAL + kFftBlock - 1) / kFftBlock;
+    {
+        // all global loads of the tile are issued before the first one is consumed
+        float2 zz[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = threadIdx.x + i * kFftBlock;
+            const int v = MODE == 0 ? (e & (V - 1)) : e / F;
+            const int n = MODE == 0 ? (e >> VS) : e - v * F;
+            zz[i] = make_float2(0.f, 0.f);
+            if ((TOTAL % kFftBlock == 0 || e < TOTAL) && v < t.nv) {
+                const long off = MODE == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+                zz[i] = load_elem(data, p, io, t, n, v, off);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = threadIdx.x + i * kFftBlock;
+            const int v = MODE == 0 ? (e & (V - 1)) : e / F;
+            const int n = MODE == 0 ? (e >> VS) : e - v * F;
+            if (TOTAL % kFftBlock == 0 || e < TOTAL) {
+                float2 z = zz[i];
+                if (p.inverse && v < t.nv) {
+                    z.y = -z.y;
+                    if (tile_tw) z = cmul(z, twj[n]);
+                    else if (p.tw_mode == 1) z = cmul(z, twT[(long)(t.lane0 + v) * n]);
+                }
+                buf[n * Vp + v] = z;
+            }
+        }
+    }
+    __syncthreads();
+
+    Stages<F, VS, 1, Rs...>::run(buf, tw);
+
+    if (io.store_kind == 1) { store_peak(buf, Vp, p, io, t, sval, skey); return; }
+    if (io.store_kind == 2) {
+        if (threadIdx.x == 0) {
+            float2 z = buf[wn0 * Vp + wv0];
+            io.window[blockIdx.x] = io.part ? -z.y : z.x;
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < TOTAL; e += kFftBlock) {
+        const int v = MODE == 0 ? (e & (V - 1)) : e / F;
+        const int n = MODE == 0 ? (e >> VS) : e - v * F;
+        if (v >= t.nv) continue;
+        float2 z = buf[n * Vp + v];
+        if (p.inverse) z.y = -z.y;
+        else if (tile_tw) z = cmul(z, twj[n]);
+        else if (p.tw_mode == 1) z = cmul(z, twT[(long)(t.lane0 + v) * n]);
+        const long off = MODE == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+        data[off] = z;
+    }
+}
+
+// table of specialisations: (F, log2 V, mode) -> kernel
+struct FastKernel {
+    int F, vshift, mode;
+    void (*fn)(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);
+};
+const FastKernel kFast[] = {
+    // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors)
+    {125, 5, 0, fft_pass_ct_kernel<125, 5, 0, 5, 5, 5>},
+    {128, 5, 0, fft_pass_ct_kernel<128, 5, 0, 8, 4, 4>},
+    {100, 5, 0, fft_pass_ct_kernel<100, 5, 0, 4, 5, 5>},
+    {160, 4, 0, fft_pass_ct_kernel<160, 4, 0, 4, 8, 5>},
+    {64, 5, 0, fft_pass_ct_kernel<64, 5, 0, 4, 4, 4>},
+    // row passes: 30000/10, 12288/10 -> 1250, the 200-column stitch overlap
+    {3000, 0, 1, fft_pass_ct_kernel<3000, 0, 1, 3, 8, 5, 5, 5>},
+    {1250, 1, 1, fft_pass_ct_kernel<1250, 1, 1, 2, 5, 5, 5, 5>},
+    {200, 4, 1, fft_pass_ct_kernel<200, 4, 1, 8, 5, 5>},
+};
+constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
 // ---- host-side planning --------------------------------------------------------------------
 bool smooth235(long n)
@@ -222,15 +542,16 @@ std::vector<int> radix_list(int F)
     std::vector<int> r;
     int twos = 0;
     while (F % 2 == 0) { F /= 2; ++twos; }
-    for (; twos >= 2; twos -= 2) r.push_back(4);
-    if (twos) r.push_back(2);
     while (F % 3 == 0) { F /= 3; r.push_back(3); }
+    for (; twos >= 3; twos -= 3) r.push_back(8);
+    if (twos == 2) r.push_back(4);
+    if (twos == 1) r.push_back(2);
     while (F % 5 == 0) { F /= 5; r.push_back(5); }
     return r;
 }
 
 // split L into pass factors: all but the last limited by max_a (mode A tiles), the last by
-// max_last; fewest passes, then the most balanced split
+// max_last; fewest passes, then the most balanced split; 125*128 preferred for 16000
 bool split_axis(int L, int max_a, int max_last, std::vector<int> *out)
 {
     if (L <= max_last) { *out = {L}; return true; }
@@ -267,6 +588,20 @@ int pick_vshift(int F, int want)
     int vs = 0;
     while ((1 << (vs + 1)) <= want && (long)F * ((1 << (vs + 1)) + 1) <= kMaxTileElems) ++vs;
     return vs;
+}
+
+void choose_kernel(OipFftPass *p, int want_v)
+{
+    p->fast = -1;
+    for (int i = 0; i < kNumFast; ++i)
+        if (kFast[i].F == p->F && kFast[i].mode == p->mode) {
+            p->fast = i;
+            p->vshift = kFast[i].vshift;
+            p->Vp = p->vshift ? (1 << p->vshift) + 1 : 1;
+            return;
+        }
+    p->vshift = pick_vshift(p->F, want_v);
+    p->Vp = p->vshift ? (1 << p->vshift) + 1 : 1;
 }
 
 }  // namespace
@@ -317,111 +652,146 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
     auto it = ctx->fft->plans.find(key);
     if (it != ctx->fft->plans.end()) { *out = &it->second; return OIP_OK; }
     if (!smooth235(M) || !smooth235(N)) return oip_fail(ctx, OIP_E_INVALID, "fft2d: %d x %d is not 2^a3^b5^c", M, N);
+    if (M < 2) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: fewer than 2 rows");
     OipFft2dPlan pl;
     pl.M = M; pl.N = N;
-    // rows (x axis): leading factors in mode A (lanes = j, >= 8 contiguous points wanted),
-    // last factor as whole contiguous sub-rows in mode B
     if (!split_axis(N, 256, 4096, &pl.xf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor row length %d", N);
-    if (!split_axis(M, 256, 256, &pl.yf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor column length %d", M);
-    // x passes
-    {
-        int T = N;                       // length of the sub-problem the pass starts from
-        for (size_t i = 0; i < pl.xf.size(); ++i) {
-            OipFftPass p;
-            memset(&p, 0, sizeof p);
-            p.F = pl.xf[i];
-            fill_radix(&p);
-            const int S = T / p.F;
-            if (S == 1) {
-                p.mode = 1;
-                p.vshift = pick_vshift(p.F, 32);
-                p.Vp = p.vshift ? (1 << p.vshift) + 1 : 1;
-                p.lanes = (long)M * (N / p.F);          // contiguous F-point vectors
-                p.tw_mode = 0; p.T = 0;
-            } else {
-                p.mode = 0;
-                p.vshift = pick_vshift(p.F, 32);
-                p.Vp = (1 << p.vshift) + 1;
-                p.nstride = S;
-                p.lanes = S;
-                p.lane_tiles = (S + (1 << p.vshift) - 1) >> p.vshift;
-                p.O1 = N / T; p.o1_stride = T;          // blocks of the current sub-problem
-                p.O2 = M;     p.o2_stride = N;          // rows
-                p.tw_mode = 1; p.T = T;
-            }
-            pl.passes.push_back(p);
-            T = S;
-        }
-    }
-    pl.n_x = (int)pl.passes.size();
-    // y passes: always mode A with lanes = x
+    if (M == 16000) pl.yf = {125, 128};
+    else if (!split_axis(M, 256, 256, &pl.yf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor column length %d", M);
+    // column (y) passes first: always mode A with lanes = x
     {
         int T = M;
         for (size_t i = 0; i < pl.yf.size(); ++i) {
             OipFftPass p;
             memset(&p, 0, sizeof p);
             p.F = pl.yf[i];
+            p.M = M; p.N = N;
+            p.axis = 1;
             fill_radix(&p);
             const int S = T / p.F;
             p.mode = 0;
-            p.vshift = pick_vshift(p.F, 32);
-            p.Vp = (1 << p.vshift) + 1;
+            choose_kernel(&p, 32);
             p.nstride = (long)S * N;
             p.lanes = N;
             p.lane_tiles = (N + (1 << p.vshift) - 1) >> p.vshift;
             p.O1 = S;     p.o1_stride = N;              // j: row offset inside the block
             p.O2 = M / T; p.o2_stride = (long)T * N;    // blocks
-            p.tw_mode = S > 1 ? 2 : 0; p.T = S > 1 ? T : 0;
+            p.tw_mode = S > 1 ? 2 : 0; p.T = T; p.S = S;
+            pl.passes.push_back(p);
+            T = S;
+        }
+    }
+    pl.n_y = (int)pl.passes.size();
+    // row (x) passes: leading factors in mode A (lanes = j), last factor as whole contiguous
+    // sub-rows in mode B
+    {
+        int T = N;
+        for (size_t i = 0; i < pl.xf.size(); ++i) {
+            OipFftPass p;
+            memset(&p, 0, sizeof p);
+            p.F = pl.xf[i];
+            p.M = M; p.N = N;
+            p.axis = 0;
+            fill_radix(&p);
+            const int S = T / p.F;
+            p.T = T; p.S = S;
+            if (S == 1) {
+                p.mode = 1;
+                choose_kernel(&p, 32);
+                p.lanes = (long)M * (N / p.F);          // contiguous F-point vectors
+                p.tw_mode = 0;
+            } else {
+                p.mode = 0;
+                choose_kernel(&p, 32);
+                p.nstride = S;
+                p.lanes = S;
+                p.lane_tiles = (S + (1 << p.vshift) - 1) >> p.vshift;
+                p.O1 = N / T; p.o1_stride = T;          // blocks of the current sub-problem
+                p.O2 = M;     p.o2_stride = N;          // rows
+                p.tw_mode = 1;
+            }
             pl.passes.push_back(p);
             T = S;
         }
     }
     for (auto &p : pl.passes) {
-        if ((long)p.F * p.Vp > kMaxTileElems) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: factor %d too long for one LDS tile", p.F);
+        if (p.fast < 0 && (long)p.F * p.Vp > kMaxTileElems)
+            return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: factor %d too long for one LDS tile", p.F);
         const float2 *t;
         int rc = get_table(ctx, p.F, &t);
         if (rc) return rc;
-        if (p.T) { rc = get_table(ctx, p.T, &t); if (rc) return rc; }
+        if (p.tw_mode) { rc = get_table(ctx, p.T, &t); if (rc) return rc; }
     }
     it = ctx->fft->plans.emplace(key, pl).first;
     *out = &it->second;
     return OIP_OK;
 }
 
-static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse)
+static long pass_blocks(const OipFftPass &p)
+{
+    if (p.mode == 0) return (long)p.lane_tiles * p.O1 * p.O2;
+    return (p.lanes + (1 << p.vshift) - 1) >> p.vshift;
+}
+
+long oip_fft2d_last_pass_blocks(const OipFft2dPlan *pl) { return pass_blocks(pl->passes[0]); }
+
+static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, const OipFftIo &io, long blocks_override)
 {
     p.inverse = inverse;
     const float2 *twF = nullptr, *twT = nullptr;
     int rc = get_table(ctx, p.F, &twF);
     if (rc) return rc;
-    if (p.T) { rc = get_table(ctx, p.T, &twT); if (rc) return rc; }
-    long blocks;
-    if (p.mode == 0) blocks = (long)p.lane_tiles * p.O1 * p.O2;
-    else blocks = (p.lanes + (1 << p.vshift) - 1) >> p.vshift;
+    if (p.tw_mode) { rc = get_table(ctx, p.T, &twT); if (rc) return rc; }
+    long blocks = blocks_override > 0 ? blocks_override : pass_blocks(p);
     if (blocks <= 0 || blocks > 0x7fffffffL) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass grid too large");
-    size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
-    OipProfScope prof(ctx, "fft_pass_kernel");
-    hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, twF, twT);
+    char pname[48];
+    snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d" : "fft_pass_kernel_F%d"), p.F);
+    OipProfScope prof(ctx, pname);
+    if (p.fast >= 0) {
+        hipLaunchKernelGGL(kFast[p.fast].fn, dim3((unsigned)blocks), dim3(kFftBlock), 0, ctx->stream, data, p, io, twF, twT);
+    } else {
+        size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
+        hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);
+    }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
 
 // In-place complex 2-D transform of an M x N row-major float2 array.
-//   inverse == 0: natural order in, digit-scrambled spectrum out (rows first, then columns)
-//   inverse == 1: scrambled spectrum in, natural order out, unnormalised (columns, then rows)
-int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inverse)
+//   inverse == 0: natural order in, digit-scrambled spectrum out (columns first, then rows);
+//                 io->load_kind applies to the first pass
+//   inverse == 1: scrambled spectrum in, natural order out, unnormalised (rows, then columns);
+//                 io->store_kind applies to the last pass
+int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inverse, const OipFftIo *io)
 {
     const int np = (int)pl->passes.size();
+    OipFftIo plain;
+    memset(&plain, 0, sizeof plain);
     if (!inverse) {
         for (int i = 0; i < np; ++i) {
-            int rc = launch_pass(ctx, data, pl->passes[i], 0);
+            OipFftIo use = plain;
+            if (i == 0 && io) { use = *io; use.store_kind = 0; }
+            int rc = launch_pass(ctx, data, pl->passes[i], 0, use, 0);
             if (rc) return rc;
         }
     } else {
         for (int i = np - 1; i >= 0; --i) {
-            int rc = launch_pass(ctx, data, pl->passes[i], 1);
+            OipFftIo use = plain;
+            if (i == 0 && io) { use.store_kind = io->store_kind; use.partials = io->partials; }
+            int rc = launch_pass(ctx, data, pl->passes[i], 1, use, 0);
             if (rc) return rc;
         }
     }
     return OIP_OK;
+}
+
+int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, const OipFftIo *io)
+{
+    OipFftIo use;
+    memset(&use, 0, sizeof use);
+    use.store_kind = 2;
+    use.peak_key = io->peak_key;
+    use.window = io->window;
+    use.part = io->part;
+    return launch_pass(ctx, data, pl->passes[0], 1, use, 25);
 }

@@ -8,13 +8,37 @@
 
 struct oip_ctx;
 
+struct OipPeakPartial {
+    float val;
+    int pad;
+    long key;           // index in the fftShift-ed image, row-major
+};
+
+// What a pass reads instead of / writes besides the complex array (fusions)
+struct OipFftIo {
+    int load_kind;      // 0: the complex array; 1: pack two real f32 images (zero padded)
+    const float *re;    // f32 image, pitch == cols ...
+    const float *im;    // ... may be null
+    const uint16_t *re16;   // ... or a u16 raster window (pointer at its first pixel, own pitch)
+    const uint16_t *im16;
+    long pitch_re16, pitch_im16;
+    int rows, cols;     // extent of the real images
+    int store_kind;     // 0: the complex array; 1: peak partials only (nothing stored);
+                        // 2: 5x5 window around a known peak (25 workgroups, nothing else stored)
+    OipPeakPartial *partials;   // store_kind 1: [2][grid] (real part, imaginary part)
+    const long *peak_key;       // store_kind 2: shifted key of the peak (device)
+    float *window;              // store_kind 2: [25] values, row-major dy,dx (NaN = outside image)
+    int part;                   // store_kind 2: 0 real / 1 imaginary part of the surface
+};
+
 struct OipFftPass {
     int F;              // sub-transform length of this pass
     int nradix;
-    int radix[16];      // Stockham radices, product == F
+    int radix[16];      // Stockham radices, product == F (generic kernel)
     int vshift;         // log2(V): V adjacent transforms per workgroup tile
     int Vp;             // LDS row pitch (V+1, or 1 when V == 1)
     int mode;           // 0: points strided, lanes contiguous; 1: points contiguous
+    int axis;           // 0: x (rows), 1: y (columns)
     long nstride;       // mode 0: elements between consecutive points
     long lanes;         // mode 0: lanes in the contiguous direction; mode 1: number of vectors
     int lane_tiles;
@@ -24,18 +48,26 @@ struct OipFftPass {
     long o2_stride;
     int tw_mode;        // 0 none; 1: j = lane index; 2: j = o1 index  (twiddle w_T^(j*k))
     int T;
+    int S;              // stride of the sub-transform in axis elements (T / F)
+    int N;              // row length of the array (to turn offsets into coordinates)
+    int M;
     int inverse;
+    int fast;           // index of a compile-time specialised kernel, -1: generic
 };
 
 struct OipFft2dPlan {
     int M, N;
     std::vector<int> xf, yf;          // pass factors per axis, in forward order
-    std::vector<OipFftPass> passes;   // forward order: x passes then y passes
-    int n_x;
+    std::vector<OipFftPass> passes;   // forward order: y passes then x passes
+    int n_y;
 };
 
 int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out);
-int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, int inverse);
+// forward: io (optional) applies to the FIRST pass' load; inverse: to the LAST pass' store
+int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, int inverse, const OipFftIo *io);
+// re-run the last inverse pass for the 25 tiles holding the 5x5 window around *peak_key
+int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, const OipFftIo *io);
+long oip_fft2d_last_pass_blocks(const OipFft2dPlan *plan);
 
 // position <-> frequency of one axis after the forward transform.  With factors
 // (F1, F2, ..) position p = k1*(F2*F3..) + k2*(F3..) + .. holds frequency
@@ -48,6 +80,7 @@ struct OipAxisDigits {
 
 __host__ __device__ inline int oip_pos_to_freq(const OipAxisDigits &a, int p)
 {
+    if (a.n == 1) return p;
     int d[4];
     int rem = p;
     int stride = a.L;
@@ -63,6 +96,7 @@ __host__ __device__ inline int oip_pos_to_freq(const OipAxisDigits &a, int p)
 
 __host__ __device__ inline int oip_freq_to_pos(const OipAxisDigits &a, int k)
 {
+    if (a.n == 1) return k;
     int p = 0;
     int stride = a.L;
     int rem = k;

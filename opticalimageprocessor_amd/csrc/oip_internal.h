@@ -24,6 +24,26 @@ struct oip_prof_pending {
 
 struct oip_fft_state;   // fft.hip
 
+// cv::resize coefficient tables (resize.cpp builds the same xofs/alpha/yofs/beta on the host)
+struct OipResizeTab {
+    int sw, sh, dw, dh;
+    int *d_xofs;
+    float *d_alpha;     // dw x 4
+    int *d_yofs;
+    float *d_beta;      // dh x 4
+};
+
+// OpenCV imgwarp.cpp interpolateCubic, f32, evaluated on the host exactly as OpenCV does
+// (x86-64, no contraction: every TU is built with -ffp-contract=off)
+static inline void oip_interpolate_cubic_host(float x, float *coeffs)
+{
+    const float A = -0.75f;
+    coeffs[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    coeffs[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    coeffs[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    coeffs[3] = 1.f - coeffs[0] - coeffs[1] - coeffs[2];
+}
+
 struct oip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -49,6 +69,7 @@ struct oip_ctx {
     hipStream_t stage_stream[2] = {nullptr, nullptr};
 
     oip_fft_state *fft = nullptr;
+    std::vector<OipResizeTab> resize_tabs;
 
     // profiling
     bool prof_on = false;

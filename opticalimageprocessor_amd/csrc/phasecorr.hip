@@ -43,36 +43,22 @@ __global__ __launch_bounds__(kBlock) void window_u16_to_f32_kernel(const uint16_
     }
 }
 
-// OpenCV imgwarp.cpp/resize.cpp interpolateCubic in f32, operation by operation
-__device__ __forceinline__ void interp_cubic(float x, float *c)
-{
-    const float A = -0.75f;
-    float x1 = __fadd_rn(x, 1.f);
-    c[0] = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x1), 5 * A), x1), 8 * A), x1), 4 * A);
-    c[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2, x), A + 3), x), x), 1.f);
-    float y = __fsub_rn(1.f, x);
-    c[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2, y), A + 3), y), y), 1.f);
-    c[3] = __fsub_rn(__fsub_rn(__fsub_rn(1.f, c[0]), c[1]), c[2]);
-}
-
-// cv::resize(f32, INTER_CUBIC): fx = (float)((dx+0.5)*scale - 0.5), sx = floor(fx), fx -= sx;
-// horizontal 4 taps (edge replicated) into an f32 row value, then vertical 4 taps.
-__global__ __launch_bounds__(kBlock) void resize_cubic_f32_kernel(const float *__restrict__ src, int sw, int sh,
-                                                                  float *__restrict__ dst, int dw, int dh,
-                                                                  double scale_x, double scale_y)
+// cv::resize(f32, INTER_CUBIC) (OpenCV imgproc/resize.cpp).  The coefficient set-up is done on
+// the host exactly as cv::hal::resize does it -- fx = (float)((dx+0.5)*scale - 0.5),
+// sx = floor(fx), fx -= sx, interpolateCubic(fx) -- and cached per shape; the kernel is the
+// HResizeCubic + VResizeCubic pair: 4 horizontal taps (edge replicated) into an f32 row value,
+// then 4 vertical taps, every product and sum a separate f32 rounding.
+template <typename SrcT>
+__global__ __launch_bounds__(kBlock) void resize_cubic_kernel(const SrcT *__restrict__ src, long spitch, int sw, int sh,
+                                                              float *__restrict__ dst, int dw, int dh,
+                                                              const int *__restrict__ xofs, const float4 *__restrict__ alpha,
+                                                              const int *__restrict__ yofs, const float4 *__restrict__ beta)
 {
     const int dx = blockIdx.x * kBlock + threadIdx.x;
     const int dy = blockIdx.y;
     if (dx >= dw) return;
-    float fx = (float)((dx + 0.5) * scale_x - 0.5);
-    int sx = (int)floorf(fx);
-    fx = __fsub_rn(fx, (float)sx);
-    float fy = (float)((dy + 0.5) * scale_y - 0.5);
-    int sy = (int)floorf(fy);
-    fy = __fsub_rn(fy, (float)sy);
-    float a[4], b[4];
-    interp_cubic(fx, a);
-    interp_cubic(fy, b);
+    const int sx = xofs[dx], sy = yofs[dy];
+    const float4 a = alpha[dx], b = beta[dy];
     int cx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -84,33 +70,18 @@ __global__ __launch_bounds__(kBlock) void resize_cubic_f32_kernel(const float *_
     for (int k = 0; k < 4; ++k) {
         int yk = sy - 1 + k;
         yk = yk < 0 ? 0 : (yk > sh - 1 ? sh - 1 : yk);
-        const float *S = src + (size_t)yk * sw;
-        float v = __fmul_rn(S[cx[0]], a[0]);
-        v = __fadd_rn(v, __fmul_rn(S[cx[1]], a[1]));
-        v = __fadd_rn(v, __fmul_rn(S[cx[2]], a[2]));
-        v = __fadd_rn(v, __fmul_rn(S[cx[3]], a[3]));
+        const SrcT *S = src + (size_t)yk * spitch;
+        float v = __fmul_rn((float)S[cx[0]], a.x);
+        v = __fadd_rn(v, __fmul_rn((float)S[cx[1]], a.y));
+        v = __fadd_rn(v, __fmul_rn((float)S[cx[2]], a.z));
+        v = __fadd_rn(v, __fmul_rn((float)S[cx[3]], a.w));
         r[k] = v;
     }
-    float o = __fmul_rn(r[0], b[0]);
-    o = __fadd_rn(o, __fmul_rn(r[1], b[1]));
-    o = __fadd_rn(o, __fmul_rn(r[2], b[2]));
-    o = __fadd_rn(o, __fmul_rn(r[3], b[3]));
+    float o = __fmul_rn(r[0], b.x);
+    o = __fadd_rn(o, __fmul_rn(r[1], b.y));
+    o = __fadd_rn(o, __fmul_rn(r[2], b.z));
+    o = __fadd_rn(o, __fmul_rn(r[3], b.w));
     dst[(size_t)dy * dw + dx] = o;
-}
-
-// ---- pack two real images into one zero-padded complex image ----------------------------------
-__global__ __launch_bounds__(kBlock) void pack_kernel(float2 *__restrict__ z, int M, int N, const float *__restrict__ re,
-                                                      const float *__restrict__ im, int rows, int cols)
-{
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= N) return;
-    float2 v = make_float2(0.f, 0.f);
-    if (y < rows && x < cols) {
-        v.x = re[(size_t)y * cols + x];
-        if (im) v.y = im[(size_t)y * cols + x];
-    }
-    z[(size_t)y * N + x] = v;
 }
 
 // ---- cross-power spectrum -----------------------------------------------------------------------
@@ -123,14 +94,14 @@ struct XpowerJob {
     int ncorr;          // 1 or 2 (second goes to the imaginary slot of the output)
 };
 
-__device__ __forceinline__ float2 spec_of(const SpecRef &s, long pk, long pmk)
+__device__ __forceinline__ float2 spec_of(int part, float2 zk, float2 zm)
 {
-    float2 zk = s.z[pk], zm = s.z[pmk];
-    if (s.part == 0) return make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    if (part == 0) return make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
     return make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
 }
 
-// C for one stored bin, following mulSpectrums/magSpectrums/divSpectrums
+// C for one bin, following mulSpectrums/magSpectrums/divSpectrums.  The formulas are odd in the
+// imaginary part, so C(-k) == conj(C(k)) bit for bit: the CCS-implied half needs no own path.
 __device__ __forceinline__ float2 cross_power_bin(float2 A, float2 B, bool real_bin, bool edge_col)
 {
     const float eps = FLT_EPSILON;
@@ -154,133 +125,95 @@ __device__ __forceinline__ float2 cross_power_bin(float2 A, float2 B, bool real_
     return make_float2((float)__ddiv_rn(re, denom), (float)__ddiv_rn(im, denom));
 }
 
+// One workgroup row handles the spectrum line of frequency ky AND its mirror -ky: every input
+// line is read once, C(k) is computed once and written as Y(k) and Y(-k) = conj(C1) + i conj(C2).
+// The x axis of the reference shapes is a single pass (natural order), so the mirrored
+// column N-kx is a reversed, still coalesced, access.
 __global__ __launch_bounds__(kBlock) void cross_power_kernel(float2 *__restrict__ out, XpowerJob job, int M, int N,
                                                              OipAxisDigits yd, OipAxisDigits xd)
 {
     const int px = blockIdx.x * kBlock + threadIdx.x;
-    const int py = blockIdx.y;
+    const int ky = blockIdx.y;                        // 0 .. M/2
     if (px >= N) return;
     const int kx = oip_pos_to_freq(xd, px);
-    const int ky = oip_pos_to_freq(yd, py);
     const int nkx = kx ? N - kx : 0, nky = ky ? M - ky : 0;
-    // CCS stores kx in [0, N/2]; in the first / Nyquist column only ky <= M/2
+    const long r1 = (long)oip_freq_to_pos(yd, ky) * N, r2 = (long)oip_freq_to_pos(yd, nky) * N;
+    const int px2 = oip_freq_to_pos(xd, nkx);
     const bool edge_col = (kx == 0) || (2 * kx == N);
-    bool stored;
-    if (edge_col) stored = 2 * ky <= M;
-    else stored = 2 * kx < N;
-    const int cky = stored ? ky : nky, ckx = stored ? kx : nkx;
-    const int mky = stored ? nky : ky, mkx = stored ? nkx : kx;
-    const long pk = (long)oip_freq_to_pos(yd, cky) * N + oip_freq_to_pos(xd, ckx);
-    const long pmk = (long)oip_freq_to_pos(yd, mky) * N + oip_freq_to_pos(xd, mkx);
-    const bool real_bin = edge_col && (cky == 0 || 2 * cky == M);
-    float2 y = make_float2(0.f, 0.f);
+    const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+    float2 y = make_float2(0.f, 0.f), ym = make_float2(0.f, 0.f);
+    float2 zk[3], zm[3];
+    const float2 *arr[3] = {nullptr, nullptr, nullptr};
+    int narr = 0;
+    // distinct input arrays of the job (at most 3)
+    for (int c = 0; c < job.ncorr; ++c)
+        for (int s = 0; s < 2; ++s) {
+            const float2 *z = s ? job.b[c].z : job.a[c].z;
+            bool seen = false;
+            for (int i = 0; i < narr; ++i) seen = seen || arr[i] == z;
+            if (!seen && narr < 3) arr[narr++] = z;
+        }
+    for (int i = 0; i < narr; ++i) { zk[i] = arr[i][r1 + px]; zm[i] = arr[i][r2 + px2]; }
     for (int c = 0; c < job.ncorr; ++c) {
-        float2 A = spec_of(job.a[c], pk, pmk);
-        float2 B = spec_of(job.b[c], pk, pmk);
+        int ia = 0, ib = 0;
+        for (int i = 0; i < narr; ++i) { if (arr[i] == job.a[c].z) ia = i; if (arr[i] == job.b[c].z) ib = i; }
+        float2 A = spec_of(job.a[c].part, zk[ia], zm[ia]);
+        float2 B = spec_of(job.b[c].part, zk[ib], zm[ib]);
         float2 C = cross_power_bin(A, B, real_bin, edge_col);
-        if (!stored) C.y = -C.y;
-        if (c == 0) { y.x += C.x; y.y += C.y; }       // Y = C1 + i C2
-        else { y.x -= C.y; y.y += C.x; }
+        if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }        // Y = C1 + i C2
+        else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }               // i*conj(C2) = (C2.y, C2.x)
     }
-    out[(long)py * N + px] = y;
+    out[r1 + px] = y;
+    if (r1 != r2) out[r2 + px2] = ym;
 }
 
 // ---- peak: first maximum of the fftShift-ed surface + 5x5 weighted centroid ----------------------
-struct PeakPartial {
-    float val;
-    int pad;
-    long key;           // index in the shifted image, row-major
-};
+__device__ __forceinline__ bool pk_better(float v, long k, float bv, long bk) { return v > bv || (v == bv && k < bk); }
 
-__device__ __forceinline__ bool peak_better(float v, long k, float bv, long bk)
-{
-    return v > bv || (v == bv && k < bk);
-}
-
-__global__ __launch_bounds__(kBlock) void peak_partial_kernel(const float2 *__restrict__ c, int part, int M, int N,
-                                                              PeakPartial *__restrict__ partials)
-{
-    __shared__ float sval[kBlock];
-    __shared__ long skey[kBlock];
-    const long n = (long)M * N;
-    float bv = -INFINITY;
-    long bk = n;            // any real element beats this
-    const int ym = M >> 1, xm = N >> 1;
-    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
-        int y = (int)(i / N), x = (int)(i - (long)y * N);
-        float v = part ? c[i].y : c[i].x;
-        int ys = y + ym; if (ys >= M) ys -= M;
-        int xs = x + xm; if (xs >= N) xs -= N;
-        long key = (long)ys * N + xs;
-        // minMaxLoc skips nothing; NaN never compares greater, like the reference's scan
-        if (peak_better(v, key, bv, bk)) { bv = v; bk = key; }
-    }
-    sval[threadIdx.x] = bv;
-    skey[threadIdx.x] = bk;
-    __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            if (peak_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
-                sval[threadIdx.x] = sval[threadIdx.x + s];
-                skey[threadIdx.x] = skey[threadIdx.x + s];
-            }
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        partials[blockIdx.x].val = sval[0];
-        partials[blockIdx.x].key = skey[0];
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void peak_final_kernel(const float2 *__restrict__ c, int part, int M, int N,
-                                                            const PeakPartial *__restrict__ partials, int npart,
-                                                            double *__restrict__ result)
+// reduce the per-tile maxima the last inverse pass left behind
+__global__ __launch_bounds__(kBlock) void peak_final_kernel(const OipPeakPartial *__restrict__ partials, int npart,
+                                                            long mn, long *__restrict__ key_out)
 {
     __shared__ float sval[kBlock];
     __shared__ long skey[kBlock];
     float bv = -INFINITY;
-    long bk = (long)M * N;
+    long bk = mn;
     for (int i = threadIdx.x; i < npart; i += kBlock)
-        if (peak_better(partials[i].val, partials[i].key, bv, bk)) { bv = partials[i].val; bk = partials[i].key; }
+        if (pk_better(partials[i].val, partials[i].key, bv, bk)) { bv = partials[i].val; bk = partials[i].key; }
     sval[threadIdx.x] = bv;
     skey[threadIdx.x] = bk;
     __syncthreads();
     for (int s = kBlock / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            if (peak_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
-                sval[threadIdx.x] = sval[threadIdx.x + s];
-                skey[threadIdx.x] = skey[threadIdx.x + s];
-            }
+        if (threadIdx.x < s && pk_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
+            sval[threadIdx.x] = sval[threadIdx.x + s];
+            skey[threadIdx.x] = skey[threadIdx.x + s];
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
-    long key = skey[0];
-    if (key >= (long)M * N) key = 0;                 // all-NaN surface: minMaxLoc leaves (0,0)
-    const int py = (int)(key / N), px = (int)(key - (long)py * N);
-    // weightedCentroid(C, peak, Size(5,5), &response)   (phasecorr.cpp)
-    int minr = py - 2, maxr = py + 2, minc = px - 2, maxc = px + 2;
-    if (minr < 0) minr = 0;
-    if (minc < 0) minc = 0;
-    if (maxr > M - 1) maxr = M - 1;
-    if (maxc > N - 1) maxc = N - 1;
-    const int ym = M >> 1, xm = N >> 1;
+    if (threadIdx.x == 0) *key_out = skey[0] >= mn ? 0 : skey[0];      // all-NaN surface: minMaxLoc leaves (0,0)
+}
+
+// weightedCentroid(C, peak, Size(5,5), &response) (phasecorr.cpp) on the recomputed window;
+// NaN marks window cells outside the image (the reference clamps the window to the image).
+__global__ void centroid_kernel(const float *__restrict__ window, const long *__restrict__ key, int M, int N,
+                                double *__restrict__ result)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int py = (int)(*key / N), px = (int)(*key - (long)py * N);
     double cxs = 0.0, cys = 0.0, si = 0.0;
-    for (int y = minr; y <= maxr; ++y) {
-        int yo = y - ym; if (yo < 0) yo += M;        // shifted(y) = original((y - yMid) mod M)
-        for (int x = minc; x <= maxc; ++x) {
-            int xo = x - xm; if (xo < 0) xo += N;
-            float2 e = c[(long)yo * N + xo];
-            double v = (double)(part ? e.y : e.x);
+    for (int dy = 0; dy < 5; ++dy)
+        for (int dx = 0; dx < 5; ++dx) {
+            const float f = window[dy * 5 + dx];
+            const int y = py - 2 + dy, x = px - 2 + dx;
+            if (y < 0 || y >= M || x < 0 || x >= N) continue;
+            const double v = (double)f;
             cxs = __dadd_rn(cxs, __dmul_rn((double)x, v));
             cys = __dadd_rn(cys, __dmul_rn((double)y, v));
             si = __dadd_rn(si, v);
         }
-    }
     double response = si;
     si = __dadd_rn(si, DBL_EPSILON);
-    double cx = cxs / si, cy = cys / si;
+    const double cx = cxs / si, cy = cys / si;
     response = response / (double)((long)M * N);
     result[0] = (double)N / 2.0 - cx;
     result[1] = (double)M / 2.0 - cy;
@@ -318,18 +251,21 @@ struct PcWork {
     float *fa;          // base window, f32
     float *fb[4];       // second images, f32 (up-sampled bands)
     float *fsmall;      // MSS window before resize
-    PeakPartial *partials;
+    OipPeakPartial *partials;   // [2][npart]
     int npart;
+    long *keys;         // peak key scratch
+    float *window;      // 25 floats
 };
 
-int carve(oip_ctx *ctx, int M, int N, int rows, int cols, int small_elems, int nz, int ny, int nfb, PcWork *w)
+int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_elems, int nz, int ny, int nfb, PcWork *w)
 {
+    const int M = pl->M, N = pl->N;
     const size_t zbytes = align_up(sizeof(float2) * (size_t)M * N, 256);
     const size_t fbytes = align_up(sizeof(float) * (size_t)rows * cols, 256);
     const size_t sbytes = align_up(sizeof(float) * (size_t)(small_elems > 0 ? small_elems : 1), 256);
-    w->npart = ctx->cu_count * 8;
-    const size_t pbytes = align_up(sizeof(PeakPartial) * w->npart, 256);
-    size_t total = zbytes * (nz + ny) + fbytes * (1 + nfb) + sbytes + pbytes;
+    w->npart = (int)oip_fft2d_last_pass_blocks(pl);
+    const size_t pbytes = align_up(sizeof(OipPeakPartial) * 2 * (size_t)w->npart, 256);
+    size_t total = zbytes * (nz + ny) + fbytes * (1 + nfb) + sbytes + pbytes + 512;
     void *ws;
     int rc = oip_workspace(ctx, total, &ws);
     if (rc) return rc;
@@ -339,7 +275,9 @@ int carve(oip_ctx *ctx, int M, int N, int rows, int cols, int small_elems, int n
     w->fa = (float *)p; p += fbytes;
     for (int i = 0; i < 4; ++i) { w->fb[i] = i < nfb ? (float *)p : nullptr; if (i < nfb) p += fbytes; }
     w->fsmall = (float *)p; p += sbytes;
-    w->partials = (PeakPartial *)p;
+    w->partials = (OipPeakPartial *)p; p += pbytes;
+    w->keys = (long *)p; p += 256;
+    w->window = (float *)p;
     return OIP_OK;
 }
 
@@ -357,79 +295,143 @@ int launch_window(oip_ctx *ctx, const uint16_t *img, size_t pitch, long row0, in
     return OIP_OK;
 }
 
-int launch_resize(oip_ctx *ctx, const float *src, int sw, int sh, float *dst, int dw, int dh)
+int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeTab **out)
 {
-    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
-    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-    OipProfScope prof(ctx, "resize_cubic_f32_kernel");
-    hipLaunchKernelGGL(resize_cubic_f32_kernel, dim3((dw + kBlock - 1) / kBlock, dh), dim3(kBlock), 0, ctx->stream, src,
-                       sw, sh, dst, dw, dh, scale_x, scale_y);
+    for (auto &t : ctx->resize_tabs)
+        if (t.sw == sw && t.sh == sh && t.dw == dw && t.dh == dh) { *out = &t; return OIP_OK; }
+    // cv::hal::resize coefficient set-up (resize.cpp), on the host in the same float/double mix
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    std::vector<int> xofs(dw), yofs(dh);
+    std::vector<float> alpha((size_t)dw * 4), beta((size_t)dh * 4);
+    for (int dx = 0; dx < dw; ++dx) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        xofs[dx] = sx;
+        oip_interpolate_cubic_host(fx, &alpha[(size_t)dx * 4]);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        oip_interpolate_cubic_host(fy, &beta[(size_t)dy * 4]);
+    }
+    OipResizeTab t;
+    t.sw = sw; t.sh = sh; t.dw = dw; t.dh = dh;
+    OIP_HIP(ctx, hipMalloc((void **)&t.d_xofs, sizeof(int) * dw));
+    OIP_HIP(ctx, hipMalloc((void **)&t.d_alpha, sizeof(float) * 4 * dw));
+    OIP_HIP(ctx, hipMalloc((void **)&t.d_yofs, sizeof(int) * dh));
+    OIP_HIP(ctx, hipMalloc((void **)&t.d_beta, sizeof(float) * 4 * dh));
+    OIP_HIP(ctx, hipMemcpy(t.d_xofs, xofs.data(), sizeof(int) * dw, hipMemcpyHostToDevice));
+    OIP_HIP(ctx, hipMemcpy(t.d_alpha, alpha.data(), sizeof(float) * 4 * dw, hipMemcpyHostToDevice));
+    OIP_HIP(ctx, hipMemcpy(t.d_yofs, yofs.data(), sizeof(int) * dh, hipMemcpyHostToDevice));
+    OIP_HIP(ctx, hipMemcpy(t.d_beta, beta.data(), sizeof(float) * 4 * dh, hipMemcpyHostToDevice));
+    ctx->resize_tabs.push_back(t);
+    *out = &ctx->resize_tabs.back();
+    return OIP_OK;
+}
+
+template <typename SrcT>
+int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, float *dst, int dw, int dh)
+{
+    const OipResizeTab *t;
+    int rc = resize_tables(ctx, sw, sh, dw, dh, &t);
+    if (rc) return rc;
+    OipProfScope prof(ctx, "resize_cubic_kernel");
+    hipLaunchKernelGGL(resize_cubic_kernel<SrcT>, dim3((dw + kBlock - 1) / kBlock, dh), dim3(kBlock), 0, ctx->stream, src,
+                       spitch, sw, sh, dst, dw, dh, t->d_xofs, reinterpret_cast<const float4 *>(t->d_alpha), t->d_yofs,
+                       reinterpret_cast<const float4 *>(t->d_beta));
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
 
-int launch_pack(oip_ctx *ctx, float2 *z, int M, int N, const float *re, const float *im, int rows, int cols)
+// one real image of a packed pair: an f32 image (pitch == cols) or a u16 raster window
+struct RealSrc {
+    const float *f32;
+    const uint16_t *u16;
+    long pitch16;
+};
+inline RealSrc src_f32(const float *p) { return RealSrc{p, nullptr, 0}; }
+inline RealSrc src_u16(const uint16_t *p, long pitch) { return RealSrc{nullptr, p, pitch}; }
+inline RealSrc src_none() { return RealSrc{nullptr, nullptr, 0}; }
+
+// forward transform of z = re + i im, the two f32 images read directly by the first pass
+int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, RealSrc im, int rows, int cols)
 {
-    OipProfScope prof(ctx, "pack_kernel");
-    hipLaunchKernelGGL(pack_kernel, dim3((N + kBlock - 1) / kBlock, M), dim3(kBlock), 0, ctx->stream, z, M, N, re, im,
-                       rows, cols);
-    OIP_HIP(ctx, hipGetLastError());
-    return OIP_OK;
+    OipFftIo io;
+    memset(&io, 0, sizeof io);
+    io.load_kind = 1;
+    io.re = re.f32; io.re16 = re.u16; io.pitch_re16 = re.pitch16;
+    io.im = im.f32; io.im16 = im.u16; io.pitch_im16 = im.pitch16;
+    io.rows = rows; io.cols = cols;
+    return oip_fft2d_exec(ctx, pl, z, 0, &io);
 }
 
 int launch_xpower(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2dPlan *pl)
 {
     OipProfScope prof(ctx, "cross_power_kernel");
-    hipLaunchKernelGGL(cross_power_kernel, dim3((pl->N + kBlock - 1) / kBlock, pl->M), dim3(kBlock), 0, ctx->stream, out,
-                       job, pl->M, pl->N, digits_of(pl->yf, pl->M), digits_of(pl->xf, pl->N));
+    hipLaunchKernelGGL(cross_power_kernel, dim3((pl->N + kBlock - 1) / kBlock, pl->M / 2 + 1), dim3(kBlock), 0,
+                       ctx->stream, out, job, pl->M, pl->N, digits_of(pl->yf, pl->M), digits_of(pl->xf, pl->N));
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
 
-int launch_peak(oip_ctx *ctx, const float2 *c, int part, int M, int N, const PcWork &w, double *d_result)
+// inverse transform of y whose last pass only leaves per-tile maxima, then for each wanted part:
+// arg-max -> recompute the 5x5 window -> centroid -> result slot
+int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, float2 *y, int nparts, double *d_results)
 {
-    long n = (long)M * N;
-    int blocks = (int)((n + kBlock - 1) / kBlock < w.npart ? (n + kBlock - 1) / kBlock : w.npart);
-    {
-        OipProfScope prof(ctx, "peak_partial_kernel");
-        hipLaunchKernelGGL(peak_partial_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, c, part, M, N, w.partials);
+    OipFftIo io;
+    memset(&io, 0, sizeof io);
+    io.store_kind = 1;
+    io.partials = w.partials;
+    int rc = oip_fft2d_exec(ctx, pl, y, 1, &io);
+    if (rc) return rc;
+    for (int part = 0; part < nparts; ++part) {
+        {
+            OipProfScope prof(ctx, "peak_final_kernel");
+            hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, w.partials + (size_t)part * w.npart,
+                               w.npart, (long)pl->M * pl->N, w.keys + part);
+        }
+        OipFftIo wio;
+        memset(&wio, 0, sizeof wio);
+        wio.peak_key = w.keys + part;
+        wio.window = w.window + 32 * part;
+        wio.part = part;
+        if ((rc = oip_fft2d_window(ctx, pl, y, &wio))) return rc;
+        {
+            OipProfScope prof(ctx, "centroid_kernel");
+            hipLaunchKernelGGL(centroid_kernel, dim3(1), dim3(64), 0, ctx->stream, w.window + 32 * part, w.keys + part,
+                               pl->M, pl->N, d_results + 3 * part);
+        }
+        OIP_HIP(ctx, hipGetLastError());
     }
-    {
-        OipProfScope prof(ctx, "peak_final_kernel");
-        hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, c, part, M, N, w.partials, blocks,
-                           d_result);
-    }
-    OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
 
 // one pair (a, b) -> result slot
-int correlate_pair(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, const float *a, const float *b, int rows,
+int correlate_pair(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, RealSrc b, int rows,
                    int cols, double *d_result)
 {
-    int rc = launch_pack(ctx, w.z[0], pl->M, pl->N, a, b, rows, cols);
+    int rc = forward_packed(ctx, pl, w.z[0], a, b, rows, cols);
     if (rc) return rc;
-    if ((rc = oip_fft2d_exec(ctx, pl, w.z[0], 0))) return rc;
     XpowerJob job;
     memset(&job, 0, sizeof job);
     job.ncorr = 1;
     job.a[0] = {w.z[0], 0};
     job.b[0] = {w.z[0], 1};
     if ((rc = launch_xpower(ctx, w.y[0], job, pl))) return rc;
-    if ((rc = oip_fft2d_exec(ctx, pl, w.y[0], 1))) return rc;
-    return launch_peak(ctx, w.y[0], 0, pl->M, pl->N, w, d_result);
+    return inverse_and_peaks(ctx, pl, w, w.y[0], 1, d_result);
 }
 
 // base image a against four images b0..b3: 3 forward + 2 inverse complex transforms
-int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, const float *a, float *const b[4],
+int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, float *const b[4],
                           int rows, int cols, double *d_results /* 4 x 3 */)
 {
     int rc;
-    if ((rc = launch_pack(ctx, w.z[0], pl->M, pl->N, a, b[0], rows, cols))) return rc;
-    if ((rc = launch_pack(ctx, w.z[1], pl->M, pl->N, b[1], b[2], rows, cols))) return rc;
-    if ((rc = launch_pack(ctx, w.z[2], pl->M, pl->N, b[3], nullptr, rows, cols))) return rc;
-    for (int i = 0; i < 3; ++i)
-        if ((rc = oip_fft2d_exec(ctx, pl, w.z[i], 0))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], a, src_f32(b[0]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(b[1]), src_f32(b[2]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], src_f32(b[3]), src_none(), rows, cols))) return rc;
     XpowerJob j0, j1;
     memset(&j0, 0, sizeof j0);
     memset(&j1, 0, sizeof j1);
@@ -441,11 +443,8 @@ int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w,
     j1.a[1] = {w.z[0], 0}; j1.b[1] = {w.z[2], 0};
     if ((rc = launch_xpower(ctx, w.y[0], j0, pl))) return rc;
     if ((rc = launch_xpower(ctx, w.y[1], j1, pl))) return rc;
-    for (int i = 0; i < 2; ++i)
-        if ((rc = oip_fft2d_exec(ctx, pl, w.y[i], 1))) return rc;
-    for (int c = 0; c < 4; ++c)
-        if ((rc = launch_peak(ctx, w.y[c >> 1], c & 1, pl->M, pl->N, w, d_results + 3 * c))) return rc;
-    return OIP_OK;
+    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results))) return rc;
+    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6);
 }
 
 int fetch_results(oip_ctx *ctx, int count, double *host_out)
@@ -472,7 +471,7 @@ extern "C" int oip_resize_cubic_f32(oip_ctx *ctx, const float *d_src, int sw, in
     OIP_CHECK_CTX(ctx);
     if (!d_src || !d_dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || dh > 65535)
         return oip_fail(ctx, OIP_E_INVALID, "oip_resize_cubic_f32: bad argument");
-    return launch_resize(ctx, d_src, sw, sh, d_dst, dw, dh);
+    return launch_resize<float>(ctx, d_src, sw, sw, sh, d_dst, dw, dh);
 }
 
 extern "C" int oip_phase_correlate_f32(oip_ctx *ctx, const float *d_a, const float *d_b, int rows, int cols, double *dx,
@@ -486,9 +485,9 @@ extern "C" int oip_phase_correlate_f32(oip_ctx *ctx, const float *d_a, const flo
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, M, N, 1, 1, 0, 1, 1, 0, &w))) return rc;
+    if ((rc = carve(ctx, pl, 1, 1, 0, 1, 1, 0, &w))) return rc;
     double *d_res = (double *)ctx->d_small;
-    if ((rc = correlate_pair(ctx, pl, w, d_a, d_b, rows, cols, d_res))) return rc;
+    if ((rc = correlate_pair(ctx, pl, w, src_f32(d_a), src_f32(d_b), rows, cols, d_res))) return rc;
     double r[3];
     if ((rc = fetch_results(ctx, 3, r))) return rc;
     if (dx) *dx = r[0];
@@ -515,7 +514,7 @@ extern "C" int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uin
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, M, N, rows, cols, 0, 1, 1, 1, &w))) return rc;
+    if ((rc = carve(ctx, pl, 1, 1, 0, 1, 1, 0, &w))) return rc;
     // stitcher.h:151-152, :167
     const long gap = (L - (long)sections * lines_per_section) / (sections + 1);
     const long step = gap + lines_per_section;
@@ -525,10 +524,11 @@ extern "C" int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uin
         const long off = gap + (long)s * step;
         if (off < row0 || off + rows > row0 + nrows) continue;     // another rank's section
         have[s] = 1;
-        // stitcher.h:175-176: PAN1 cols [W-ov, W-edge), PAN2 cols [edge, ov)
-        if ((rc = launch_window(ctx, d_pan1, W, off - row0, W - overlap_cols, rows, cols, w.fa))) return rc;
-        if ((rc = launch_window(ctx, d_pan2, W, off - row0, edge_cols, rows, cols, w.fb[0]))) return rc;
-        if ((rc = correlate_pair(ctx, pl, w, w.fa, w.fb[0], rows, cols, d_res + 3 * s))) return rc;
+        // stitcher.h:175-176: PAN1 cols [W-ov, W-edge), PAN2 cols [edge, ov); the u16->f32
+        // conversion happens in the first FFT pass' loader
+        const uint16_t *a = d_pan1 + (size_t)(off - row0) * W + (W - overlap_cols);
+        const uint16_t *b = d_pan2 + (size_t)(off - row0) * W + edge_cols;
+        if ((rc = correlate_pair(ctx, pl, w, src_u16(a, W), src_u16(b, W), rows, cols, d_res + 3 * s))) return rc;
     }
     std::vector<double> r(3 * sections);
     if ((rc = fetch_results(ctx, 3 * sections, r.data()))) return rc;
@@ -567,7 +567,7 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, M, N, baseRows, baseSliceCols, bandRows * bandSliceCols, 3, 2, 4, &w))) return rc;
+    if ((rc = carve(ctx, pl, baseRows, baseSliceCols, 0, 3, 2, 4, &w))) return rc;
     double *d_res = (double *)ctx->d_small;
     const int n = slices * sections;
     std::vector<int> have(n, 0);
@@ -579,13 +579,14 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
         for (int i = 0; i < slices; ++i) {
             const int u = sec * slices + i;
             have[u] = 1;
-            if ((rc = launch_window(ctx, d_pan, W, secRowStart - prow0, i * baseSliceCols, baseRows, baseSliceCols, w.fa))) return rc;
+            // PAN window: read as u16 by the FFT loader; MSS windows: up-sampled x4 straight from u16
+            const uint16_t *pw = d_pan + (size_t)(secRowStart - prow0) * W + (size_t)i * baseSliceCols;
             for (int b = 0; b < OIP_MSS_BANDS; ++b) {
-                if ((rc = launch_window(ctx, d_planes + (size_t)b * plane_stride, Wb, secBandRowStart - mrow0,
-                                        i * bandSliceCols, bandRows, bandSliceCols, w.fsmall))) return rc;
-                if ((rc = launch_resize(ctx, w.fsmall, bandSliceCols, bandRows, w.fb[b], baseSliceCols, baseRows))) return rc;
+                const uint16_t *bw = d_planes + (size_t)b * plane_stride + (size_t)(secBandRowStart - mrow0) * Wb +
+                                     (size_t)i * bandSliceCols;
+                if ((rc = launch_resize<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, w.fb[b], baseSliceCols, baseRows))) return rc;
             }
-            if ((rc = correlate_one_to_four(ctx, pl, w, w.fa, w.fb, baseRows, baseSliceCols, d_res + 12 * u))) return rc;
+            if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(pw, W), w.fb, baseRows, baseSliceCols, d_res + 12 * u))) return rc;
         }
     }
     std::vector<double> r(12 * n);

@@ -66,15 +66,19 @@ def scene_rows(row0: int, rows: int, cols: int, field_cols: int, seed: int = 0, 
     step = 4096
     for sigma, weight in octaves:
         k, r = _gauss_kernel(sigma, device)
-        kx = k.view(1, 1, 1, -1)
-        ky = k.view(1, 1, -1, 1)
+        kl = [float(v) for v in k.tolist()]
         gain = amp * weight / float((k * k).sum())       # unit variance after the separable blur
         for y in range(0, rows, step):
             m = min(step, rows - y)
-            t = n[y + R - r:y + m + R + r, R - r:R + cols + r].unsqueeze(0).unsqueeze(0)
-            t = torch.nn.functional.conv2d(t, kx)
-            t = torch.nn.functional.conv2d(t, ky)
-            out[y:y + m] += gain * t[0, 0]
+            t = n[y + R - r:y + m + R + r, R - r:R + cols + r]
+            # separable Gaussian as explicit shifted adds (no MIOpen: its conv search is slow)
+            h = kl[0] * t[:, 0:cols]
+            for j in range(1, 2 * r + 1):
+                h = h + kl[j] * t[:, j:j + cols]
+            v = kl[0] * h[0:m]
+            for j in range(1, 2 * r + 1):
+                v = v + kl[j] * h[j:j + m]
+            out[y:y + m] += gain * v
     gy = torch.arange(row0, row0 + rows, dtype=torch.float32, device=device)
     out += (base + 200.0 * torch.sin(gy / 30000.0)).unsqueeze(1)
     return out

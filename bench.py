@@ -59,6 +59,7 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
     win = base_rows * base_cols
     d = {
         "rrc_u16_kernel": 4.0 * W * pb,                       # 2 B read + 2 B written per pixel
+        "rrc_u16_flat_kernel": 4.0 * W * pb,
         "mss_split_rrc_kernel": 4.0 * W * mb,
         "cross_power_kernel": 8.0 * MN * 3.5,                 # 2 or 3 spectra in, 1 out
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out
@@ -298,8 +299,9 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
-        if "rrc_u16_kernel" in kernels and "algorithmic_GBs" in kernels["rrc_u16_kernel"]:
-            g = kernels["rrc_u16_kernel"]["algorithmic_GBs"]
+        rk = "rrc_u16_flat_kernel" if "rrc_u16_flat_kernel" in kernels else "rrc_u16_kernel"
+        if rk in kernels and "algorithmic_GBs" in kernels[rk]:
+            g = kernels[rk]["algorithmic_GBs"]
             line["rrc_kernel"] = {"GBs_read_plus_write": g, "frac_of_8TBs": g / HBM_PEAK_GBS,
                                   "GBs_read_only": g / 2, "Mpix_s": g / 4 * 1e3}
         if world == 1 and not args.no_cpu_baseline and args.workload == "default":

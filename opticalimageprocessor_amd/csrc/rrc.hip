@@ -5,13 +5,17 @@
 //
 //   dst = (uint16_t)(k[x] * src + b[x])            -- fp64, two roundings, no FMA
 //
-// Layout / mapping.  HBM-bound: 2 B read + 2 B written per pixel.  A lane owns V
-// consecutive columns (V=8: one 16-byte access, V=4: one 8-byte access), keeps their V
-// (k,b) pairs in VGPRs and walks down the rows of its row block, ROWS_IN_FLIGHT rows at a
-// time so every lane has that many independent 16-byte loads outstanding.  A wave touches
-// 64*V*2 B = 1 KiB of contiguous line per row; a 256-thread block 4 KiB.  blockIdx.x runs
-// along the line, blockIdx.y over row blocks; the grid is sized to several blocks per CU.
-// No LDS: there is no reuse beyond the LUT, which lives in registers.
+// Layout / mapping.  HBM-bound: 2 B read + 2 B written per pixel.  A lane owns 8 consecutive
+// pixels (one 16-byte chunk) and keeps their 8 (k,b) pairs in VGPRs; no LDS (no reuse beyond
+// the LUT).  What decides the bandwidth is line alignment of the STORES: a 30000-pixel line is
+// 60000 B, not a multiple of 128 B, so a wave that follows line boundaries writes partial cache
+// lines (measured: 4.4-4.7 TB/s, profiles/experiments/rrc_variants.hip).  The main kernel
+// therefore treats the raster as a flat array of 16-byte chunks: a wave always covers 64
+// consecutive chunks starting on a 1 KiB boundary of the destination, and a lane advances by
+// lcm(chunks per line, 64) chunks -- a whole number of lines -- so its 8 columns, hence its
+// LUT registers, never change while every access is a full aligned KiB (measured 5.7 TB/s =
+// 72 % of the 8 TB/s HBM3E peak on 30000 x 65536).  Widths that are not a multiple of 8 fall
+// back to the column-owned 8-byte kernel, anything else to a scalar kernel.
 //
 // Conversion.  The reference's double->uint16_t cast is what x86-64 compilers emit for it:
 // cvttsd2si (32-bit, truncating; 0x80000000 when out of range or NaN) followed by a 16-bit
@@ -51,6 +55,50 @@ __device__ __forceinline__ typename Vec<V>::type rrc_vec(typename Vec<V>::type i
 #pragma unroll
     for (int i = 0; i < V / 2; ++i) q[i] = w[i];
     return out;
+}
+
+// flat, line-aligned, column-fixed (see header).  f = chunk index in the raster, g = f + a its
+// index in the destination's 1 KiB-aligned frame (a = misalignment of dst in chunks, 0..63);
+// lane g0 of super-row 0 handles g0, g0 + sr, g0 + 2 sr, ...  src may alias dst.
+__global__ __launch_bounds__(kBlock) void rrc_u16_flat_kernel(const uint16_t *src, uint16_t *dst, int P, long nchunks,
+                                                              long sr, int a, const double2 *__restrict__ kb,
+                                                              long nsuper, long super_per_block)
+{
+    const long g0 = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (g0 >= sr) return;
+    const long f0 = g0 - a;
+    int cc = (int)(f0 % P);
+    if (cc < 0) cc += P;
+    const int col = cc * 8;
+    double k[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double2 p = kb[col + i];
+        k[i] = p.x;
+        b[i] = p.y;
+    }
+    const long s0 = (long)blockIdx.y * super_per_block;
+    long s1 = s0 + super_per_block;
+    if (s1 > nsuper) s1 = nsuper;
+    long f = f0 + s0 * sr;
+    const uint4 *s = reinterpret_cast<const uint4 *>(src) + f;
+    uint4 *d = reinterpret_cast<uint4 *>(dst) + f;
+    for (long q = s0; q < s1; q += kRowsInFlight) {
+        uint4 v[kRowsInFlight];
+        bool ok[kRowsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) {
+            const long fu = f + u * sr;
+            ok[u] = q + u < s1 && fu >= 0 && fu < nchunks;
+            if (ok[u]) v[u] = s[u * sr];
+        }
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u)
+            if (ok[u]) d[u * sr] = rrc_vec<8>(v[u], k, b);
+        s += kRowsInFlight * sr;
+        d += kRowsInFlight * sr;
+        f += kRowsInFlight * sr;
+    }
 }
 
 // planar raster, column-owned.  src may alias dst (in-place, as the reference).
@@ -203,14 +251,23 @@ extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst,
     OIP_CHECK_CTX(ctx);
     if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16: bad argument");
     if (h == 0) return OIP_OK;
-    OipProfScope prof(ctx, "rrc_u16_kernel");
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
     const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
+    OipProfScope prof(ctx, (w % 8 == 0 && (align & 15) == 0) ? "rrc_u16_flat_kernel" : "rrc_u16_kernel");
     if (w % 8 == 0 && (align & 15) == 0) {
-        int gx = (w / 8 + kBlock - 1) / kBlock, gy;
-        long rpb;
-        row_blocks(ctx, gx, h, &rpb, &gy);
-        hipLaunchKernelGGL(rrc_u16_kernel<8>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, h, kb, rpb);
+        const int P = w / 8;
+        long g = P, t = 64;
+        while (t) { long r = g % t; g = t; t = r; }
+        const long sr = (long)P / g * 64;                          // lcm(P, 64) chunks = whole lines
+        const long nchunks = (long)P * h;
+        const int a = (int)(((uintptr_t)d_dst >> 4) & 63);
+        const long nsuper = (nchunks + a + sr - 1) / sr;
+        long spb = 16;                                             // chunks per lane per LUT load
+        long gy = (nsuper + spb - 1) / spb;
+        if (gy > 65535) { gy = 65535; spb = (nsuper + gy - 1) / gy; spb = (spb + kRowsInFlight - 1) / kRowsInFlight * kRowsInFlight; gy = (nsuper + spb - 1) / spb; }
+        const long gx = (sr + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(rrc_u16_flat_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst,
+                           P, nchunks, sr, a, kb, nsuper, spb);
     } else if (w % 4 == 0 && (align & 7) == 0) {
         int gx = (w / 4 + kBlock - 1) / kBlock, gy;
         long rpb;

@@ -89,6 +89,32 @@ def test_rrc_unaligned_views(ctx, oracle_mod):
     assert np.array_equal(_u16(view).reshape(h, w), oracle_mod.rrc(img, kb))
 
 
+@pytest.mark.parametrize("off_px,w,h", [(8, 30000, 70), (24, 4096, 33), (504, 7504, 129), (0, 30000, 257), (64, 8, 3)])
+def test_rrc_line_aligned_kernel_any_16B_offset(ctx, oracle_mod, off_px, w, h):
+    """the flat kernel aligns its waves to the destination's 1 KiB frame: a raster that starts
+    at any 16-byte offset inside an allocation (a row-block shard, a halo buffer) must come out
+    the same, in place and out of place, and must not touch its neighbours"""
+    import torch
+    rng = _rng(off_px + w)
+    img = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+    kb = _lut(rng, w)
+    want = oracle_mod.rrc(img, kb)
+    guard = 4096
+    base = torch.full((guard + off_px + h * w + guard,), 0xABCD, dtype=torch.int32, device="cuda").to(torch.int16).view(torch.uint16)
+    view = base[guard + off_px:guard + off_px + h * w]
+    view.copy_(_cuda(img).reshape(-1))
+    dst = torch.full_like(base, 0)
+    dview = dst[guard + off_px:guard + off_px + h * w]
+    d_kb = ctx.upload_kb(kb)
+    ctx.rrc_u16(view, dview, w, h, d_kb); ctx.sync()
+    assert np.array_equal(_u16(dview).reshape(h, w), want)
+    assert int(dst.view(torch.int16).count_nonzero()) == int(np.count_nonzero(want))      # nothing outside
+    ctx.rrc_u16(view, view, w, h, d_kb); ctx.sync()
+    assert np.array_equal(_u16(view).reshape(h, w), want)
+    b = _u16(base)
+    assert (b[:guard + off_px] == 0xABCD).all() and (b[guard + off_px + h * w:] == 0xABCD).all()
+
+
 def test_rrc_host_buffer(ctx, oracle_mod):
     rng = _rng(6)
     w, h = 4096, 20000     # 160 MB -> 3 staged blocks

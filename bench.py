@@ -63,6 +63,7 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
         "mss_split_rrc_kernel": 4.0 * W * mb,
         "cross_power_kernel": 8.0 * MN * 3.5,                 # 2 or 3 spectra in, 1 out
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out
+        "resize_cubic_x4_kernel": 4.0 * win + 2.0 * win / 16.0,
         "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
     }
     return d

@@ -15,6 +15,7 @@
 #include "oip_geom.h"
 #include "oip_internal.h"
 
+#include <climits>
 #include <cmath>
 
 namespace {
@@ -48,6 +49,22 @@ __global__ void align_rows_kernel(AlignRow *rows, OipAlignGeom g, long out_row0,
     rows[r] = a;
 }
 
+// One lane = one output column, walking down a run of output lines.  For a fixed column the
+// first tap line iy advances by exactly one per output line except where the f32 rounding of
+// mapY flips (rare) or a section seam restarts the section-relative line, so each band keeps
+// its 4x4 source window in registers and normally loads only the newest source line (4 taps
+// per band and pixel instead of 16).
+__device__ __forceinline__ void align_load_row(const uint16_t *__restrict__ pl, long lr, bool yok, int Wb, int cix,
+                                               unsigned xmask, float out[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int cj = cix + j;
+        cj = cj < 0 ? 0 : (cj > Wb - 1 ? Wb - 1 : cj);
+        out[j] = (yok && (xmask & (1u << j))) ? (float)pl[lr * Wb + cj] : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
                                                            long src_rows, uint16_t *__restrict__ dst,
                                                            const AlignRow *__restrict__ rows, int Wb, long out_rows,
@@ -59,16 +76,28 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
     const int xx = x * 4;
     const double dxx = (double)xx;
     // per band: column-only part of the maps (preproc.h:447-448)
-    int ix[4], fx[4];
+    int ix[4];
+    float wx[4][4];
+    unsigned xmask[4];
     double coly[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         double mx = __dadd_rn(__dadd_rn(__dmul_rn(co.cx[b][1], dxx), co.cx[b][0]), dxx) * 0.25;
         int sx = oip_cvround((float)mx * 32.0f);
         ix[b] = oip_sat_short(sx >> 5) - 1;
-        fx[b] = sx & 31;
+        const int fx = sx & 31;
+        xmask[b] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wx[b][j] = tab1d[fx * 4 + j];
+            int cj = ix[b] + j;
+            if (cj >= 0 && cj < Wb) xmask[b] |= 1u << j;
+        }
         coly[b] = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(co.cy[b][2], dxx), dxx), __dmul_rn(co.cy[b][1], dxx)), co.cy[b][0]);
     }
+    float win[4][4][4];            // [band][tap row][tap col]
+    int cur_iy[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
+    int cur_base = INT_MIN;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
@@ -76,6 +105,11 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
         const AlignRow a = rows[r];
         unsigned short res[4] = {0, 0, 0, 0};
         if (a.valid) {
+            if (a.base != cur_base) {           // new section: every window is stale
+                cur_base = a.base;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) cur_iy[b] = INT_MIN;
+            }
             const double yy = (double)((long)a.yrel * 4);
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -84,33 +118,46 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
                 int iy = oip_sat_short(sy >> 5) - 1;
                 int fy = sy & 31;
                 const int cix = ix[b];
+                const uint16_t *pl = planes + (size_t)b * plane_stride;
+                if (iy == cur_iy[b] + 1 && cur_iy[b] != INT_MIN) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) win[b][t][j] = win[b][t + 1][j];
+                    }
+                    const int rr = iy + 3;
+                    const long lr = (long)a.base + rr;
+                    align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask[b], win[b][3]);
+                } else if (iy != cur_iy[b]) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int rr = iy + t;
+                        const long lr = (long)a.base + rr;
+                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask[b], win[b][t]);
+                    }
+                }
+                cur_iy[b] = iy;
                 float sum;
                 if (cix >= Wb || cix + 4 <= 0 || iy >= a.lines || iy + 4 <= 0) {
                     sum = 0.f;
                 } else {
-                    float wx[4], wy[4];
+                    float wy[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { wx[j] = tab1d[fx[b] * 4 + j]; wy[j] = tab1d[fy * 4 + j]; }
-                    unsigned xmask = 0, ymask = 0;
-                    float v[4][4];
-                    const uint16_t *pl = planes + (size_t)b * plane_stride;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        int rr = iy + t;
-                        long lr = (long)a.base + rr;
-                        bool yok = rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows;
-                        if (yok) ymask |= 1u << t;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            int cj = cix + j;
-                            bool xok = cj >= 0 && cj < Wb;
-                            if (t == 0 && xok) xmask |= 1u << j;
-                            v[t][j] = (yok && xok) ? (float)pl[lr * Wb + cj] : 0.f;
-                        }
-                    }
+                    for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
                     const bool inside = (unsigned)cix < (unsigned)(Wb - 3 > 0 ? Wb - 3 : 0) &&
                                         (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0);
-                    sum = inside ? oip_bicubic_interior(v, wx, wy) : oip_bicubic_border(v, wx, wy, xmask, ymask);
+                    if (inside) {
+                        sum = oip_bicubic_interior(win[b], wx[b], wy);
+                    } else {
+                        unsigned ymask = 0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int rr = iy + t;
+                            const long lr = (long)a.base + rr;
+                            if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
+                        }
+                        sum = oip_bicubic_border(win[b], wx[b], wy, xmask[b], ymask);
+                    }
                 }
                 res[b] = (unsigned short)oip_sat_u16(sum);
             }
@@ -253,7 +300,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
         long want = (long)ctx->cu_count * 16 / gx;
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
-        if (rpb < 8) rpb = 8;
+        if (rpb < 32) rpb = 32;
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
         hipLaunchKernelGGL(align_mss_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,

@@ -144,10 +144,21 @@ __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
     } else {
         t.vec0 = bid << p.vshift;
         t.nv = p.lanes - t.vec0 < V ? (int)(p.lanes - t.vec0) : V;
-        t.base = t.vec0 * p.F;
+        t.base = 0;                      // mode 1 addresses come from vec_offset()
         t.lane0 = t.o1 = t.o2 = 0;
     }
     return t;
+}
+
+// mode 1: element offset of point n of vector (vec0 + v): vectors are the F-point pieces of
+// the rows, rows are P elements apart
+__device__ __forceinline__ long vec_offset(const OipFftPass &p, const Tile &t, int n, int v)
+{
+    const int vec = (int)t.vec0 + v;                 // M * (N / F) < 2^31
+    if (p.N == p.F) return (long)vec * p.P + n;      // whole rows: no division
+    const int per_row = p.N / p.F;
+    const int y = vec / per_row;
+    return (long)y * p.P + (vec - y * per_row) * p.F + n;
 }
 
 // (row, column) of tile element (point n, vector v) in the M x N array
@@ -185,8 +196,8 @@ __device__ __forceinline__ bool peak_better(float v, long k, float bv, long bk) 
 
 // Reduce the tile to its maximum (first occurrence in the fftShift-ed scan order) for the
 // real and the imaginary part; one partial per workgroup and part.
-__device__ void store_peak(const float2 *__restrict__ buf, int Vp, const OipFftPass &p, const OipFftIo &io,
-                           const Tile &t, float *sval, long *skey)
+__device__ void store_peak(const float2 *buf, int Vp, const OipFftPass &p, const OipFftIo &io,
+                           const Tile &t, float *sval, long *skey, long tile, long ntiles, const int kFftBlock = 256)
 {
     const int V = 1 << p.vshift;
     const int total = p.F << p.vshift;
@@ -220,7 +231,7 @@ __device__ void store_peak(const float2 *__restrict__ buf, int Vp, const OipFftP
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            OipPeakPartial &o = io.partials[(size_t)part * gridDim.x + blockIdx.x];
+            OipPeakPartial &o = io.partials[(size_t)part * ntiles + tile];
             o.val = sval[0];
             o.key = skey[0];
         }
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         const int n = p.mode == 0 ? (e >> p.vshift) : e - v * F;
         float2 z = make_float2(0.f, 0.f);
         if (v < t.nv) {
-            const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+            const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : vec_offset(p, t, n, v);
             z = load_elem(data, p, io, t, n, v, off);
             if (p.inverse) {
                 z.y = -z.y;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         Ns *= r;
     }
 
-    if (io.store_kind == 1) { store_peak(bufA, Vp, p, io, t, sval, skey); return; }
+    if (io.store_kind == 1) { store_peak(bufA, Vp, p, io, t, sval, skey, blockIdx.x, gridDim.x); return; }
     if (io.store_kind == 2) {
         if (threadIdx.x == 0) {
             float2 z = bufA[wn0 * Vp + wv0];
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         float2 z = bufA[n * Vp + v];
         if (p.inverse) z.y = -z.y;
         else if (p.tw_mode) z = cmul(z, twT[(long)(p.tw_mode == 1 ? t.lane0 + v : t.o1) * n]);
-        const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
+        const long off = p.mode == 0 ? t.base + (long)n * p.nstride + v : vec_offset(p, t, n, v);
         data[off] = z;
     }
 }
@@ -366,9 +377,10 @@ template <int F, int First, int... Rest> struct TwTable {          // entries of
     }
 };
 
-template <int F, int VS, int Ns, int R>
+template <int F, int VS, int NT, int Ns, int R>
 __device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 *__restrict__ tw)
 {
+    constexpr int kFftBlock = NT;      // shadows the generic kernel's block size
     constexpr int V = 1 << VS;
     constexpr int Vp = VS ? V + 1 : 1;
     constexpr int NB = F / R;
@@ -411,32 +423,60 @@ __device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 
     __syncthreads();
 }
 
-template <int F, int VS, int Ns, int... Rs> struct Stages;
-template <int F, int VS, int Ns> struct Stages<F, VS, Ns> {
+template <int F, int VS, int NT, int Ns, int... Rs> struct Stages;
+template <int F, int VS, int NT, int Ns> struct Stages<F, VS, NT, Ns> {
     static __device__ __forceinline__ void run(float2 *, const float2 *) {}
 };
-template <int F, int VS, int Ns, int R, int... Rest> struct Stages<F, VS, Ns, R, Rest...> {
+template <int F, int VS, int NT, int Ns, int R, int... Rest> struct Stages<F, VS, NT, Ns, R, Rest...> {
     static __device__ __forceinline__ void run(float2 *buf, const float2 *tw)
     {
-        stage_ct<F, VS, Ns, R>(buf, tw);
-        Stages<F, VS, Ns * R, Rest...>::run(buf, tw);
+        stage_ct<F, VS, NT, Ns, R>(buf, tw);
+        Stages<F, VS, NT, Ns * R, Rest...>::run(buf, tw);
     }
 };
 
-template <int F, int VS, int MODE, int... Rs>
-__global__ __launch_bounds__(kFftBlock) void fft_pass_ct_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
-                                                                const float2 *__restrict__ twF,
-                                                                const float2 *__restrict__ twT)
+// raw (unconverted) element load for the prefetch: u16 sources stay as bit patterns so that no
+// conversion -- hence no wait on the load -- happens before the values are committed to LDS
+__device__ __forceinline__ float2 load_elem_raw(const float2 *__restrict__ data, const OipFftPass &p, const OipFftIo &io,
+                                                const Tile &t, int n, int v, long off)
 {
+    if (io.load_kind == 0) return data[off];
+    int y, x;
+    elem_coord(p, t, n, v, &y, &x);
+    float2 z = make_float2(0.f, 0.f);
+    if (y < io.rows && x < io.cols) {
+        const size_t i = (size_t)y * io.cols + x;
+        if (io.re) z.x = io.re[i];
+        else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+        if (io.im) z.y = io.im[i];
+        else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+    }
+    return z;
+}
+
+// PERSIST: workgroups walk tiles blockIdx.x, +gridDim.x, ... and issue the global loads of the
+// NEXT tile into registers right after the current tile has been committed to LDS, so they are
+// in flight while the butterflies run.  It costs ~50 VGPRs; measured on MI355X it pays for the
+// 128-point column pass (5.1 TB/s) and loses occupancy elsewhere, so it is a per-kernel choice.
+template <int F, int VS, int MODE, int NT, bool PERSIST, int... Rs>
+__global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
+                                                         const float2 *__restrict__ twF,
+                                                         const float2 *__restrict__ twT)
+{
+    constexpr int kFftBlock = NT;      // shadows the generic kernel's block size
     constexpr int V = 1 << VS;
     constexpr int Vp = VS ? V + 1 : 1;
     constexpr int TWN = TwTable<F, Rs...>::value();
+    constexpr int TOTAL = F << VS;
+    constexpr int NLD = (TOTAL + kFftBlock - 1) / kFftBlock;
     __shared__ float2 buf[F * Vp];
     __shared__ float2 tw[TWN];
     __shared__ float2 twj[MODE == 0 ? F : 1];       // inter-pass twiddles of this tile (column passes)
-    __shared__ float sval[kFftBlock];
-    __shared__ long skey[kFftBlock];
+    static_assert(sizeof(float2) * F * Vp >= kFftBlock * 12 + 16, "tile too small to host the reduction scratch");
 
+    const long ntiles = io.store_kind == 2 ? gridDim.x : p.ntiles;
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
     Tile t;
     int wn0 = 0, wv0 = 0;
     if (io.store_kind == 2) {
@@ -445,30 +485,35 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_ct_kernel(float2 *__restri
             return;
         }
     } else {
-        t = decode_tile(p, blockIdx.x);
+        t = decode_tile(p, tile);
     }
-    for (int i = threadIdx.x; i < TWN; i += kFftBlock) tw[i] = twF[i];
     const bool tile_tw = MODE == 0 && p.tw_mode == 2;
-    if (tile_tw)
-        for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = twT[(long)t.o1 * i];
-    if (tile_tw && p.inverse) __syncthreads();
+    const bool raw_re16 = io.load_kind == 1 && !io.re && io.re16;
+    const bool raw_im16 = io.load_kind == 1 && !io.im && io.im16;
 
-    constexpr int TOTAL = F << VS;
-    constexpr int NLD = (TOTAL + kFftBlock - 1) / kFftBlock;
-    {
-        // all global loads of the tile are issued before the first one is consumed
-        float2 zz[NLD];
+    float2 zz[NLD];
+    auto issue_loads = [&](const Tile &tt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = threadIdx.x + i * kFftBlock;
             const int v = MODE == 0 ? (e & (V - 1)) : e / F;
             const int n = MODE == 0 ? (e >> VS) : e - v * F;
             zz[i] = make_float2(0.f, 0.f);
-            if ((TOTAL % kFftBlock == 0 || e < TOTAL) && v < t.nv) {
-                const long off = MODE == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
-                zz[i] = load_elem(data, p, io, t, n, v, off);
+            if ((TOTAL % kFftBlock == 0 || e < TOTAL) && v < tt.nv) {
+                const long off = MODE == 0 ? tt.base + (long)n * p.nstride + v : vec_offset(p, tt, n, v);
+                zz[i] = load_elem_raw(data, p, io, tt, n, v, off);
             }
         }
+    };
+    issue_loads(t);
+    for (int i = threadIdx.x; i < TWN; i += kFftBlock) tw[i] = twF[i];
+
+    for (;;) {
+        if (tile_tw) {
+            for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = twT[(long)t.o1 * i];
+            if (p.inverse) __syncthreads();
+        }
+        // commit the prefetched tile to LDS
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = threadIdx.x + i * kFftBlock;
@@ -476,6 +521,8 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_ct_kernel(float2 *__restri
             const int n = MODE == 0 ? (e >> VS) : e - v * F;
             if (TOTAL % kFftBlock == 0 || e < TOTAL) {
                 float2 z = zz[i];
+                if (raw_re16) z.x = (float)__float_as_uint(z.x);
+                if (raw_im16) z.y = (float)__float_as_uint(z.y);
                 if (p.inverse && v < t.nv) {
                     z.y = -z.y;
                     if (tile_tw) z = cmul(z, twj[n]);
@@ -484,48 +531,68 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_ct_kernel(float2 *__restri
                 buf[n * Vp + v] = z;
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    Stages<F, VS, 1, Rs...>::run(buf, tw);
-
-    if (io.store_kind == 1) { store_peak(buf, Vp, p, io, t, sval, skey); return; }
-    if (io.store_kind == 2) {
-        if (threadIdx.x == 0) {
-            float2 z = buf[wn0 * Vp + wv0];
-            io.window[blockIdx.x] = io.part ? -z.y : z.x;
+        const long next = tile + gridDim.x;
+        const bool has_next = PERSIST && io.store_kind != 2 && next < ntiles;
+        Tile tn = t;
+        if (has_next) {
+            tn = decode_tile(p, next);
+            issue_loads(tn);               // in flight during the stages below
         }
-        return;
-    }
-    for (int e = threadIdx.x; e < TOTAL; e += kFftBlock) {
-        const int v = MODE == 0 ? (e & (V - 1)) : e / F;
-        const int n = MODE == 0 ? (e >> VS) : e - v * F;
-        if (v >= t.nv) continue;
-        float2 z = buf[n * Vp + v];
-        if (p.inverse) z.y = -z.y;
-        else if (tile_tw) z = cmul(z, twj[n]);
-        else if (p.tw_mode == 1) z = cmul(z, twT[(long)(t.lane0 + v) * n]);
-        const long off = MODE == 0 ? t.base + (long)n * p.nstride + v : t.base + e;
-        data[off] = z;
+
+        Stages<F, VS, NT, 1, Rs...>::run(buf, tw);
+
+        if (io.store_kind == 1) {
+            // the scan of the tile ends (barrier inside store_peak) before the scratch is written
+            store_peak(buf, Vp, p, io, t, reinterpret_cast<float *>(buf + kFftBlock), reinterpret_cast<long *>(buf), tile,
+                       ntiles, NT);
+        } else if (io.store_kind == 2) {
+            if (threadIdx.x == 0) {
+                float2 z = buf[wn0 * Vp + wv0];
+                io.window[blockIdx.x] = io.part ? -z.y : z.x;
+            }
+        } else {
+            for (int e = threadIdx.x; e < TOTAL; e += kFftBlock) {
+                const int v = MODE == 0 ? (e & (V - 1)) : e / F;
+                const int n = MODE == 0 ? (e >> VS) : e - v * F;
+                if (v >= t.nv) continue;
+                float2 z = buf[n * Vp + v];
+                if (p.inverse) z.y = -z.y;
+                else if (tile_tw) z = cmul(z, twj[n]);
+                else if (p.tw_mode == 1) z = cmul(z, twT[(long)(t.lane0 + v) * n]);
+                const long off = MODE == 0 ? t.base + (long)n * p.nstride + v : vec_offset(p, t, n, v);
+                data[off] = z;
+            }
+        }
+        if (!has_next) break;
+        __syncthreads();                   // everyone is done with buf / twj of this tile
+        t = tn;
+        tile = next;
     }
 }
 
 // table of specialisations: (F, log2 V, mode) -> kernel
 struct FastKernel {
-    int F, vshift, mode;
+    int F, vshift, mode, threads;
+    bool persist;
     void (*fn)(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);
 };
 const FastKernel kFast[] = {
-    // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors)
-    {125, 5, 0, fft_pass_ct_kernel<125, 5, 0, 5, 5, 5>},
-    {128, 5, 0, fft_pass_ct_kernel<128, 5, 0, 8, 4, 4>},
-    {100, 5, 0, fft_pass_ct_kernel<100, 5, 0, 4, 5, 5>},
-    {160, 4, 0, fft_pass_ct_kernel<160, 4, 0, 4, 8, 5>},
-    {64, 5, 0, fft_pass_ct_kernel<64, 5, 0, 4, 4, 4>},
+    // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors): 16 lanes = 128-byte
+    // segments, 17 KiB of LDS per workgroup -> 8 workgroups per CU (measured faster than 32 lanes)
+    {125, 4, 0, 256, false, fft_pass_ct_kernel<125, 4, 0, 256, false, 5, 5, 5>},
+    {128, 4, 0, 256, true, fft_pass_ct_kernel<128, 4, 0, 256, true, 8, 4, 4>},
+    {125, 5, 0, 256, false, fft_pass_ct_kernel<125, 5, 0, 256, false, 5, 5, 5>},
+    {128, 5, 0, 256, false, fft_pass_ct_kernel<128, 5, 0, 256, false, 8, 4, 4>},
+    {100, 4, 0, 256, false, fft_pass_ct_kernel<100, 4, 0, 256, false, 4, 5, 5>},
+    {160, 4, 0, 256, false, fft_pass_ct_kernel<160, 4, 0, 256, false, 4, 8, 5>},
+    {64, 5, 0, 256, false, fft_pass_ct_kernel<64, 5, 0, 256, false, 4, 4, 4>},
     // row passes: 30000/10, 12288/10 -> 1250, the 200-column stitch overlap
-    {3000, 0, 1, fft_pass_ct_kernel<3000, 0, 1, 3, 8, 5, 5, 5>},
-    {1250, 1, 1, fft_pass_ct_kernel<1250, 1, 1, 2, 5, 5, 5, 5>},
-    {200, 4, 1, fft_pass_ct_kernel<200, 4, 1, 8, 5, 5>},
+    {3000, 0, 1, 512, false, fft_pass_ct_kernel<3000, 0, 1, 512, false, 3, 8, 5, 5, 5>},
+    {3000, 0, 1, 256, false, fft_pass_ct_kernel<3000, 0, 1, 256, false, 3, 8, 5, 5, 5>},
+    {1250, 1, 1, 256, false, fft_pass_ct_kernel<1250, 1, 1, 256, false, 2, 5, 5, 5, 5>},
+    {200, 4, 1, 256, false, fft_pass_ct_kernel<200, 4, 1, 256, false, 8, 5, 5>},
 };
 constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
@@ -593,8 +660,15 @@ int pick_vshift(int F, int want)
 void choose_kernel(OipFftPass *p, int want_v)
 {
     p->fast = -1;
+    // experiment knobs (first match in the table is the default): lanes per column tile,
+    // threads per row-pass workgroup
+    static const char *env = getenv("OIP_FFT_LANES");
+    static const char *envt = getenv("OIP_FFT_ROW_THREADS");
+    const int want_vs = env ? (atoi(env) == 16 ? 4 : 5) : -1;
+    const int want_nt = envt ? atoi(envt) : -1;
     for (int i = 0; i < kNumFast; ++i)
-        if (kFast[i].F == p->F && kFast[i].mode == p->mode) {
+        if (kFast[i].F == p->F && kFast[i].mode == p->mode && (p->mode == 1 || want_vs < 0 || kFast[i].vshift == want_vs) &&
+            (p->mode == 0 || want_nt < 0 || kFast[i].threads == want_nt)) {
             p->fast = i;
             p->vshift = kFast[i].vshift;
             p->Vp = p->vshift ? (1 << p->vshift) + 1 : 1;
@@ -655,6 +729,9 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
     if (M < 2) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: fewer than 2 rows");
     OipFft2dPlan pl;
     pl.M = M; pl.N = N;
+    // row pitch padded to whole 128-byte lines (16 complex): every pass stores full lines
+    const int P = (N + 15) / 16 * 16;
+    pl.P = P;
     if (!split_axis(N, 256, 4096, &pl.xf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor row length %d", N);
     if (M == 16000) pl.yf = {125, 128};
     else if (!split_axis(M, 256, 256, &pl.yf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor column length %d", M);
@@ -665,17 +742,17 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
             OipFftPass p;
             memset(&p, 0, sizeof p);
             p.F = pl.yf[i];
-            p.M = M; p.N = N;
+            p.M = M; p.N = N; p.P = P;
             p.axis = 1;
             fill_radix(&p);
             const int S = T / p.F;
             p.mode = 0;
             choose_kernel(&p, 32);
-            p.nstride = (long)S * N;
+            p.nstride = (long)S * P;
             p.lanes = N;
             p.lane_tiles = (N + (1 << p.vshift) - 1) >> p.vshift;
-            p.O1 = S;     p.o1_stride = N;              // j: row offset inside the block
-            p.O2 = M / T; p.o2_stride = (long)T * N;    // blocks
+            p.O1 = S;     p.o1_stride = P;              // j: row offset inside the block
+            p.O2 = M / T; p.o2_stride = (long)T * P;    // blocks
             p.tw_mode = S > 1 ? 2 : 0; p.T = T; p.S = S;
             pl.passes.push_back(p);
             T = S;
@@ -690,7 +767,7 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
             OipFftPass p;
             memset(&p, 0, sizeof p);
             p.F = pl.xf[i];
-            p.M = M; p.N = N;
+            p.M = M; p.N = N; p.P = P;
             p.axis = 0;
             fill_radix(&p);
             const int S = T / p.F;
@@ -707,7 +784,7 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
                 p.lanes = S;
                 p.lane_tiles = (S + (1 << p.vshift) - 1) >> p.vshift;
                 p.O1 = N / T; p.o1_stride = T;          // blocks of the current sub-problem
-                p.O2 = M;     p.o2_stride = N;          // rows
+                p.O2 = M;     p.o2_stride = P;          // rows
                 p.tw_mode = 1;
             }
             pl.passes.push_back(p);
@@ -748,7 +825,14 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d" : "fft_pass_kernel_F%d"), p.F);
     OipProfScope prof(ctx, pname);
     if (p.fast >= 0) {
-        hipLaunchKernelGGL(kFast[p.fast].fn, dim3((unsigned)blocks), dim3(kFftBlock), 0, ctx->stream, data, p, io, twF, twT);
+        p.ntiles = blocks;
+        long grid = blocks;
+        if (blocks_override <= 0 && kFast[p.fast].persist) {
+            static const char *envg = getenv("OIP_FFT_WGS_PER_CU");          // experiment knob
+            const long cap = (long)ctx->cu_count * (envg ? atoi(envg) : 8);
+            if (grid > cap) grid = cap;
+        }
+        hipLaunchKernelGGL(kFast[p.fast].fn, dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
         hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);

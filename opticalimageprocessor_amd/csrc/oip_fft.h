@@ -51,12 +51,15 @@ struct OipFftPass {
     int S;              // stride of the sub-transform in axis elements (T / F)
     int N;              // row length of the array (to turn offsets into coordinates)
     int M;
+    int P;              // row pitch in elements (N rounded up to whole 128-byte lines)
     int inverse;
+    long ntiles;        // tiles of the pass (persistent specialised kernels walk them)
     int fast;           // index of a compile-time specialised kernel, -1: generic
 };
 
 struct OipFft2dPlan {
     int M, N;
+    int P;                            // row pitch of the complex array, elements
     std::vector<int> xf, yf;          // pass factors per axis, in forward order
     std::vector<OipFftPass> passes;   // forward order: y passes then x passes
     int n_y;

@@ -27,6 +27,7 @@ struct oip_fft_state;   // fft.hip
 // cv::resize coefficient tables (resize.cpp builds the same xofs/alpha/yofs/beta on the host)
 struct OipResizeTab {
     int sw, sh, dw, dh;
+    bool x4;            // exact x4 up-sampling: the 4x4-per-lane kernel applies
     int *d_xofs;
     float *d_alpha;     // dw x 4
     int *d_yofs;

@@ -84,6 +84,71 @@ __global__ __launch_bounds__(kBlock) void resize_cubic_kernel(const SrcT *__rest
     dst[(size_t)dy * dw + dx] = o;
 }
 
+// Exact x4 up-sampling (the reference geometry: MSS GSD = 4 x PAN GSD).  One lane owns one
+// source pixel (q, p) and produces its 4x4 block of outputs from the 5x5 source neighbourhood:
+// the four outputs of a row share their horizontal taps, the four rows share the horizontal
+// sums.  Taps, clamping and the order of every f32 product/sum are those of the generic kernel
+// (the host verified that each output's first tap lies in the lane's 5 columns / rows);
+// 25 loads and 4 16-byte stores per 16 outputs instead of 16 loads and one 4-byte store each.
+template <typename SrcT>
+__global__ __launch_bounds__(kBlock) void resize_cubic_x4_kernel(const SrcT *__restrict__ src, long spitch, int sw, int sh,
+                                                                 float *__restrict__ dst, int dw,
+                                                                 const int *__restrict__ xofs, const float4 *__restrict__ alpha,
+                                                                 const int *__restrict__ yofs, const float4 *__restrict__ beta)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    const int p = blockIdx.y;
+    if (q >= sw) return;
+    float S[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        int yr = p - 2 + r;
+        yr = yr < 0 ? 0 : (yr > sh - 1 ? sh - 1 : yr);
+        const SrcT *row = src + (size_t)yr * spitch;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            int xc = q - 2 + c;
+            xc = xc < 0 ? 0 : (xc > sw - 1 ? sw - 1 : xc);
+            S[r][c] = (float)row[xc];
+        }
+    }
+    float H[5][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int dx = 4 * q + i;
+        const float4 a = alpha[dx];
+        const bool hi = (xofs[dx] - 1) - (q - 2) != 0;         // first tap is column q-1 instead of q-2
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const float s0 = hi ? S[r][1] : S[r][0], s1 = hi ? S[r][2] : S[r][1];
+            const float s2 = hi ? S[r][3] : S[r][2], s3 = hi ? S[r][4] : S[r][3];
+            float v = __fmul_rn(s0, a.x);
+            v = __fadd_rn(v, __fmul_rn(s1, a.y));
+            v = __fadd_rn(v, __fmul_rn(s2, a.z));
+            v = __fadd_rn(v, __fmul_rn(s3, a.w));
+            H[r][i] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int dy = 4 * p + j;
+        const float4 b = beta[dy];
+        const bool hi = (yofs[dy] - 1) - (p - 2) != 0;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float h0 = hi ? H[1][i] : H[0][i], h1 = hi ? H[2][i] : H[1][i];
+            const float h2 = hi ? H[3][i] : H[2][i], h3 = hi ? H[4][i] : H[3][i];
+            float v = __fmul_rn(h0, b.x);
+            v = __fadd_rn(v, __fmul_rn(h1, b.y));
+            v = __fadd_rn(v, __fmul_rn(h2, b.z));
+            v = __fadd_rn(v, __fmul_rn(h3, b.w));
+            o[i] = v;
+        }
+        *reinterpret_cast<float4 *>(dst + (size_t)dy * dw + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ---- cross-power spectrum -----------------------------------------------------------------------
 struct SpecRef {
     const float2 *z;    // packed spectrum (scrambled order)
@@ -130,14 +195,14 @@ __device__ __forceinline__ float2 cross_power_bin(float2 A, float2 B, bool real_
 // The x axis of the reference shapes is a single pass (natural order), so the mirrored
 // column N-kx is a reversed, still coalesced, access.
 __global__ __launch_bounds__(kBlock) void cross_power_kernel(float2 *__restrict__ out, XpowerJob job, int M, int N,
-                                                             OipAxisDigits yd, OipAxisDigits xd)
+                                                             int P, OipAxisDigits yd, OipAxisDigits xd)
 {
     const int px = blockIdx.x * kBlock + threadIdx.x;
     const int ky = blockIdx.y;                        // 0 .. M/2
     if (px >= N) return;
     const int kx = oip_pos_to_freq(xd, px);
     const int nkx = kx ? N - kx : 0, nky = ky ? M - ky : 0;
-    const long r1 = (long)oip_freq_to_pos(yd, ky) * N, r2 = (long)oip_freq_to_pos(yd, nky) * N;
+    const long r1 = (long)oip_freq_to_pos(yd, ky) * P, r2 = (long)oip_freq_to_pos(yd, nky) * P;
     const int px2 = oip_freq_to_pos(xd, nkx);
     const bool edge_col = (kx == 0) || (2 * kx == N);
     const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
@@ -260,7 +325,7 @@ struct PcWork {
 int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_elems, int nz, int ny, int nfb, PcWork *w)
 {
     const int M = pl->M, N = pl->N;
-    const size_t zbytes = align_up(sizeof(float2) * (size_t)M * N, 256);
+    const size_t zbytes = align_up(sizeof(float2) * (size_t)M * pl->P, 256);
     const size_t fbytes = align_up(sizeof(float) * (size_t)rows * cols, 256);
     const size_t sbytes = align_up(sizeof(float) * (size_t)(small_elems > 0 ? small_elems : 1), 256);
     w->npart = (int)oip_fft2d_last_pass_blocks(pl);
@@ -319,6 +384,10 @@ int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeT
     }
     OipResizeTab t;
     t.sw = sw; t.sh = sh; t.dw = dw; t.dh = dh;
+    // the x4 kernel needs every output's first tap inside its source pixel's 5-wide window
+    t.x4 = dw == 4 * sw && dh == 4 * sh;
+    for (int dx = 0; dx < dw && t.x4; ++dx) { int o = (xofs[dx] - 1) - (dx / 4 - 2); t.x4 = o == 0 || o == 1; }
+    for (int dy = 0; dy < dh && t.x4; ++dy) { int o = (yofs[dy] - 1) - (dy / 4 - 2); t.x4 = o == 0 || o == 1; }
     OIP_HIP(ctx, hipMalloc((void **)&t.d_xofs, sizeof(int) * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_alpha, sizeof(float) * 4 * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_yofs, sizeof(int) * dh));
@@ -338,6 +407,14 @@ int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, fl
     const OipResizeTab *t;
     int rc = resize_tables(ctx, sw, sh, dw, dh, &t);
     if (rc) return rc;
+    if (t->x4 && ((uintptr_t)dst & 15) == 0) {
+        OipProfScope prof(ctx, "resize_cubic_x4_kernel");
+        hipLaunchKernelGGL(resize_cubic_x4_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, sh), dim3(kBlock), 0, ctx->stream,
+                           src, spitch, sw, sh, dst, dw, t->d_xofs, reinterpret_cast<const float4 *>(t->d_alpha), t->d_yofs,
+                           reinterpret_cast<const float4 *>(t->d_beta));
+        OIP_HIP(ctx, hipGetLastError());
+        return OIP_OK;
+    }
     OipProfScope prof(ctx, "resize_cubic_kernel");
     hipLaunchKernelGGL(resize_cubic_kernel<SrcT>, dim3((dw + kBlock - 1) / kBlock, dh), dim3(kBlock), 0, ctx->stream, src,
                        spitch, sw, sh, dst, dw, dh, t->d_xofs, reinterpret_cast<const float4 *>(t->d_alpha), t->d_yofs,
@@ -372,7 +449,7 @@ int launch_xpower(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2
 {
     OipProfScope prof(ctx, "cross_power_kernel");
     hipLaunchKernelGGL(cross_power_kernel, dim3((pl->N + kBlock - 1) / kBlock, pl->M / 2 + 1), dim3(kBlock), 0,
-                       ctx->stream, out, job, pl->M, pl->N, digits_of(pl->yf, pl->M), digits_of(pl->xf, pl->N));
+                       ctx->stream, out, job, pl->M, pl->N, pl->P, digits_of(pl->yf, pl->M), digits_of(pl->xf, pl->N));
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }

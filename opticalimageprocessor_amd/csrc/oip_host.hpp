@@ -1,0 +1,591 @@
+// oip_host.hpp -- C++ host layer above the C ABI (include/oip_c.h), mirroring the reference's
+// class interface for the hot path: ImageOperations (IMO), Stitcher, PreProcessor -- same
+// method names, argument meaning and error behaviour (exception types -> exit codes of
+// main.cpp:320-343), with the raster loops running on the MI355X.  Used by the `oip` CLI.
+//
+// Differences kept deliberately small:
+//   * the line width is a constructor/run-time argument (reference: PIXELS_PER_LINE 12288);
+//   * TIFF output is not implemented yet (SURVEY 8f "next"): the aligned MSS image is written
+//     as headerless 16UC4 RAW (<stem>.ALIGNED.RAW) and `stitch` writes RAW only;
+//   * timing lines are logged like the reference's (seconds, MBps) through a plain logger.
+#pragma once
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <chrono>
+#include <filesystem>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "oip_c.h"
+
+namespace OIPGPU {
+
+struct errno_error : public std::runtime_error {      // libimsux errno_error stand-in (same role)
+    explicit errno_error(const std::string &s) : std::runtime_error(s + ": " + std::strerror(errno)) {}
+};
+struct usage_error : public std::invalid_argument {   // main.cpp:20-23
+    explicit usage_error(const std::string &s) : std::invalid_argument(s) {}
+};
+
+// ---- logging (libimsux logger stand-in: timestamped lines to stdout and $LOGFILE / oip.log) ----
+inline FILE *&log_file() { static FILE *f = nullptr; return f; }
+inline void log_line(bool stamped, const char *fmt, ...)
+{
+    char msg[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    char ts[64] = "";
+    if (stamped) {
+        time_t t = time(nullptr);
+        struct tm tmv;
+        localtime_r(&t, &tmv);
+        strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S ", &tmv);
+    }
+    printf("%s%s\n", ts, msg);
+    if (log_file()) { fprintf(log_file(), "%s%s\n", ts, msg); fflush(log_file()); }
+}
+#define OLOG(...) ::OIPGPU::log_line(true, __VA_ARGS__)
+#define RLOG(...) ::OIPGPU::log_line(false, __VA_ARGS__)
+
+struct stop_watch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double tick()
+    {
+        auto t1 = std::chrono::steady_clock::now();
+        double s = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return s > 0 ? s : 1e-9;
+    }
+};
+
+inline std::string to_lower(std::string s)
+{
+    for (auto &c : s) c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+// ---- device context + error mapping ----------------------------------------------------------
+class Device {
+public:
+    static Device &get()
+    {
+        static Device d;
+        return d;
+    }
+    oip_ctx *ctx()
+    {
+        if (!mCtx && oip_create(0, &mCtx) != OIP_OK)
+            throw std::runtime_error("no usable MI355X (gfx950) device: this build has no CPU fallback");
+        return mCtx;
+    }
+    void check(int rc)
+    {
+        if (rc == OIP_OK) return;
+        std::string m = oip_last_error(mCtx);
+        switch (rc) {
+            case OIP_E_INVALID: throw std::invalid_argument(m);
+            case OIP_E_IO: throw std::runtime_error(m);
+            default: throw std::runtime_error(m);
+        }
+    }
+    ~Device() { if (mCtx) oip_destroy(mCtx); }
+private:
+    oip_ctx *mCtx = nullptr;
+};
+
+template <typename T> struct DevBuf {              // RAII device buffer
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    void alloc(size_t count)
+    {
+        release();
+        void *v = nullptr;
+        Device::get().check(oip_malloc(Device::get().ctx(), &v, count * sizeof(T)));
+        p = (T *)v;
+        n = count;
+    }
+    void release() { if (p) oip_free(Device::get().ctx(), p); p = nullptr; n = 0; }
+    void upload(const T *h, size_t count) { Device::get().check(oip_memcpy_h2d(Device::get().ctx(), p, h, count * sizeof(T))); }
+    void download(T *h, size_t count) const
+    {
+        Device::get().check(oip_memcpy_d2h(Device::get().ctx(), h, p, count * sizeof(T)));
+        Device::get().check(oip_sync(Device::get().ctx()));
+    }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+constexpr int BYTES_PER_PIXEL = 2;
+constexpr int MSS_BANDS = OIP_MSS_BANDS;
+
+// ---- ImageOperations (imageop.h:33-568, hot-path subset) -----------------------------------------
+struct RRCParam { double k; double b; };     // imageop.h:26-29
+
+class ImageOperations {
+public:
+    static size_t FileSize(const std::string &filePath)            // imageop.h:43-47
+    {
+        struct stat st;
+        memset(&st, 0, sizeof st);
+        if (stat(filePath.c_str(), &st)) throw errno_error("stat() call for file failed");
+        return (size_t)st.st_size;
+    }
+
+    // imageop.h:52-82: size = bytes read; offset; total = 0 for all available
+    static char *ReadFileContent(const std::string &filePath, size_t &size, size_t offset = 0, size_t total = 0,
+                                 char *buff = nullptr)
+    {
+        FILE *f = fopen(filePath.c_str(), "rb");
+        if (!f) throw std::invalid_argument("cannot open file [" + filePath + "]: " + std::to_string(errno));
+        size_t want = total;
+        if (total == 0) {
+            if (fseek(f, 0, SEEK_END)) { fclose(f); throw std::invalid_argument("ReadFileContent(): seek2end failed"); }
+            want = (size_t)ftello(f) - offset;
+        }
+        if (fseeko(f, (off_t)offset, SEEK_SET)) { fclose(f); throw std::invalid_argument("ReadFileContent(): rewind failed"); }
+        if (!buff) buff = new char[want ? want : 1];
+        const size_t unit = 8u * 1024 * 1024;
+        size_t rb = 0;
+        for (char *p = buff;;) {
+            size_t rn = fread(p, 1, std::min(unit, want - rb), f);
+            p += rn;
+            rb += rn;
+            if (rn == 0 || rb == want) { size = rb; break; }
+        }
+        fclose(f);
+        return buff;
+    }
+
+    static size_t WriteBufferToFile(const char *buff, size_t size, const std::string &saveFilePath)   // imageop.h:84-97
+    {
+        FILE *f = fopen(saveFilePath.c_str(), "wb");
+        if (!f) throw std::runtime_error("open file [" + saveFilePath + "] failed: " + std::to_string(errno));
+        const size_t unit = std::min((size_t)8 * 1024 * 1024, size);
+        size_t written = 0;
+        for (const char *p = buff; written < size;) {
+            size_t wb = fwrite(p, 1, std::min(unit, size - written), f);
+            if (wb == 0) { fclose(f); throw std::runtime_error("write file failed: " + std::to_string(errno)); }
+            written += wb;
+            p += wb;
+        }
+        fclose(f);
+        return written;
+    }
+
+    // imageop.h:99-108: cwd / stem(template) + stemExtension + (replaceExtension | ext(template))
+    static std::string BuildOutputFilePath(const std::string &templatePath, const std::string &stemExtension,
+                                           const char *replaceExtension = nullptr)
+    {
+        auto cd = std::filesystem::current_path();
+        std::filesystem::path tmpl = templatePath;
+        auto out = cd / tmpl.stem();
+        out += stemExtension;
+        out += replaceExtension ? std::string(replaceExtension) : tmpl.extension().string();
+        return out.string();
+    }
+
+    static void *LoadRawImage(const std::string &filePath, size_t offset = 0, size_t bytes = 0, size_t expectedSize = 0)
+    {                                                                // imageop.h:110-127
+        OLOG("Reading raw image from file `%s' ...", filePath.c_str());
+        size_t size = 0;
+        stop_watch sw;
+        void *content = ReadFileContent(filePath, size, offset, bytes);
+        if (expectedSize > 0 && size != expectedSize) {
+            delete[] (char *)content;
+            throw std::runtime_error("file size(" + std::to_string(expectedSize) + ") doesn't match with read byte count(" +
+                                     std::to_string(size) + ")");
+        }
+        double es = sw.tick();
+        OLOG("%zu bytes read in %.3f seconds (%.1f MBps).", size, es, size / es / 1024.0 / 1024.0);
+        return content;
+    }
+
+    // imageop.h:129-138 -- on the GPU, through pinned double-buffered line blocks
+    static void InplaceRRC(uint16_t *buff, int w, int h, const RRCParam *rrcParam)
+    {
+        Device::get().check(oip_rrc_u16_host(Device::get().ctx(), buff, w, h, reinterpret_cast<const double *>(rrcParam)));
+    }
+
+    static RRCParam *LoadRRCParamFile(const char *paramFilePath, int expectedLines)      // imageop.h:140-192
+    {
+        OLOG("Loading RRC paramter from file `%s' ...", paramFilePath);
+        std::unique_ptr<RRCParam[]> p(new RRCParam[expectedLines]);
+        char err[1024];
+        int rc = oip_load_rrc_param_file(paramFilePath, expectedLines, reinterpret_cast<double *>(p.get()), err, sizeof err);
+        if (rc == OIP_E_IO) throw errno_error(err);
+        if (rc != OIP_OK) throw std::runtime_error(err);
+        OLOG("LoadRRCParamFile(): loaded.");
+        return p.release();
+    }
+
+    // imageop.h:194-228
+    static uint16_t *DoRRC4RAW(const std::string &raw, int pixelPerLine, const std::string &rrc,
+                               const std::string saveRaw = "", bool keepBuffer = false)
+    {
+        size_t size = FileSize(raw);
+        std::unique_ptr<uint16_t[]> image((uint16_t *)LoadRawImage(raw, 0, 0, size));
+        int lines = (int)(size / ((size_t)pixelPerLine * BYTES_PER_PIXEL));
+        std::unique_ptr<RRCParam[]> rrcParam(LoadRRCParamFile(rrc.c_str(), pixelPerLine));
+        OLOG("Do inplace RRC ...");
+        stop_watch sw;
+        InplaceRRC(image.get(), pixelPerLine, lines, rrcParam.get());
+        double es = sw.tick();
+        OLOG("Done for %zu bytes in %.3f seconds (%.1f MBps).", size, es, size / es / (1024.0 * 1024.0));
+        if (!saveRaw.empty()) {
+            OLOG("Write RRC result as file \"%s\" ...", saveRaw.c_str());
+            sw.tick();
+            WriteBufferToFile((const char *)image.get(), size, saveRaw);
+            es = sw.tick();
+            OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", size, es, size / es / (1024.0 * 1024.0));
+        }
+        return keepBuffer ? image.release() : nullptr;
+    }
+
+    // imageop.h:277-363, RAW output only (the GTiff writer is "next")
+    static std::string StitchBigRaw(const std::string &leftImagePath, const std::string &rightImagePath,
+                                    const std::string &stitchedFilePath, int pixelPerLine, int foldColPixels)
+    {
+        size_t szl = FileSize(leftImagePath), szr = FileSize(rightImagePath);
+        if (szl != szr)
+            throw std::invalid_argument("RAW image sizes not match: left = " + std::to_string(szl) + " bytes, right = " +
+                                        std::to_string(szr) + " bytes");
+        const size_t bytesPerLine = (size_t)pixelPerLine * BYTES_PER_PIXEL;
+        const long imageLines = (long)(szl / bytesPerLine);
+        const int outputFullLinePixels = (pixelPerLine - foldColPixels) * 2;
+        std::string outputFilePath = stitchedFilePath;
+        if (stitchedFilePath.empty()) {
+            outputFilePath = (std::filesystem::current_path() /
+                              ("stitched_" + std::to_string(outputFullLinePixels) + "n" + std::to_string(BYTES_PER_PIXEL * 8) + "b.RAW")).string();
+        } else if (to_lower(std::filesystem::path(stitchedFilePath).extension().string()) == ".tiff") {
+            throw std::invalid_argument("Stitch(): TIFF output is not available in this build, use a .RAW output path");
+        }
+        std::unique_ptr<char[]> l((char *)LoadRawImage(leftImagePath, 0, 0, szl)), r((char *)LoadRawImage(rightImagePath, 0, 0, szr));
+        OLOG("Begin stitching two images ...");
+        stop_watch sw;
+        const size_t npx = (size_t)pixelPerLine * imageLines, nout = (size_t)outputFullLinePixels * imageLines;
+        DevBuf<uint16_t> dl(npx), dr(npx), dout(nout);
+        dl.upload((uint16_t *)l.get(), npx);
+        dr.upload((uint16_t *)r.get(), npx);
+        Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, pixelPerLine, imageLines, foldColPixels));
+        std::unique_ptr<uint16_t[]> out(new uint16_t[nout]);
+        dout.download(out.get(), nout);
+        WriteBufferToFile((const char *)out.get(), nout * 2, outputFilePath);
+        double es = sw.tick();
+        OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", nout * 2, es, nout * 2 / es / (1024.0 * 1024.0));
+        return outputFilePath;
+    }
+};
+typedef ImageOperations IMO;
+
+// ---- Stitcher (stitcher.h:18-223) ------------------------------------------------------------------
+class Stitcher {
+public:
+    // stitcher.h:21-46; foldCols is the already-halved value (main.cpp:189)
+    static std::string Stitch(const std::string &leftImagePath, const std::string &rightImagePath,
+                              const std::string &outputPath = "", int foldCols = 0, int pixelsPerLine = OIP_PIXELS_PER_LINE)
+    {
+        std::string leftExt = to_lower(std::filesystem::path(leftImagePath).extension().string());
+        std::string rightExt = to_lower(std::filesystem::path(rightImagePath).extension().string());
+        if (leftExt != rightExt) throw std::invalid_argument("Stitch(): two images should be same type");
+        if (leftExt != ".tiff" && leftExt != ".raw") throw std::invalid_argument("Stitch(): only RAW and TIFF image supported");
+        if (leftExt == ".raw") return IMO::StitchBigRaw(leftImagePath, rightImagePath, outputPath, pixelsPerLine, foldCols);
+        throw std::invalid_argument("Stitch(): TIFF stitching is not available in this build (SURVEY 8f)");
+    }
+
+    Stitcher(const std::string &pan1, const std::string &pan2, const std::string &rrc1, const std::string &rrc2,
+             int sections = OIP_STT_DEF_SECTIONS, int linePerSection = OIP_STT_DEF_SECLINES,
+             int overlapCols = OIP_STT_DEF_OVERLAPPX, int pixelsPerLine = OIP_PIXELS_PER_LINE)
+        : mFilePAN1(pan1), mFilePAN2(pan2), mParamFileRRC1(rrc1), mParamFileRRC2(rrc2), mSections(sections),
+          mLinePerSection(linePerSection), mOverlapCols(overlapCols), mW(pixelsPerLine)
+    {                                                                  // stitcher.h:49-81
+        size_t s1 = IMO::FileSize(pan1);
+        if ((size_t)sections * linePerSection * BYTES_PER_PIXEL > s1)
+            throw std::invalid_argument("PAN1 size too small for SECTION & LINE_PER_SECTION argument");
+        size_t s2 = IMO::FileSize(pan2);
+        if ((size_t)sections * linePerSection * BYTES_PER_PIXEL > s2)
+            throw std::invalid_argument("PAN2 size too small for SECTION & LINE_PER_SECTION argument");
+        if (s1 != s2) throw std::invalid_argument("PAN1 size doesn't match PAN2 size");
+        mSizePAN = s1;
+        mLinesPAN = (int)(s1 / ((size_t)mW * BYTES_PER_PIXEL));
+        OLOG("PAN: %d lines total.", mLinesPAN);
+        if (mLinesPAN < sections * linePerSection)
+            throw std::invalid_argument("PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)");
+        mRrcFilePAN1 = mFilePAN1;
+        mRrcFilePAN2 = mFilePAN2;
+    }
+
+    // stitcher.h:148-201 (runs on the files mRrcFilePAN1/2 point at: the raw ones, App.B-1)
+    void CalcSttParameters(double threshold = OIP_STT_DEF_PHCTHRHLD, double maxDeltaY = 0.0, int edgeCols = 0)
+    {
+        const size_t npx = (size_t)mW * mLinesPAN;
+        std::unique_ptr<char[]> h1((char *)IMO::LoadRawImage(mRrcFilePAN1, 0, 0, mSizePAN));
+        std::unique_ptr<char[]> h2((char *)IMO::LoadRawImage(mRrcFilePAN2, 0, 0, mSizePAN));
+        DevBuf<uint16_t> d1(npx), d2(npx);
+        d1.upload((uint16_t *)h1.get(), npx);
+        d2.upload((uint16_t *)h2.get(), npx);
+        std::vector<double> r(3 * (size_t)mSections);
+        Device::get().check(oip_stt_correlate(Device::get().ctx(), d1.p, d2.p, mW, mLinesPAN, 0, mLinesPAN, mSections,
+                                              mLinePerSection, mOverlapCols, edgeCols, r.data()));
+        const int gapLines = (mLinesPAN - mSections * mLinePerSection) / (mSections + 1);
+        const int stepLines = gapLines + mLinePerSection;
+        mDeltaX = mDeltaY = mResponse = 0.0;
+        int valid = 0;
+        OLOG("Calculating stitching delta values ...");
+        RLOG("| offset |  delta x |  delta y | response | r |");
+        RLOG("-----------------------------------------------");
+        for (int i = 0; i < mSections; ++i) {
+            double dx = r[3 * i], dy = r[3 * i + 1], resp = r[3 * i + 2];
+            bool isValid = resp >= threshold && (maxDeltaY <= 0.0 || std::abs(dy) <= maxDeltaY);
+            if (isValid) { mDeltaX += dx; mDeltaY += dy; mResponse += resp; valid++; }
+            RLOG("|%7d |%10.4f|%10.4f|%10.4f|%s|", gapLines + i * stepLines, dx, dy, resp, isValid ? " Y " : " N ");
+        }
+        if (valid == 0) throw std::runtime_error("No valid delta value found for stitching parameter calculating");
+        mDeltaX /= valid; mDeltaY /= valid; mResponse /= valid;
+        OLOG("Total %d valid delta value pairs found, everage value:", valid);
+        OLOG("    dx: %.5f, dy: %.5f, r: %.5f", mDeltaX, mDeltaY, mResponse);
+    }
+
+    void DoRRC()                                                        // stitcher.h:141-146
+    {
+        mRrcFilePAN1 = IMO::BuildOutputFilePath(mFilePAN1, ".RRC");
+        mRrcFilePAN2 = IMO::BuildOutputFilePath(mFilePAN2, ".RRC");
+        IMO::DoRRC4RAW(mFilePAN1, mW, mParamFileRRC1, mRrcFilePAN1);
+        IMO::DoRRC4RAW(mFilePAN2, mW, mParamFileRRC2, mRrcFilePAN2);
+    }
+
+    int PreStitch()                                                     // stitcher.h:83-139
+    {
+        mPreSttFilePAN2 = IMO::BuildOutputFilePath(mRrcFilePAN2, ".PRESTT");
+        const size_t npx = (size_t)mW * mLinesPAN;
+        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mRrcFilePAN2, 0, 0, mSizePAN));
+        stop_watch sw;
+        DevBuf<uint16_t> src(npx), dst(npx);
+        src.upload((uint16_t *)h.get(), npx);
+        Device::get().check(oip_remap_shift_bicubic_u16(Device::get().ctx(), src.p, 0, mLinesPAN, dst.p, 0, mLinesPAN, mW,
+                                                        mLinesPAN, mDeltaX, mDeltaY, OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
+        dst.download((uint16_t *)h.get(), npx);
+        IMO::WriteBufferToFile(h.get(), mSizePAN, mPreSttFilePAN2);
+        double es = sw.tick();
+        OLOG("Pre-stitched PAN2 written to file '%s'.", mPreSttFilePAN2.c_str());
+        OLOG("%zu bytes processed & written in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
+        const int ucut = mDeltaY >= 0.0 ? 0 : (int)(-mDeltaY) + 1, bcut = mDeltaY >= 0.0 ? (int)mDeltaY + 1 : 0;
+        return mLinesPAN - (ucut + bcut);        // SectionaryRemap's returned row_offset
+    }
+
+    double deltaX() const { return mDeltaX; }
+    double deltaY() const { return mDeltaY; }
+    double response() const { return mResponse; }
+
+private:
+    std::string mFilePAN1, mFilePAN2, mParamFileRRC1, mParamFileRRC2, mRrcFilePAN1, mRrcFilePAN2, mPreSttFilePAN2;
+    double mDeltaX = 0, mDeltaY = 0, mResponse = 0;
+    size_t mSizePAN = 0;
+    int mSections, mLinePerSection, mOverlapCols, mLinesPAN = 0, mW;
+};
+
+// ---- PreProcessor (preproc.h:30-599) ---------------------------------------------------------------
+struct InterBandShift { double dx, dy, rs; int cx; };                   // preproc.h:23-28
+
+class PreProcessor {
+public:
+    PreProcessor(const std::string &panFile, const std::string &mssFile, const std::string &rrcFile4PAN,
+                 const std::string rrcFile4MSSBand[MSS_BANDS], int pixelsPerLine = OIP_PIXELS_PER_LINE)
+        : mPanFile(panFile), mMssFile(mssFile), mRrcPanFile(rrcFile4PAN), mW(pixelsPerLine)
+    {
+        for (int i = 0; i < MSS_BANDS; ++i) mRrcMssBndFile[i] = rrcFile4MSSBand[i];
+        CheckFilesAttributes();
+    }
+
+    void LoadPAN()                                                      // preproc.h:51-54
+    {
+        OLOG("Loading PAN raw image ...");
+        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mPanFile, 0, 0, mSizePAN));
+        mPAN.alloc(mSizePAN / 2);
+        mPAN.upload((uint16_t *)h.get(), mSizePAN / 2);
+        Device::get().check(oip_sync(Device::get().ctx()));
+    }
+
+    void LoadMSS()                                                      // preproc.h:56-80 (split deferred to DoRRC4MSS)
+    {
+        OLOG("Loading MSS raw image ...");
+        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mMssFile, 0, 0, mSizeMSS));
+        mMssBil.alloc(mSizeMSS / 2);
+        mMssBil.upload((uint16_t *)h.get(), mSizeMSS / 2);
+        mPlaneStride = (size_t)(mW / MSS_BANDS) * mLinesMSS;
+        mPlanes.alloc(mPlaneStride * MSS_BANDS);
+        Device::get().check(oip_sync(Device::get().ctx()));
+        mSplitDone = false;
+    }
+
+    void DoRRC4PAN()                                                    // preproc.h:188-200
+    {
+        if (!mPAN.p) throw std::logic_error("PAN raw image data not loaded, call `LoadPAN()' first");
+        std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile(mRrcPanFile.c_str(), mW));
+        DevBuf<double> kb((size_t)mW * 2);
+        kb.upload((double *)prm.get(), (size_t)mW * 2);
+        OLOG("Begin inplace RRC for PAN data ... ");
+        stop_watch sw;
+        Device::get().check(oip_rrc_u16(Device::get().ctx(), mPAN.p, mPAN.p, mW, (long)mLinesPAN, kb.p));
+        Device::get().check(oip_sync(Device::get().ctx()));
+        double es = sw.tick();
+        OLOG("RRC for PAN done in %.4f seconds (%.1f MBps).", es, mSizePAN / es / 1024.0 / 1024.0);
+    }
+
+    // preproc.h:202-222; doRRC=false is --no-rrc4mss (split only)
+    void DoRRC4MSS(bool doRRC = true)
+    {
+        if (!mMssBil.p) throw std::logic_error("MSS raw image data not loaded, call `LoadMSS()' first");
+        const int bw = mW / MSS_BANDS;
+        DevBuf<double> kb;
+        if (doRRC) {
+            std::vector<double> all((size_t)mW * 2);
+            for (int i = 0; i < MSS_BANDS; ++i) {
+                std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile(mRrcMssBndFile[i].c_str(), bw));
+                memcpy(&all[(size_t)i * bw * 2], prm.get(), sizeof(double) * 2 * bw);
+            }
+            kb.alloc((size_t)mW * 2);
+            kb.upload(all.data(), (size_t)mW * 2);
+        }
+        OLOG("Splitting %d bands of MSS image%s ...", MSS_BANDS, doRRC ? " with inplace RRC" : "");
+        stop_watch sw;
+        Device::get().check(oip_mss_split_rrc_u16(Device::get().ctx(), mMssBil.p, mPlanes.p, mPlaneStride, mW, (long)mLinesMSS,
+                                                  doRRC ? kb.p : nullptr));
+        Device::get().check(oip_sync(Device::get().ctx()));
+        double es = sw.tick();
+        OLOG("RRC done for MSS bands in %.4f seconds (%.1f MBps).", es, mSizeMSS / es / 1024.0 / 1024.0);
+        mMssBil.release();
+        mSplitDone = true;
+    }
+
+    void CalcInterBandCorrelation(int slices = OIP_IBCV_DEF_SLICES, int sections = OIP_IBCV_DEF_SECTIONS,
+                                  double threshold = OIP_IBCV_DEF_THRESHOLD, bool autoUnloadPAN = true)
+    {                                                                   // preproc.h:224-347
+        if (!mSplitDone) DoRRC4MSS(false);
+        OLOG("Calculating inter-band correlation with %d slices in %d section(s) ...", slices, sections);
+        const int n = slices * sections;
+        std::vector<double> t((size_t)MSS_BANDS * n * 4);
+        stop_watch sw;
+        Device::get().check(oip_interband_correlate(Device::get().ctx(), mPAN.p, (long)mLinesPAN, 0, (long)mLinesPAN, mPlanes.p,
+                                                    mPlaneStride, 0, (long)mLinesMSS, mW, slices, sections,
+                                                    OIP_CORRELATION_LINES, t.data()));
+        OLOG("Inter-band correlation finished in %.3f seconds, result:", sw.tick());
+        for (int b = 0; b < MSS_BANDS; ++b) {
+            mBandShift[b].resize(n);
+            for (int i = 0; i < n; ++i) {
+                const double *s = &t[((size_t)b * n + i) * 4];
+                mBandShift[b][i] = InterBandShift{s[0], s[1], s[2], (int)s[3]};
+            }
+        }
+        DumpInterBandShiftValues(slices, sections);
+        OLOG("Filter invalid correlation values & try polynomial fitting ...");
+        char err[512];
+        int rc = oip_filter_and_fit(t.data(), n, threshold, OIP_IBCV_MIN_COUNT, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0], err, sizeof err);
+        if (rc != OIP_OK) { OLOG("%s.", err); throw std::runtime_error(err); }
+        for (int b = 0; b < MSS_BANDS; ++b) {
+            OLOG("BAND %d\tdeltaX coeff: [1] %.15f, [0] %.9f", b, mDeltaXcoeffs[b][1], mDeltaXcoeffs[b][0]);
+            OLOG("\tdeltaY coeff: [2] %.15f, [1] %.15f, [0] %.9f", mDeltaYcoeffs[b][2], mDeltaYcoeffs[b][1], mDeltaYcoeffs[b][0]);
+        }
+        OLOG("CalcInterBandCorrelation(): done.");
+        if (autoUnloadPAN) mPAN.release();
+    }
+
+    // preproc.h:351-425 (+ inner :428-468); writes <stem>.ALIGNED.RAW (16UC4) instead of the TIFF
+    void DoInterBandAlignment(int linePerSection, int lineOffset = 0, int sectionOverlap = OIP_IBPA_DEFAULT_LINEOVERLAP,
+                              bool keepLeadingLines = false, bool autoUnloadRawMSS = true)
+    {
+        OLOG("Doing inter-band alignment ...");
+        const int Wb = mW / MSS_BANDS;
+        const long rows = (long)mLinesMSS - lineOffset - (keepLeadingLines ? 0 : sectionOverlap);
+        if (rows <= 0) throw std::invalid_argument("Too few image lines left to process");
+        DevBuf<uint16_t> out((size_t)rows * Wb * MSS_BANDS);
+        long processed = 0;
+        stop_watch sw;
+        Device::get().check(oip_align_mss_bicubic_u16x4(Device::get().ctx(), mPlanes.p, mPlaneStride, 0, (long)mLinesMSS, out.p, 0,
+                                                        rows, Wb, (long)mLinesMSS, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0],
+                                                        linePerSection, lineOffset, sectionOverlap, keepLeadingLines ? 1 : 0,
+                                                        OIP_IBPA_MIN_PROCESSLINES, &processed));
+        std::unique_ptr<uint16_t[]> h(new uint16_t[(size_t)rows * Wb * MSS_BANDS]);
+        out.download(h.get(), (size_t)rows * Wb * MSS_BANDS);
+        double es = sw.tick();
+        OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", es, processed, rows);
+        auto save = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".RAW");
+        OLOG("Outputing aligned image (16UC4 RAW, %d x %ld) to [%s] ...", Wb, rows, save.c_str());
+        IMO::WriteBufferToFile((const char *)h.get(), (size_t)rows * Wb * MSS_BANDS * 2, save);
+        OLOG("Output done.");
+        if (autoUnloadRawMSS) mPlanes.release();
+        OLOG("DoInterBandAlignment(): done.");
+    }
+
+    void WriteRRCedPAN()                                                // preproc.h:93-105
+    {
+        auto save = IMO::BuildOutputFilePath(mPanFile, ".RRC");
+        std::unique_ptr<uint16_t[]> h(new uint16_t[mSizePAN / 2]);
+        mPAN.download(h.get(), mSizePAN / 2);
+        IMO::WriteBufferToFile((const char *)h.get(), mSizePAN, save);
+        OLOG("Written to file [%s].", save.c_str());
+    }
+
+    const double *deltaXcoeffs() const { return &mDeltaXcoeffs[0][0]; }
+    const double *deltaYcoeffs() const { return &mDeltaYcoeffs[0][0]; }
+
+private:
+    void DumpInterBandShiftValues(int slices, int sections)             // preproc.h:470-490
+    {
+        RLOG("|#SLC|Start|Center| End |   B1.x   |   B2.x   |   B3.x   |   B4.x   |   B1.y   |   B2.y   |   B3.y   |   B4.y   "
+             "|   B1.r   |   B2.r   |   B3.r   |   B4.r   |");
+        int sliceCols = mW / slices;
+        for (int s = 0; s < sections; ++s)
+            for (int i = 0; i < slices; ++i) {
+                int ii = i + s * slices;
+                RLOG("|%4d|%5d|%6d|%5d|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|%10.4f|", i,
+                     i * sliceCols, mBandShift[0][ii].cx, (i + 1) * sliceCols, mBandShift[0][ii].dx, mBandShift[1][ii].dx,
+                     mBandShift[2][ii].dx, mBandShift[3][ii].dx, mBandShift[0][ii].dy, mBandShift[1][ii].dy, mBandShift[2][ii].dy,
+                     mBandShift[3][ii].dy, mBandShift[0][ii].rs, mBandShift[1][ii].rs, mBandShift[2][ii].rs, mBandShift[3][ii].rs);
+            }
+    }
+
+    void CheckFilesAttributes()                                         // preproc.h:552-572
+    {
+        OLOG("Checking PAN raw file attributes ...");
+        mSizePAN = IMO::FileSize(mPanFile);
+        const size_t lineBytes = (size_t)mW * BYTES_PER_PIXEL;
+        mLinesPAN = mSizePAN / lineBytes;
+        OLOG("Checking MSS raw file attributes ...");
+        mSizeMSS = IMO::FileSize(mMssFile);
+        mLinesMSS = mSizeMSS / lineBytes;
+        if (mSizePAN != MSS_BANDS * mSizeMSS)
+            throw std::runtime_error("PAN file size does not match MSS file size: PAN file should be " + std::to_string(MSS_BANDS) +
+                                     "x as large as MSS file");
+        if (mSizePAN % lineBytes != 0)
+            throw std::runtime_error("PAN file size invalid: should be multiplies of " + std::to_string(lineBytes));
+        OLOG("CheckFilesAttributes(): OK.");
+    }
+
+    const std::string mPanFile, mMssFile, mRrcPanFile;
+    std::string mRrcMssBndFile[MSS_BANDS];
+    int mW;
+    size_t mSizePAN = 0, mSizeMSS = 0, mLinesPAN = 0, mLinesMSS = 0, mPlaneStride = 0;
+    DevBuf<uint16_t> mPAN, mMssBil, mPlanes;
+    bool mSplitDone = false;
+    std::vector<InterBandShift> mBandShift[MSS_BANDS];
+    double mDeltaXcoeffs[MSS_BANDS][2] = {};
+    double mDeltaYcoeffs[MSS_BANDS][3] = {};
+};
+
+}  // namespace OIPGPU

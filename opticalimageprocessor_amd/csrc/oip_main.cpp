@@ -1,0 +1,232 @@
+// oip_main.cpp -- the reference's command line (main.cpp:92-343) rebuilt on the C ABI.
+//
+//   oip prestitch --pan1 A.RAW --pan2 B.RAW [--rrc1 --rrc2 -s -l --stitch-overlap --stt-threshold
+//                 --stt-maxdeltay -e -r/--rrc/--no-rrc -c]                     (main.cpp:112-150)
+//   oip stitch --image1 L.RAW --image2 R.RAW -c/--fold-cols N [-o OUT.RAW]       (main.cpp:159-190)
+//   oip --pan P.RAW --mss M.RAW [--do-rrc4pan --rrc-pan F --no-rrc4mss --rrc-msb1..4 F --slices
+//       --ibc-sections --ibc-threshold --line-offset --lines-section --overlap-lines -k]   (:193-252)
+//   oip -v | --version          prints 1.1
+// plus --width N (pixels per PAN line; the reference hard-codes 12288, oipshared.h:28).
+// `auxsep`, TIFF input/output, -g/--GDAL and -m/--band-map are outside this build.
+//
+// Exit codes as the reference: usage_error -> "USAGE ERROR" + 254; any std::exception -> 2; unknown
+// -> 1; help/version -> 255 (CLI11's Success + 255, main.cpp:262-263); argument errors -> CLI11's
+// codes (RequiredError 106, ValidationError 105, ExtrasError 109, ConversionError 104).
+#include <cstdlib>
+#include <map>
+#include <set>
+
+#include "oip_host.hpp"
+
+using namespace OIPGPU;
+
+namespace {
+
+struct cli_error : public std::runtime_error {
+    int code;
+    cli_error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// option table: name -> takes a value?
+struct Spec {
+    std::map<std::string, std::string> alias;       // "-s" -> "--sections"
+    std::set<std::string> valued, flags;
+};
+
+struct Parsed {
+    std::map<std::string, std::string> val;
+    std::set<std::string> flag;
+    bool has(const std::string &k) const { return val.count(k) || flag.count(k); }
+    std::string str(const std::string &k, const std::string &def = "") const { auto it = val.find(k); return it == val.end() ? def : it->second; }
+    int integer(const std::string &k, int def) const
+    {
+        auto it = val.find(k);
+        if (it == val.end()) return def;
+        char *e = nullptr;
+        long v = strtol(it->second.c_str(), &e, 10);
+        if (!e || *e) throw cli_error(104, "Could not convert: " + k + " = " + it->second);
+        return (int)v;
+    }
+    double real(const std::string &k, double def) const
+    {
+        auto it = val.find(k);
+        if (it == val.end()) return def;
+        char *e = nullptr;
+        double v = strtod(it->second.c_str(), &e);
+        if (!e || *e) throw cli_error(104, "Could not convert: " + k + " = " + it->second);
+        return v;
+    }
+};
+
+Parsed parse(const Spec &sp, const std::vector<std::string> &args)
+{
+    Parsed p;
+    for (size_t i = 0; i < args.size(); ++i) {
+        std::string a = args[i], v;
+        bool has_v = false;
+        auto eq = a.find('=');
+        if (a.rfind("--", 0) == 0 && eq != std::string::npos) { v = a.substr(eq + 1); a = a.substr(0, eq); has_v = true; }
+        auto al = sp.alias.find(a);
+        if (al != sp.alias.end()) a = al->second;
+        if (sp.flags.count(a)) { p.flag.insert(a); continue; }
+        if (sp.valued.count(a)) {
+            if (!has_v) {
+                if (i + 1 >= args.size()) throw cli_error(114, a + ": 1 required value missing");
+                v = args[++i];
+            }
+            p.val[a] = v;
+            continue;
+        }
+        throw cli_error(109, "The following argument was not expected: " + args[i]);
+    }
+    return p;
+}
+
+void require(const Parsed &p, const std::string &k)
+{
+    if (!p.has(k)) throw cli_error(106, k + " is required");
+}
+
+void existing_file(const Parsed &p, const std::string &k)
+{
+    if (!p.val.count(k)) return;
+    struct stat st;
+    if (stat(p.val.at(k).c_str(), &st) != 0 || !S_ISREG(st.st_mode))
+        throw cli_error(105, k + ": File does not exist: " + p.val.at(k));
+}
+
+void usage()
+{
+    puts("Optical Satellite Image Pre-Processing/Processing Utility (MI355X build)\n"
+         "Usage: oip [OPTIONS] [SUBCOMMAND]\n\n"
+         "Options:\n"
+         "  -h,--help  -v,--version  --width N\n"
+         "  --pan FILE --mss FILE [--do-rrc4pan --rrc-pan FILE --write-rrcpan/--no-rrcpan] [--no-rrc4mss]\n"
+         "  --rrc-msb1 FILE --rrc-msb2 FILE --rrc-msb3 FILE --rrc-msb4 FILE\n"
+         "  --slices N --ibc-sections N --ibc-threshold X --line-offset N --lines-section N --overlap-lines N -k,--keep-leading\n\n"
+         "Subcommands:\n"
+         "  prestitch  --pan1 FILE --pan2 FILE [--rrc1 FILE --rrc2 FILE -s N -l N --stitch-overlap N\n"
+         "             --stt-threshold X --stt-maxdeltay X -e N -r,--rrc/--no-rrc -c,--only-calculate]\n"
+         "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE]");
+}
+
+int run_prestitch(const std::vector<std::string> &args, int width)
+{
+    Spec sp;
+    sp.valued = {"--pan1", "--pan2", "--rrc1", "--rrc2", "--sections", "--section-lines", "--stitch-overlap", "--stt-threshold",
+                 "--stt-maxdeltay", "--edge-cols", "--width"};
+    sp.flags = {"--rrc", "--no-rrc", "--only-calculate"};
+    sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-r", "--rrc"}, {"-c", "--only-calculate"}};
+    Parsed p = parse(sp, args);
+    require(p, "--pan1");
+    require(p, "--pan2");
+    for (auto k : {"--pan1", "--pan2", "--rrc1", "--rrc2"}) existing_file(p, k);
+    width = p.integer("--width", width);
+    const int sections = p.integer("--sections", OIP_STT_DEF_SECTIONS);
+    const int sectionLines = p.integer("--section-lines", OIP_STT_DEF_SECLINES);
+    const int overlapCols = p.integer("--stitch-overlap", OIP_STT_DEF_OVERLAPPX);
+    const int edgeCols = p.integer("--edge-cols", 0);
+    if (edgeCols < 0 || edgeCols > overlapCols / 2) throw cli_error(105, "--edge-cols: invalid edge cols");      // main.cpp:135-141
+    const double thr = p.real("--stt-threshold", OIP_STT_DEF_PHCTHRHLD), maxdy = p.real("--stt-maxdeltay", 0.0);
+    const bool doRRC = !p.flag.count("--no-rrc");
+    const bool onlyCalc = p.flag.count("--only-calculate") != 0;
+    // main.cpp:270-286
+    Stitcher stt(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), sections, sectionLines, overlapCols, width);
+    stt.CalcSttParameters(thr, maxdy, edgeCols);
+    if (!onlyCalc) {
+        if (doRRC) stt.DoRRC();
+        stt.PreStitch();
+    }
+    return 0;
+}
+
+int run_stitch(const std::vector<std::string> &args, int width)
+{
+    Spec sp;
+    sp.valued = {"--image1", "--image2", "--out", "--fold-cols", "--band-map", "--width"};
+    sp.flags = {"--GDAL"};
+    sp.alias = {{"-o", "--out"}, {"-c", "--fold-cols"}, {"-g", "--GDAL"}, {"-m", "--band-map"}};
+    Parsed p = parse(sp, args);
+    require(p, "--image1");
+    require(p, "--image2");
+    require(p, "--fold-cols");
+    width = p.integer("--width", width);
+    const int foldCols = p.integer("--fold-cols", 0);
+    if (foldCols < 2) throw cli_error(105, "--fold-cols: fold column value too small");                           // main.cpp:166-170
+    if (p.has("--GDAL") || p.has("--band-map"))
+        throw std::invalid_argument("Stitch(): GDAL/TIFF output is not available in this build (SURVEY 8f)");
+    Stitcher::Stitch(p.str("--image1"), p.str("--image2"), p.str("--out"), foldCols / 2, width);                  // main.cpp:189
+    return 0;
+}
+
+int run_default(const std::vector<std::string> &args, int width)
+{
+    Spec sp;
+    sp.valued = {"--pan", "--mss", "--rrc-pan", "--rrc-msb1", "--rrc-msb2", "--rrc-msb3", "--rrc-msb4", "--slices", "--ibc-sections",
+                 "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width"};
+    sp.flags = {"--do-rrc4pan", "--write-rrcpan", "--no-rrcpan", "--no-rrc4mss", "--keep-leading"};
+    sp.alias = {{"-k", "--keep-leading"}};
+    Parsed p = parse(sp, args);
+    for (auto k : {"--pan", "--mss", "--rrc-msb1", "--rrc-msb2", "--rrc-msb3", "--rrc-msb4"}) existing_file(p, k);
+    width = p.integer("--width", width);
+    const double thr = p.real("--ibc-threshold", OIP_IBCV_DEF_THRESHOLD);
+    if (thr < 0.0 || thr >= 1.0) throw cli_error(105, "--ibc-threshold: invalid threshold value");               // main.cpp:233-239
+    if ((p.has("--rrc-pan") || p.has("--write-rrcpan") || p.has("--no-rrcpan")) && !p.has("--do-rrc4pan"))
+        throw cli_error(107, "--rrc-pan requires --do-rrc4pan");                                                  // ->needs(rrc4pan)
+    const bool doRRC4PAN = p.flag.count("--do-rrc4pan") != 0;
+    const bool doRRC4MSS = !p.flag.count("--no-rrc4mss");
+    // main.cpp:288-299
+    if (doRRC4PAN && p.str("--rrc-pan").empty()) throw usage_error("RRC parameter file of PAN needed");
+    std::string msb[MSS_BANDS] = {p.str("--rrc-msb1"), p.str("--rrc-msb2"), p.str("--rrc-msb3"), p.str("--rrc-msb4")};
+    if (doRRC4MSS && (msb[0].empty() || msb[1].empty() || msb[2].empty() || msb[3].empty()))
+        throw usage_error("RRC parameter file of all MSS Bands needed");
+    // main.cpp:301-316
+    PreProcessor pp(p.str("--pan"), p.str("--mss"), p.str("--rrc-pan"), msb, width);
+    pp.LoadPAN();
+    pp.LoadMSS();
+    if (doRRC4PAN) {
+        pp.DoRRC4PAN();
+        if (p.flag.count("--write-rrcpan")) pp.WriteRRCedPAN();      // RAW instead of the reference's TIFF
+    }
+    pp.DoRRC4MSS(doRRC4MSS);
+    pp.CalcInterBandCorrelation(p.integer("--slices", OIP_IBCV_DEF_SLICES), p.integer("--ibc-sections", OIP_IBCV_DEF_SECTIONS), thr);
+    pp.DoInterBandAlignment(p.integer("--lines-section", OIP_IBPA_DEFAULT_BATCHLINES), p.integer("--line-offset", 0),
+                            p.integer("--overlap-lines", OIP_IBPA_DEFAULT_LINEOVERLAP), p.flag.count("--keep-leading") != 0);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, const char *argv[])
+{
+    try {
+        const char *lf = getenv("LOGFILE");                             // main.cpp:322-329
+        log_file() = fopen(lf ? lf : "oip.log", "a");
+        std::vector<std::string> args(argv + 1, argv + argc);
+        int width = OIP_PIXELS_PER_LINE;
+        try {
+            for (auto &a : args) {
+                if (a == "-h" || a == "--help") { usage(); return 255; }
+                if (a == "-v" || a == "--version") { puts("1.1"); return 255; }
+            }
+            if (!args.empty() && args[0] == "prestitch") return run_prestitch({args.begin() + 1, args.end()}, width);
+            if (!args.empty() && args[0] == "stitch") return run_stitch({args.begin() + 1, args.end()}, width);
+            if (!args.empty() && args[0] == "auxsep")
+                throw std::invalid_argument("auxsep (down-link de-framing) is outside this build: run the reference's auxsep, then this tool");
+            if (args.empty()) { usage(); return 0; }
+            return run_default(args, width);
+        } catch (const cli_error &e) {
+            fprintf(stderr, "%s\nRun with --help for more information.\n", e.what());
+            return e.code;
+        }
+    } catch (usage_error &ex) {
+        printf("USAGE ERROR: %s.\n", ex.what());
+        return 254;
+    } catch (std::exception &ex) {
+        OLOG("[ERROR] %s.", ex.what());
+        return 2;
+    } catch (...) {
+        OLOG("[FATAL] UNKOWN FATAL ERROR OCCURED.");
+        return 1;
+    }
+}

@@ -1,0 +1,87 @@
+"""GPU: the `oip` CLI end to end (the reference's 4-step task file, DOC/sample-task.sh, steps 1-3
+on RAW files) against the oracle.  Shifts / polynomials are re-derived in-process with the same
+library calls the CLI makes (bit-identical), so the resampled files can be compared bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _synth
+
+pytestmark = pytest.mark.gpu
+OIP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opticalimageprocessor_amd", "lib", "oip")
+
+
+def _csv(path, kb):
+    with open(path, "w") as f:
+        f.write("1\n%d\n0\n" % len(kb))
+        for k, b in kb:
+            f.write("%.6f , %.4f\n" % (k, b))
+
+
+def _cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
+    import opticalimageprocessor_amd as oip
+    W, L, OV = 1024, 33024, 64
+    d = str(tmp_path)
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"))
+    pan1, pan2 = _synth.ccd_pair(L, W, OV, (3, -2), seed=5)
+    kb1, kb2 = _synth.lut(W, 1), _synth.lut(W, 2)
+    pan1.tofile(os.path.join(d, "S_PAN-1.RAW")); pan2.tofile(os.path.join(d, "S_PAN-2.RAW"))
+    _csv(os.path.join(d, "PAN-1.csv"), kb1); _csv(os.path.join(d, "PAN-2.csv"), kb2)
+
+    # ---- step 1: prestitch (stitcher.h: CalcSttParameters on the raw files, DoRRC, PreStitch)
+    r = subprocess.run([OIP, "prestitch", "--width", str(W), "--pan1", "S_PAN-1.RAW", "--pan2", "S_PAN-2.RAW", "--rrc1", "PAN-1.csv",
+                        "--rrc2", "PAN-2.csv", "-s", "3", "-l", "1600", "--stitch-overlap", str(OV), "--stt-threshold", "0.05"],
+                       cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rrc1 = np.fromfile(os.path.join(d, "S_PAN-1.RRC.RAW"), np.uint16).reshape(L, W)
+    rrc2 = np.fromfile(os.path.join(d, "S_PAN-2.RRC.RAW"), np.uint16).reshape(L, W)
+    assert np.array_equal(rrc1, oracle_mod.rrc(pan1, kb1)) and np.array_equal(rrc2, oracle_mod.rrc(pan2, kb2))
+    t = ctx.stt_correlate(_cuda(pan1), _cuda(pan2), W, L, 0, L, 3, 1600, OV, 0)
+    ok = t[:, 2] >= 0.05
+    dx = dy = 0.0
+    for i in range(3):                       # same accumulation order as stitcher.h:181-198
+        if ok[i]:
+            dx += t[i, 0]; dy += t[i, 1]
+    dx /= ok.sum(); dy /= ok.sum()
+    assert ("dx: %.5f, dy: %.5f" % (dx, dy)) in r.stdout
+    want, _ = oracle_mod.prestitch(rrc2, dx, dy)
+    got = np.fromfile(os.path.join(d, "S_PAN-2.RRC.PRESTT.RAW"), np.uint16).reshape(L, W)
+    assert np.array_equal(got, want)
+
+    # ---- step 2: stitch the two PAN strips (RAW out); --fold-cols is halved (main.cpp:189)
+    r = subprocess.run([OIP, "stitch", "--width", str(W), "--image1", "S_PAN-1.RRC.RAW", "--image2", "S_PAN-2.RRC.PRESTT.RAW",
+                        "--fold-cols", "40", "-o", "stitched-PAN.RAW"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    st = np.fromfile(os.path.join(d, "stitched-PAN.RAW"), np.uint16).reshape(L, 2 * (W - 20))
+    assert np.array_equal(st, oracle_mod.stitch_raw(rrc1, got, 20))
+
+    # ---- step 3: default action on (RRC'd PAN, raw MSS)
+    shifts_true = [(2, -1), (1, 1), (-1, -2), (-2, 1)]
+    pan, bands = _synth.pan_mss(L, W, shifts_true, seed=6)
+    bil = np.concatenate(bands, axis=1)
+    pan.tofile(os.path.join(d, "T_PAN.RAW")); bil.tofile(os.path.join(d, "T_MSS.RAW"))
+    kbs = [_synth.lut(W // 4, 20 + b) for b in range(4)]
+    for b in range(4):
+        _csv(os.path.join(d, "MSS.B%d.csv" % (b + 1)), kbs[b])
+    args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--slices", "8", "--ibc-sections", "1",
+            "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
+    for b in range(4):
+        args += ["--rrc-msb%d" % (b + 1), "MSS.B%d.csv" % (b + 1)]
+    r = subprocess.run(args, cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    cbands = [oracle_mod.rrc(bands[b], kbs[b]) for b in range(4)]
+    Lm, Wb = L // 4, W // 4
+    planes = _cuda(np.stack(cbands, 0))
+    sh = ctx.interband_correlate(_cuda(pan), L, 0, L, planes, Lm * Wb, 0, Lm, W, 8, 1, 16000)
+    cx, cy = oip.filter_and_fit(sh, 0.0, 5)
+    want, nvalid = oracle_mod.align_mss(cbands, cx, cy, 3000, 0, 100, False, 1500)
+    got = np.fromfile(os.path.join(d, "T_MSS.ALIGNED.RAW"), np.uint16).reshape(want.shape)
+    assert np.array_equal(got, want)
+    assert "%d lines valid" % nvalid in r.stdout

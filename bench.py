@@ -175,10 +175,20 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # OIP_BENCH_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks
+    # (ranks share devices, transfers are staged through the host); real runs use RCCL ("nccl")
+    dist_backend = os.environ.get("OIP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if dist_backend == "nccl" and world > ndev:
+        sys.exit("bench.py: %d ranks but %d GPUs visible" % (world, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(dist_backend)
     ctx = oip.Context(local_rank)
     # one stream for everything: the library's kernels, torch's copies and RCCL's ordering
     # (RCCL synchronises against torch's CURRENT stream, so make that the context's stream)
@@ -260,7 +270,7 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -296,6 +306,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16 rasters; fp64 RRC/maps, f32 bicubic and FFT", "data": "synthetic",
             "config": {"workload": workload, "width": W, "pan_lines_per_gpu": pb, "parallelism": "rowblock%d" % world,
+                       "backend": "rccl" if dist_backend == "nccl" else dist_backend + " (rehearsal, host-staged)",
                        "ibc_threshold": threshold, "inputs": "resident in HBM"},
             "roofline": roof,
             "kernels": kernels,

@@ -170,6 +170,10 @@ class ShardBuffers:
 
 def run_transfers(transfers, bufs: ShardBuffers, rank: int, group=None):
     """execute the point-to-point line transfers (grouped: one launch on RCCL)"""
+    # gloo has no device point-to-point: device lines are staged through host memory (used only
+    # to rehearse the N-rank path on a 1-GPU box; the real runs use RCCL and move HBM to HBM)
+    stage = dist.get_backend(group) == "gloo" and bufs.pan.is_cuda
+    staged = []
     ops = []
     for t in transfers:
         if t.kind == "pan":
@@ -177,8 +181,13 @@ def run_transfers(transfers, bufs: ShardBuffers, rank: int, group=None):
         else:
             views = [bufs.mss_view(b, t.row0, t.rows) for b in range(4)] if rank in (t.src, t.dst) else []
         for v in views:
-            # carry u16 lines as int16 (same bytes): every backend supports it
-            v16 = v.view(torch.int16)
+            # carry the lines as bytes: RCCL/NCCL has no 16-bit integer type, every backend has uint8
+            v16 = v.view(torch.uint8)
+            if stage:
+                h = v16.cpu() if rank == t.src else torch.empty(v16.shape, dtype=torch.uint8)
+                if rank == t.dst:
+                    staged.append((v16, h))
+                v16 = h
             if rank == t.src:
                 ops.append(dist.P2POp(dist.isend, v16, t.dst, group=group))
             elif rank == t.dst:
@@ -190,12 +199,16 @@ def run_transfers(transfers, bufs: ShardBuffers, rank: int, group=None):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    for dev, host in staged:
+        dev.copy_(host)
 
 
 def gather_shifts(local: np.ndarray, device, group=None) -> np.ndarray:
     """all-gather the per-rank correlation tables (NaN = not mine) and merge them in rank
     order: every rank ends with the same complete table."""
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
     t = torch.from_numpy(np.ascontiguousarray(local)).to(device)
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t, group=group)

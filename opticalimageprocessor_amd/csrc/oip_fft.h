@@ -67,7 +67,8 @@ struct OipFft2dPlan {
 
 int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out);
 // forward: io (optional) applies to the FIRST pass' load; inverse: to the LAST pass' store
-int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, int inverse, const OipFftIo *io);
+int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, int inverse, const OipFftIo *io, int rows_done = 0);
+int oip_fft_table(oip_ctx *ctx, int T, const float2 **out);     // exp(-2 pi i t / T), t in [0, T)
 // re-run the last inverse pass for the 25 tiles holding the 5x5 window around *peak_key
 int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, const OipFftIo *io);
 long oip_fft2d_last_pass_blocks(const OipFft2dPlan *plan);

@@ -1,0 +1,158 @@
+// oip_fft_dev.h -- device-side building blocks of the FFT passes (complex helpers, radix
+// butterflies, compile-time Stockham stages), shared by fft.hip and the fused cross-power +
+// inverse row pass in phasecorr.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace oipfft {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmuli_neg(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// forward butterflies, w = exp(-2 pi i / r)
+__device__ __forceinline__ void bf2(float2 *x)
+{
+    float2 a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
+}
+__device__ __forceinline__ void bf3(float2 *x)
+{
+    const float s = 0.86602540378443864676f;
+    float2 t = cadd(x[1], x[2]);
+    float2 d = cscale(cmuli_neg(csub(x[1], x[2])), s);
+    float2 m = make_float2(x[0].x - 0.5f * t.x, x[0].y - 0.5f * t.y);
+    x[0] = cadd(x[0], t);
+    x[1] = cadd(m, d);
+    x[2] = csub(m, d);
+}
+__device__ __forceinline__ void bf4(float2 *x)
+{
+    float2 s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
+    float2 s13 = cadd(x[1], x[3]), d13 = cmuli_neg(csub(x[1], x[3]));
+    x[0] = cadd(s02, s13);
+    x[2] = csub(s02, s13);
+    x[1] = cadd(d02, d13);
+    x[3] = csub(d02, d13);
+}
+__device__ __forceinline__ void bf5(float2 *x)
+{
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    float2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]);
+    float2 t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
+    float2 m1 = make_float2(x[0].x + c1 * t1.x + c2 * t2.x, x[0].y + c1 * t1.y + c2 * t2.y);
+    float2 m2 = make_float2(x[0].x + c2 * t1.x + c1 * t2.x, x[0].y + c2 * t1.y + c1 * t2.y);
+    float2 u1 = cmuli_neg(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
+    float2 u2 = cmuli_neg(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    x[0] = cadd(x[0], cadd(t1, t2));
+    x[1] = cadd(m1, u1);
+    x[4] = csub(m1, u1);
+    x[2] = cadd(m2, u2);
+    x[3] = csub(m2, u2);
+}
+__device__ __forceinline__ void bf8(float2 *x)
+{
+    const float h = 0.70710678118654752440f;
+    float2 e[4] = {x[0], x[2], x[4], x[6]};
+    float2 o[4] = {x[1], x[3], x[5], x[7]};
+    bf4(e);
+    bf4(o);
+    o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));      // * w8
+    o[2] = cmuli_neg(o[2]);                                                // * w8^2
+    o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));     // * w8^3
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = cadd(e[k], o[k]);
+        x[k + 4] = csub(e[k], o[k]);
+    }
+}
+template <int R> __device__ __forceinline__ void butterfly(float2 *x)
+{
+    if (R == 2) bf2(x);
+    else if (R == 3) bf3(x);
+    else if (R == 4) bf4(x);
+    else if (R == 5) bf5(x);
+    else bf8(x);
+}
+
+template <int... Rs> struct RadixList {};
+
+template <int F, int First, int... Rest> struct TwTable {          // entries of w_F^t the stages need
+    static constexpr int rest_max(int acc) { return acc; }
+    static constexpr int value()
+    {
+        int m = 1;
+        const int r[] = {Rest..., 0};
+        for (int i = 0; r[i]; ++i) m = (F / r[i]) > m ? (F / r[i]) : m;
+        return m;
+    }
+};
+
+template <int F, int VS, int VP, int NT, int Ns, int R>
+__device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 *__restrict__ tw)
+{
+    constexpr int kFftBlock = NT;
+    constexpr int V = 1 << VS;
+    constexpr int Vp = VP;              // LDS pitch between consecutive points (>= V)
+    constexpr int NB = F / R;
+    constexpr int ITEMS = NB << VS;
+    constexpr int PER = (ITEMS + kFftBlock - 1) / kFftBlock;
+    constexpr int TWSTEP = F / (Ns * R);
+    float2 x[PER][R];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int item = threadIdx.x + i * kFftBlock;
+        if (ITEMS % kFftBlock == 0 || item < ITEMS) {
+            const int v = item & (V - 1), b = item >> VS;
+#pragma unroll
+            for (int m = 0; m < R; ++m) x[i][m] = buf[(b + m * NB) * Vp + v];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int item = threadIdx.x + i * kFftBlock;
+        if (ITEMS % kFftBlock == 0 || item < ITEMS) {
+            const int v = item & (V - 1), b = item >> VS;
+            const int k = b % Ns;
+            if (Ns > 1) {
+                // w^(k m) from w^k by repeated products: one table look-up per butterfly
+                const float2 w1 = tw[k * TWSTEP];
+                float2 w = w1;
+#pragma unroll
+                for (int m = 1; m < R; ++m) {
+                    x[i][m] = cmul(x[i][m], w);
+                    if (m + 1 < R) w = cmul(w, w1);
+                }
+            }
+            butterfly<R>(x[i]);
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int m = 0; m < R; ++m) buf[(j0 + m * Ns) * Vp + v] = x[i][m];
+        }
+    }
+    __syncthreads();
+}
+
+template <int F, int VS, int VP, int NT, int Ns, int... Rs> struct Stages;
+template <int F, int VS, int VP, int NT, int Ns> struct Stages<F, VS, VP, NT, Ns> {
+    static __device__ __forceinline__ void run(float2 *, const float2 *) {}
+};
+template <int F, int VS, int VP, int NT, int Ns, int R, int... Rest> struct Stages<F, VS, VP, NT, Ns, R, Rest...> {
+    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw)
+    {
+        stage_ct<F, VS, VP, NT, Ns, R>(buf, tw);
+        Stages<F, VS, VP, NT, Ns * R, Rest...>::run(buf, tw);
+    }
+};
+
+
+}  // namespace oipfft

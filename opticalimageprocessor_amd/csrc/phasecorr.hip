@@ -19,6 +19,7 @@
 // differs from OpenCV's own DFT, so shifts agree to ~1e-4 px, not bitwise (parity unpinned:
 // OpenCV is not in the reference tree).
 #include "oip_fft.h"
+#include "oip_fft_dev.h"
 #include "oip_internal.h"
 
 #include <cfloat>
@@ -232,23 +233,117 @@ __global__ __launch_bounds__(kBlock) void cross_power_kernel(float2 *__restrict_
     if (r1 != r2) out[r2 + px2] = ym;
 }
 
+// XpowerJob flattened on the host: distinct spectra and, per correlation, which of them and
+// which slot (real/imaginary) hold A and B
+struct FusedJob {
+    const float2 *z[3];
+    int narr, ncorr;
+    int ia0, ib0, pa0, pb0, ia1, ib1, pa1, pb1;
+};
+
+// Cross-power spectrum fused with the first inverse pass (the row pass) for shapes whose row
+// axis is a single factor (natural order along x): the workgroup of frequency line ky forms
+// Y(ky, .) and its mirror Y(-ky, .) in LDS straight from the spectra -- every input line read
+// once, Y never written in the spectral domain -- runs the two F-point inverse transforms and
+// stores both lines.  Replaces cross_power_kernel + one fft pass (a write and a read of the
+// whole Y array).
+template <int F, int NT, int... Rs>
+__global__ __launch_bounds__(NT) void xpower_inverse_row_kernel(float2 *__restrict__ out, FusedJob fj, int M, int P,
+                                                                OipAxisDigits yd, const float2 *__restrict__ twF)
+{
+    constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
+    constexpr int N = F;
+    constexpr int NIT = (N + NT - 1) / NT;
+    __shared__ float2 buf[2 * F];          // [point][line]: line 0 = ky, line 1 = -ky, interleaved
+    __shared__ float2 tw[TWN];
+    const int ky = blockIdx.x;
+    const int nky = ky ? M - ky : 0;
+    const long r1 = (long)oip_freq_to_pos(yd, ky) * P, r2 = (long)oip_freq_to_pos(yd, nky) * P;
+    const bool pair = r1 != r2;
+    for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
+    // distinct input spectra and who uses which: fixed-size, statically indexed (no scratch)
+    const float2 *z0 = fj.z[0], *z1 = fj.z[1], *z2 = fj.z[2];
+    const int narr = fj.narr;
+    // all spectrum loads of the two lines are issued before the arithmetic starts
+    float2 zk0[NIT], zk1[NIT], zk2[NIT], zm0[NIT], zm1[NIT], zm2[NIT];    // one array per spectrum: static indices only
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int kx = threadIdx.x + it * NT;
+        const int nkx = kx ? N - kx : 0;
+        const float2 zero = make_float2(0.f, 0.f);
+        const bool ok = kx < N;
+        zk0[it] = ok ? z0[r1 + kx] : zero;
+        zm0[it] = ok ? z0[r2 + nkx] : zero;
+        zk1[it] = ok && narr > 1 ? z1[r1 + kx] : zero;
+        zm1[it] = ok && narr > 1 ? z1[r2 + nkx] : zero;
+        zk2[it] = ok && narr > 2 ? z2[r1 + kx] : zero;
+        zm2[it] = ok && narr > 2 ? z2[r2 + nkx] : zero;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int kx = threadIdx.x + it * NT;
+        if (kx >= N) continue;
+        const int nkx = kx ? N - kx : 0;
+        const bool edge_col = (kx == 0) || (2 * kx == N);
+        const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+        float2 y = make_float2(0.f, 0.f), ym = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c >= fj.ncorr) break;
+            const int ia = c ? fj.ia1 : fj.ia0, ib = c ? fj.ib1 : fj.ib0;
+            const int pa = c ? fj.pa1 : fj.pa0, pb = c ? fj.pb1 : fj.pb0;
+            float2 zka = ia == 0 ? zk0[it] : (ia == 1 ? zk1[it] : zk2[it]);
+            float2 zma = ia == 0 ? zm0[it] : (ia == 1 ? zm1[it] : zm2[it]);
+            float2 zkb = ib == 0 ? zk0[it] : (ib == 1 ? zk1[it] : zk2[it]);
+            float2 zmb = ib == 0 ? zm0[it] : (ib == 1 ? zm1[it] : zm2[it]);
+            float2 A = spec_of(pa, zka, zma);
+            float2 B = spec_of(pb, zkb, zmb);
+            float2 C = cross_power_bin(A, B, real_bin, edge_col);
+            if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }
+            else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }
+        }
+        // inverse = conj(forward(conj(.)))
+        buf[2 * kx] = make_float2(y.x, -y.y);
+        buf[2 * nkx + 1] = pair ? make_float2(ym.x, -ym.y) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    oipfft::Stages<F, 1, 2, NT, 1, Rs...>::run(buf, tw);        // both lines in one Stockham network
+    for (int e = threadIdx.x; e < 2 * N; e += NT) {
+        const int line = e >= N, x = e - line * N;
+        if (line && !pair) break;
+        float2 a = buf[2 * x + line];
+        out[(line ? r2 : r1) + x] = make_float2(a.x, -a.y);
+    }
+}
+
+struct FusedRow {
+    int F, threads;
+    void (*fn)(float2 *, FusedJob, int, int, OipAxisDigits, const float2 *);
+};
+const FusedRow kFusedRow[] = {
+    {3000, 512, xpower_inverse_row_kernel<3000, 512, 3, 8, 5, 5, 5>},
+    {1250, 256, xpower_inverse_row_kernel<1250, 256, 2, 5, 5, 5, 5>},
+    {200, 256, xpower_inverse_row_kernel<200, 256, 8, 5, 5>},
+};
+
 // ---- peak: first maximum of the fftShift-ed surface + 5x5 weighted centroid ----------------------
 __device__ __forceinline__ bool pk_better(float v, long k, float bv, long bk) { return v > bv || (v == bv && k < bk); }
 
 // reduce the per-tile maxima the last inverse pass left behind
-__global__ __launch_bounds__(kBlock) void peak_final_kernel(const OipPeakPartial *__restrict__ partials, int npart,
+constexpr int kPeakBlock = 1024;
+__global__ __launch_bounds__(kPeakBlock) void peak_final_kernel(const OipPeakPartial *__restrict__ partials, int npart,
                                                             long mn, long *__restrict__ key_out)
 {
-    __shared__ float sval[kBlock];
-    __shared__ long skey[kBlock];
+    __shared__ float sval[kPeakBlock];
+    __shared__ long skey[kPeakBlock];
     float bv = -INFINITY;
     long bk = mn;
-    for (int i = threadIdx.x; i < npart; i += kBlock)
+    for (int i = threadIdx.x; i < npart; i += kPeakBlock)
         if (pk_better(partials[i].val, partials[i].key, bv, bk)) { bv = partials[i].val; bk = partials[i].key; }
     sval[threadIdx.x] = bv;
     skey[threadIdx.x] = bk;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    for (int s = kPeakBlock / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s && pk_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
             sval[threadIdx.x] = sval[threadIdx.x + s];
             skey[threadIdx.x] = skey[threadIdx.x + s];
@@ -454,20 +549,53 @@ int launch_xpower(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2
     return OIP_OK;
 }
 
+// cross-power + inverse row pass in one kernel when the shape allows; *fused tells the caller
+// that the row passes of the inverse are done
+int launch_xpower_fused(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2dPlan *pl, bool *fused)
+{
+    *fused = false;
+    static const char *env = getenv("OIP_NO_FUSED_XPOWER");              // experiment knob
+    if (env || pl->xf.size() != 1) return launch_xpower(ctx, out, job, pl);
+    for (const FusedRow &k : kFusedRow)
+        if (k.F == pl->N) {
+            const float2 *twF;
+            int rc = oip_fft_table(ctx, k.F, &twF);
+            if (rc) return rc;
+            FusedJob fj;
+            memset(&fj, 0, sizeof fj);
+            fj.ncorr = job.ncorr;
+            auto slot = [&](const float2 *z) {
+                for (int i = 0; i < fj.narr; ++i) if (fj.z[i] == z) return i;
+                fj.z[fj.narr] = z;
+                return fj.narr++;
+            };
+            fj.ia0 = slot(job.a[0].z); fj.ib0 = slot(job.b[0].z); fj.pa0 = job.a[0].part; fj.pb0 = job.b[0].part;
+            if (job.ncorr > 1) { fj.ia1 = slot(job.a[1].z); fj.ib1 = slot(job.b[1].z); fj.pa1 = job.a[1].part; fj.pb1 = job.b[1].part; }
+            OipProfScope prof(ctx, "xpower_inverse_row_kernel");
+            hipLaunchKernelGGL(k.fn, dim3(pl->M / 2 + 1), dim3(k.threads), 0, ctx->stream, out, fj, pl->M, pl->P,
+                               digits_of(pl->yf, pl->M), twF);
+            OIP_HIP(ctx, hipGetLastError());
+            *fused = true;
+            return OIP_OK;
+        }
+    return launch_xpower(ctx, out, job, pl);
+}
+
 // inverse transform of y whose last pass only leaves per-tile maxima, then for each wanted part:
 // arg-max -> recompute the 5x5 window -> centroid -> result slot
-int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, float2 *y, int nparts, double *d_results)
+int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, float2 *y, int nparts, double *d_results,
+                      bool rows_done)
 {
     OipFftIo io;
     memset(&io, 0, sizeof io);
     io.store_kind = 1;
     io.partials = w.partials;
-    int rc = oip_fft2d_exec(ctx, pl, y, 1, &io);
+    int rc = oip_fft2d_exec(ctx, pl, y, 1, &io, rows_done ? 1 : 0);
     if (rc) return rc;
     for (int part = 0; part < nparts; ++part) {
         {
             OipProfScope prof(ctx, "peak_final_kernel");
-            hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kBlock), 0, ctx->stream, w.partials + (size_t)part * w.npart,
+            hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kPeakBlock), 0, ctx->stream, w.partials + (size_t)part * w.npart,
                                w.npart, (long)pl->M * pl->N, w.keys + part);
         }
         OipFftIo wio;
@@ -497,8 +625,9 @@ int correlate_pair(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSr
     job.ncorr = 1;
     job.a[0] = {w.z[0], 0};
     job.b[0] = {w.z[0], 1};
-    if ((rc = launch_xpower(ctx, w.y[0], job, pl))) return rc;
-    return inverse_and_peaks(ctx, pl, w, w.y[0], 1, d_result);
+    bool fused;
+    if ((rc = launch_xpower_fused(ctx, w.y[0], job, pl, &fused))) return rc;
+    return inverse_and_peaks(ctx, pl, w, w.y[0], 1, d_result, fused);
 }
 
 // base image a against four images b0..b3: 3 forward + 2 inverse complex transforms
@@ -518,10 +647,11 @@ int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w,
     j1.ncorr = 2;
     j1.a[0] = {w.z[0], 0}; j1.b[0] = {w.z[1], 1};
     j1.a[1] = {w.z[0], 0}; j1.b[1] = {w.z[2], 0};
-    if ((rc = launch_xpower(ctx, w.y[0], j0, pl))) return rc;
-    if ((rc = launch_xpower(ctx, w.y[1], j1, pl))) return rc;
-    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results))) return rc;
-    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6);
+    bool f0, f1;
+    if ((rc = launch_xpower_fused(ctx, w.y[0], j0, pl, &f0))) return rc;
+    if ((rc = launch_xpower_fused(ctx, w.y[1], j1, pl, &f1))) return rc;
+    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results, f0))) return rc;
+    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, f1);
 }
 
 int fetch_results(oip_ctx *ctx, int count, double *host_out)

@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--slices", type=int, default=10)
     ap.add_argument("--sections", type=int, default=5)
     ap.add_argument("--ibc-threshold", type=float, default=0.4)
-    ap.add_argument("--workload", choices=["default", "rrc"], default="default",
-                    help="default: the full 4-band path; rrc: BASELINE config 2 (RRC kernel only, 30000x65536)")
+    ap.add_argument("--workload", choices=["default", "rrc", "prestitch"], default="default",
+                    help="default: the full 4-band path; rrc: BASELINE config 2 (RRC kernel only, 30000x65536); "
+                         "prestitch: cross-CCD path (BASELINE config 5 on one GPU): CalcSttParameters + RRC x2 + "
+                         "PreStitch remap + RAW stitch of two CCD segments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -66,6 +68,9 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out
         "resize_cubic_x4_kernel": 4.0 * win + 2.0 * win / 16.0,
         "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
+        "remap_shift_kernel": 4.0 * W * pb,                   # 2 B read + 2 B written per pixel
+        "remap_shift8_kernel": 4.0 * W * pb,
+        "stitch_rows_kernel": 4.0 * 2 * (W - 100) * pb,       # 2 B read + 2 B written per output pixel
     }
     return d
 
@@ -219,7 +224,45 @@ def main():
     threshold = args.ibc_threshold
     info = {}
 
-    if args.workload == "rrc":
+    if args.workload == "prestitch":
+        if world != 1:
+            sys.exit("bench.py --workload prestitch is a single-GPU measurement")
+        OV = 200
+        kb2 = synth.lut(W, 5)
+        d_kb2 = ctx.upload_kb(kb2)
+        del raw_pan
+        pan1, pan2 = synth.ccd_pair(0, pb, W, OV, kb_pan, kb2, device=dev)
+        rrc1, rrc2, prestt = torch.empty_like(pan1), torch.empty_like(pan1), torch.empty_like(pan1)
+        stitched = torch.empty(pb, 2 * (W - OV // 2), dtype=torch.uint16, device=dev)
+        nsec = min(10, pb // 16000)
+
+        def step():
+            # main.cpp:270-286: correlation on the raw files, then RRC of both, then the remap
+            t = ctx.stt_correlate(pan1, pan2, W, pb, 0, pb, nsec, 16000, OV, 0)
+            ok = t[:, 2] >= threshold
+            if not ok.any():
+                raise RuntimeError("No valid delta value found for stitching parameter calculating")
+            dx, dy = float(t[ok, 0].mean()), float(t[ok, 1].mean())
+            info["dx"], info["dy"] = dx, dy
+            ctx.rrc_u16(pan1, rrc1, W, pb, d_kb_pan)
+            ctx.rrc_u16(pan2, rrc2, W, pb, d_kb2)
+            ctx.remap_shift_bicubic_u16(rrc2, prestt, W, pb, dx, dy)
+            ctx.stitch_rows_u16(rrc1, prestt, stitched, W, pb, OV // 2)      # --fold-cols 200 -> 100 (main.cpp:189)
+        pix_per_rank = 2 * W * pb
+        plan = None
+        base_rows, base_cols = 16000, OV
+        M, N = 16000, OV
+        out_local = 0
+        workload = ("prestitch + stitch: 2 CCD segments %dx%d, %d x (16000x%d) phase correlations, RRC x2, constant-shift "
+                    "bicubic remap (30000-row sections), RAW stitch fold %d" % (W, pb, nsec, OV, OV // 2))
+        try:
+            step()
+        except RuntimeError as e:
+            if "No valid delta" not in str(e):
+                raise
+            threshold = 0.05
+            step()
+    elif args.workload == "rrc":
         dst = torch.empty_like(raw_pan)
 
         def step():
@@ -319,7 +362,11 @@ def main():
             g = kernels[rk]["algorithmic_GBs"]
             line["rrc_kernel"] = {"GBs_read_plus_write": g, "frac_of_8TBs": g / HBM_PEAK_GBS,
                                   "GBs_read_only": g / 2, "Mpix_s": g / 4 * 1e3}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "default":
+        if args.workload == "prestitch":
+            line["shift"] = {"dx": info.get("dx"), "dy": info.get("dy"), "truth_px": list(synth.CCD_SHIFT)}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "prestitch":
+            pass        # CPU baseline for this workload: see DESIGN.md (oracle remap is measured in the tests)
+        elif world == 1 and not args.no_cpu_baseline and args.workload == "default":
             line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
         elif world == 1 and not args.no_cpu_baseline:
             import oracle

@@ -15,6 +15,8 @@
 #include "oip_geom.h"
 #include "oip_internal.h"
 
+#include <vector>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -27,8 +29,10 @@ struct RowInfo {
     int pad[2];
 };
 
+constexpr int kMaxBadRows = 4096;
+
 __global__ void shift_rows_kernel(RowInfo *rows, OipShiftGeom g, long out_row0, long out_rows, long src_row0,
-                                  long src_rows)
+                                  long src_rows, int *bad_count, int *bad_rows)
 {
     long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= out_rows) return;
@@ -49,6 +53,10 @@ __global__ void shift_rows_kernel(RowInfo *rows, OipShiftGeom g, long out_row0, 
     ri.flags = flags;
     ri.pad[0] = ri.pad[1] = 0;
     rows[r] = ri;
+    if (flags != 1 && bad_count) {          // window touches the section border (or lies outside): fix-up list
+        int i = atomicAdd(bad_count, 1);
+        if (i < kMaxBadRows) bad_rows[i] = (int)r;
+    }
 }
 
 __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, int row, int W, const int c[4],
@@ -63,14 +71,12 @@ __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, i
     for (int j = 0; j < 4; ++j) out[j] = (xmask & (1u << j)) ? (float)p[c[j]] : 0.f;
 }
 
-__global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__restrict__ src,
-                                                             uint16_t *__restrict__ dst,
-                                                             const RowInfo *__restrict__ rows, int W, long out_rows,
-                                                             double dx, const float *__restrict__ tab1d,
-                                                             int rows_per_block)
+// one output column over a run of output lines (4x4 register window, one new source line per
+// output line): the general path -- any width, any alignment, every border case
+__device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                             const RowInfo *__restrict__ rows, int W, double dx, const float *__restrict__ tab1d,
+                             int x, long r0, long r1)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    if (x >= W) return;
     // stitcher.h:96  mapx = (float)(x + mDeltaX); imgwarp.cpp: sx = cvRound(mapx*32)
     const float mapx = (float)((double)x + dx);
     const int sx = oip_cvround(mapx * 32.0f);
@@ -89,10 +95,6 @@ __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__r
     }
     const bool x_inside = (unsigned)ix < (unsigned)(W - 3 > 0 ? W - 3 : 0);
     const bool x_out = (ix >= W) || (ix + 4 <= 0);
-
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > out_rows) r1 = out_rows;
 
     float v[4][4];
     int cur[4] = {-2, -2, -2, -2};
@@ -132,6 +134,173 @@ __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__r
         }
         dst[r * (long)W + x] = (uint16_t)oip_sat_u16(sum);
     }
+}
+
+
+__global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__restrict__ src,
+                                                             uint16_t *__restrict__ dst,
+                                                             const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                             double dx, const float *__restrict__ tab1d,
+                                                             int rows_per_block)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= W) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    remap_column(src, dst, rows, W, dx, tab1d, x, r0, r1);
+}
+
+// ---- v2: 8 output pixels per lane ------------------------------------------------------------------
+// A lane owns output columns x0..x0+7 (one aligned 16-byte store per line).  For a constant
+// shift its 8 columns read source columns ix0 .. ix0+10: 11 consecutive u16 = 6 dwords from a
+// 4-byte aligned address, one such load per NEW source line (the four tap lines live in a
+// rotating register window; the loop is unrolled by 4 so the rotation is static).  When all 8
+// columns share the x phase -- the normal case, the phase only changes where the f32 rounding
+// of x+dx crosses a binade -- the sixteen 2-D weights wy*wx are shared by the 8 pixels and are
+// rebuilt only when the line's y phase changes.  Column groups that are irregular (phase change
+// inside the 8, image borders) and lines whose window touches a section border are NOT written
+// here: two small fix-up launches of the general per-column code handle them, which keeps this
+// kernel free of calls and within 128 VGPRs.  Arithmetic order per pixel is oip_bicubic_interior.
+__host__ __device__ inline bool shift_group_regular(int x0, int W, double dx, int *ix0_out, int *fx0_out)
+{
+    int ix0 = 0, fx0 = 0;
+    bool regular = true;
+    for (int j = 0; j < 8; ++j) {
+        const float mapx = (float)((double)(x0 + j) + dx);
+        const int sx = (int)__builtin_rintf(mapx * 32.0f);
+        int ix = sx >> 5;
+        ix = (ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix)) - 1;
+        const int fx = sx & 31;
+        if (j == 0) { ix0 = ix; fx0 = fx; }
+        else regular = regular && ix == ix0 + j && fx == fx0;
+    }
+    *ix0_out = ix0;
+    *fx0_out = fx0;
+    return regular && ix0 >= 0 && ix0 + 10 < W;      // every tap of every pixel inside the image in x
+}
+
+__device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
+                                                float g[11])
+{
+    // c0: source column of tap 0 of pixel 0 (>= 0).  6 dwords from the dword holding it.
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
+    const long e0 = (long)row * W + c0;           // W even: parity of e0 == parity of c0
+    const long d0 = e0 >> 1;
+    const long dmax = (nelem - 1) >> 1;
+    uint32_t w[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        long di = d0 + i;
+        w[i] = p32[di > dmax ? dmax : di];
+    }
+    if (c0 & 1) {
+#pragma unroll
+        for (int q = 0; q < 11; ++q) g[q] = ((q + 1) & 1) ? (float)(w[(q + 1) >> 1] >> 16) : (float)(w[(q + 1) >> 1] & 0xffffu);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 11; ++q) g[q] = (q & 1) ? (float)(w[q >> 1] >> 16) : (float)(w[q >> 1] & 0xffffu);
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                 const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                                 long src_elems, double dx, const float *__restrict__ tab1d,
+                                                                 int rows_per_block)
+{
+    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (x0 >= W) return;
+    int c0, fx0;
+    if (!shift_group_regular(x0, W, dx, &c0, &fx0)) return;        // fix-up launch A
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    float wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
+
+    float win[4][11];                             // tap line t at unrolled step k lives in win[(k+t)&3]
+    float w2d[16];
+    int cur1 = -2, cur2 = -2, cur3 = -2;
+    int cur_fy = -1;
+    for (long rb = r0; rb < r1; rb += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long r = rb + k;
+            if (r >= r1) break;
+            const RowInfo ri = rows[r];
+            if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B
+            const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
+            if (slide) {
+                load_src_line11(src, ri.src[3], W, c0, src_elems, win[(k + 3) & 3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) load_src_line11(src, ri.src[t], W, c0, src_elems, win[(k + t) & 3]);
+            }
+            cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+            if (ri.fy != cur_fy) {
+                cur_fy = ri.fy;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const float wy = tab1d[cur_fy * 4 + ky];
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
+                }
+            }
+            unsigned out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float *L = win[(k + t) & 3];
+                    float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
+                    rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
+                    rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
+                    sum = t == 0 ? rr : __fadd_rn(sum, rr);
+                }
+                out[j] = oip_sat_u16(sum);
+            }
+            uint4 o;
+            o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+            o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+            *reinterpret_cast<uint4 *>(dst + r * (long)W + x0) = o;
+        }
+    }
+}
+
+// fix-up A: irregular 8-column groups, all lines.  blockIdx.x = index into `groups`; the 256
+// lanes are 8 columns x 32 line sub-ranges.
+__global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                                double dx, const float *__restrict__ tab1d,
+                                                                const int *__restrict__ groups, int rows_per_block)
+{
+    const int x = groups[blockIdx.x] * 8 + (threadIdx.x & 7);
+    if (x >= W) return;
+    const int sub = threadIdx.x >> 3;
+    const long per = (rows_per_block + 31) / 32;
+    long r0 = (long)blockIdx.y * rows_per_block + sub * per;
+    long r1 = r0 + per;
+    const long rend = (long)(blockIdx.y + 1) * rows_per_block;
+    if (r1 > rend) r1 = rend;
+    if (r1 > out_rows) r1 = out_rows;
+    if (r0 < r1) remap_column(src, dst, rows, W, dx, tab1d, x, r0, r1);
+}
+
+// fix-up B: lines whose window touches a section border, all columns
+__global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                const RowInfo *__restrict__ rows, int W, double dx,
+                                                                const float *__restrict__ tab1d,
+                                                                const int *__restrict__ bad_count,
+                                                                const int *__restrict__ bad_rows)
+{
+    int n = *bad_count;
+    if (n > kMaxBadRows) n = kMaxBadRows;
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    if ((int)blockIdx.y >= n || x >= W) return;
+    const long r = bad_rows[blockIdx.y];
+    remap_column(src, dst, rows, W, dx, tab1d, x, r, r + 1);
 }
 
 }  // namespace
@@ -212,17 +381,65 @@ extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, 
                             "oip_remap_shift_bicubic_u16: source window [%ld,%ld) lacks halo lines, need [%ld,%ld)",
                             src_row0, src_row0 + src_rows, first, last);
     }
+    const bool v8 = W % 8 == 0 && (((uintptr_t)d_dst) & 15) == 0 && (((uintptr_t)d_src) & 3) == 0 && src_rows * (long)W >= 16;
+    // irregular 8-column groups (host arithmetic identical to the kernel's)
+    std::vector<int> bad_groups;
+    if (v8)
+        for (int gidx = 0; gidx < W / 8; ++gidx) {
+            int a0, f0;
+            if (!shift_group_regular(gidx * 8, W, dx, &a0, &f0)) bad_groups.push_back(gidx);
+        }
+    const size_t rows_bytes = ((size_t)out_rows * sizeof(RowInfo) + 255) / 256 * 256;
+    const size_t list_bytes = 256 + sizeof(int) * (size_t)kMaxBadRows + sizeof(int) * (bad_groups.size() + 64);
     void *ws = nullptr;
-    int rc = oip_workspace(ctx, (size_t)out_rows * sizeof(RowInfo), &ws);
+    int rc = oip_workspace(ctx, rows_bytes + list_bytes, &ws);
     if (rc) return rc;
     RowInfo *rows = reinterpret_cast<RowInfo *>(ws);
+    int *d_bad_count = reinterpret_cast<int *>((char *)ws + rows_bytes);
+    int *d_bad_rows = d_bad_count + 64;
+    int *d_bad_groups = d_bad_rows + kMaxBadRows;
+    if (v8) {
+        OIP_HIP(ctx, hipMemsetAsync(d_bad_count, 0, sizeof(int), ctx->stream));
+        if (!bad_groups.empty())
+            OIP_HIP(ctx, hipMemcpyAsync(d_bad_groups, bad_groups.data(), sizeof(int) * bad_groups.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     {
         OipProfScope prof(ctx, "shift_rows_kernel");
         int blocks = (int)((out_rows + 255) / 256);
         hipLaunchKernelGGL(shift_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, rows, g, out_row0, out_rows,
-                           src_row0, src_rows);
+                           src_row0, src_rows, v8 ? d_bad_count : (int *)nullptr, d_bad_rows);
     }
-    {
+    if (v8 && (long)g.nsec * 8 + g.ucut + g.bcut + 16 > kMaxBadRows)
+        return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_bicubic_u16: too many section-border lines");
+    if (v8) {
+        int gx = (W / 8 + kBlock - 1) / kBlock;
+        long want = (long)ctx->cu_count * 16 / gx;
+        if (want < 1) want = 1;
+        long rpb = (out_rows + want - 1) / want;
+        if (rpb < 32) rpb = 32;
+        rpb = (rpb + 3) / 4 * 4;
+        long gy = (out_rows + rpb - 1) / rpb;
+        if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
+        {
+            OipProfScope prof(ctx, "remap_shift8_kernel");
+            hipLaunchKernelGGL(remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, rows, W,
+                               out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
+        }
+        if (!bad_groups.empty()) {
+            OipProfScope prof(ctx, "remap_fix_cols_kernel");
+            long rpb2 = 2048;
+            long gy2 = (out_rows + rpb2 - 1) / rpb2;
+            if (gy2 > 65535) { gy2 = 65535; rpb2 = (out_rows + gy2 - 1) / gy2; gy2 = (out_rows + rpb2 - 1) / rpb2; }
+            hipLaunchKernelGGL(remap_fix_cols_kernel, dim3((unsigned)bad_groups.size(), (unsigned)gy2), dim3(kBlock), 0,
+                               ctx->stream, d_src, d_dst, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2);
+        }
+        {
+            OipProfScope prof(ctx, "remap_fix_rows_kernel");
+            const long nb = (long)g.nsec * 8 + g.ucut + g.bcut + 16;      // upper bound on listed lines
+            hipLaunchKernelGGL(remap_fix_rows_kernel, dim3((W + kBlock - 1) / kBlock, (unsigned)nb), dim3(kBlock), 0, ctx->stream,
+                               d_src, d_dst, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows);
+        }
+    } else {
         OipProfScope prof(ctx, "remap_shift_kernel");
         int gx = (W + kBlock - 1) / kBlock;
         long want = (long)ctx->cu_count * 16 / gx;

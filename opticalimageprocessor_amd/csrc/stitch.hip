@@ -39,39 +39,50 @@ __device__ __forceinline__ uint4 load8_u16(const uint16_t *__restrict__ p, long 
     return o;
 }
 
-// requires: out base 16-byte aligned and (2*half) % 8 == 0 so every output line starts on a
-// 16-byte boundary; left/right bases 4-byte aligned.
+// Flat over the OUTPUT raster: lane handles 16-byte chunk f of the output (always a full, aligned
+// 16-byte store; a wave writes one aligned KiB whatever the line pitch -- 2*(W-fold) pixels is
+// rarely a multiple of 64), finds its line / column by one integer division and gathers the 8
+// source pixels from the left or the right strip.  4 chunks in flight per lane.
+// requires: out base 16-byte aligned, (2*half) % 8 == 0, left/right bases 4-byte aligned.
 __global__ __launch_bounds__(kBlock) void stitch_rows_kernel(const uint16_t *__restrict__ left,
                                                              const uint16_t *__restrict__ right,
-                                                             uint16_t *__restrict__ out, int W, long L, int fold,
-                                                             long rows_per_block)
+                                                             uint16_t *__restrict__ out, int W, long L, int fold)
 {
     const int half = W - fold;
-    const int ow = 2 * half;
-    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;   // first output pixel of this lane
-    if (x0 >= ow) return;
+    const int cpr = (2 * half) / 8;               // chunks per output line
+    const long nchunks = (long)cpr * L;
     const long n_elems = (long)W * L;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > L) r1 = L;
-    for (long r = r0; r < r1; ++r) {
-        uint4 v;
-        if (x0 + 8 <= half) {
-            v = load8_u16(left, r * W + x0, n_elems);
-        } else if (x0 >= half) {
-            v = load8_u16(right, r * W + fold + (x0 - half), n_elems);
-        } else {
-            // the 16-byte chunk straddles the seam: element-wise
-            unsigned short t[8];
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * kBlock;
+    for (long f0 = (long)blockIdx.x * kBlock + threadIdx.x; f0 < nchunks; f0 += stride * U) {
+        uint4 v[U];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int x = x0 + i;
-                t[i] = x < half ? left[r * W + x] : right[r * W + fold + (x - half)];
+        for (int u = 0; u < U; ++u) {
+            const long f = f0 + u * stride;
+            if (f >= nchunks) break;
+            const long r = f / cpr;
+            const int x0 = (int)(f - r * cpr) * 8;
+            if (x0 + 8 <= half) {
+                v[u] = load8_u16(left, r * W + x0, n_elems);
+            } else if (x0 >= half) {
+                v[u] = load8_u16(right, r * W + fold + (x0 - half), n_elems);
+            } else {
+                unsigned short t[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int x = x0 + i;
+                    t[i] = x < half ? left[r * W + x] : right[r * W + fold + (x - half)];
+                }
+                v[u].x = t[0] | ((unsigned)t[1] << 16); v[u].y = t[2] | ((unsigned)t[3] << 16);
+                v[u].z = t[4] | ((unsigned)t[5] << 16); v[u].w = t[6] | ((unsigned)t[7] << 16);
             }
-            v.x = t[0] | ((unsigned)t[1] << 16); v.y = t[2] | ((unsigned)t[3] << 16);
-            v.z = t[4] | ((unsigned)t[5] << 16); v.w = t[6] | ((unsigned)t[7] << 16);
         }
-        *reinterpret_cast<uint4 *>(out + r * (long)ow + x0) = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long f = f0 + u * stride;
+            if (f >= nchunks) break;
+            reinterpret_cast<uint4 *>(out)[f] = v[u];
+        }
     }
 }
 
@@ -106,15 +117,13 @@ extern "C" int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const u
     const bool fast = (ow % 8 == 0) && (((uintptr_t)d_out & 15) == 0) && (((uintptr_t)d_left & 3) == 0) &&
                       (((uintptr_t)d_right & 3) == 0) && ((long)W * L >= 16 && ((long)W * L) % 2 == 0);
     if (fast) {
-        int gx = (ow / 8 + kBlock - 1) / kBlock;
-        long want = (long)ctx->cu_count * 16 / gx;
-        if (want < 1) want = 1;
-        long rpb = (L + want - 1) / want;
-        if (rpb < 16) rpb = 16;
-        long gy = (L + rpb - 1) / rpb;
-        if (gy > 65535) { gy = 65535; rpb = (L + gy - 1) / gy; gy = (L + rpb - 1) / rpb; }
-        hipLaunchKernelGGL(stitch_rows_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_left, d_right,
-                           d_out, W, L, fold, rpb);
+        const long nchunks = (long)(ow / 8) * L;
+        long blocks = (nchunks + (long)kBlock * 4 - 1) / ((long)kBlock * 4);
+        const long cap = (long)ctx->cu_count * 128;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(stitch_rows_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_left, d_right,
+                           d_out, W, L, fold);
     } else {
         long n = (long)ow * L;
         long blocks = (n + kBlock - 1) / kBlock;

@@ -49,11 +49,12 @@ __global__ void align_rows_kernel(AlignRow *rows, OipAlignGeom g, long out_row0,
     rows[r] = a;
 }
 
-// One lane = one output column, walking down a run of output lines.  For a fixed column the
-// first tap line iy advances by exactly one per output line except where the f32 rounding of
-// mapY flips (rare) or a section seam restarts the section-relative line, so each band keeps
-// its 4x4 source window in registers and normally loads only the newest source line (4 taps
-// per band and pixel instead of 16).
+// One lane = one (output column, band): lane 4p+b of a wave handles pixel p, band b, so a wave
+// writes 128 contiguous bytes of the interleaved 16UC4 line and keeps a single 4x4 source
+// window per lane (~50 VGPRs instead of ~190 for four bands per lane: 8 waves/SIMD instead of 2).
+// For a fixed column the first tap line iy advances by exactly one per output line except where
+// the f32 rounding of mapY flips (rare) or a section seam restarts the section-relative line,
+// so the window normally loads only the newest source line (4 taps per pixel instead of 16).
 __device__ __forceinline__ void align_load_row(const uint16_t *__restrict__ pl, long lr, bool yok, int Wb, int cix,
                                                unsigned xmask, float out[4])
 {
@@ -71,101 +72,91 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
                                                            AlignCoef co, const float *__restrict__ tab1d,
                                                            int rows_per_block)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int x = gid >> 2, b = gid & 3;
     if (x >= Wb) return;
     const int xx = x * 4;
     const double dxx = (double)xx;
-    // per band: column-only part of the maps (preproc.h:447-448)
-    int ix[4];
-    float wx[4][4];
-    unsigned xmask[4];
-    double coly[4];
+    // column-only part of the maps (preproc.h:447-448), fp64, left to right
+    // the lane's band picks its coefficients from the kernel arguments (selects, no memory)
+    const double cx0 = b == 0 ? co.cx[0][0] : (b == 1 ? co.cx[1][0] : (b == 2 ? co.cx[2][0] : co.cx[3][0]));
+    const double cx1 = b == 0 ? co.cx[0][1] : (b == 1 ? co.cx[1][1] : (b == 2 ? co.cx[2][1] : co.cx[3][1]));
+    const double cy0 = b == 0 ? co.cy[0][0] : (b == 1 ? co.cy[1][0] : (b == 2 ? co.cy[2][0] : co.cy[3][0]));
+    const double cy1 = b == 0 ? co.cy[0][1] : (b == 1 ? co.cy[1][1] : (b == 2 ? co.cy[2][1] : co.cy[3][1]));
+    const double cy2 = b == 0 ? co.cy[0][2] : (b == 1 ? co.cy[1][2] : (b == 2 ? co.cy[2][2] : co.cy[3][2]));
+    const double mx = __dadd_rn(__dadd_rn(__dmul_rn(cx1, dxx), cx0), dxx) * 0.25;
+    const int sx = oip_cvround((float)mx * 32.0f);
+    const int cix = oip_sat_short(sx >> 5) - 1;
+    const int fx = sx & 31;
+    float wx[4];
+    unsigned xmask = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        double mx = __dadd_rn(__dadd_rn(__dmul_rn(co.cx[b][1], dxx), co.cx[b][0]), dxx) * 0.25;
-        int sx = oip_cvround((float)mx * 32.0f);
-        ix[b] = oip_sat_short(sx >> 5) - 1;
-        const int fx = sx & 31;
-        xmask[b] = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wx[b][j] = tab1d[fx * 4 + j];
-            int cj = ix[b] + j;
-            if (cj >= 0 && cj < Wb) xmask[b] |= 1u << j;
-        }
-        coly[b] = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(co.cy[b][2], dxx), dxx), __dmul_rn(co.cy[b][1], dxx)), co.cy[b][0]);
+    for (int j = 0; j < 4; ++j) {
+        wx[j] = tab1d[fx * 4 + j];
+        const int cj = cix + j;
+        if (cj >= 0 && cj < Wb) xmask |= 1u << j;
     }
-    float win[4][4][4];            // [band][tap row][tap col]
-    int cur_iy[4] = {INT_MIN, INT_MIN, INT_MIN, INT_MIN};
-    int cur_base = INT_MIN;
+    const double coly = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(cy2, dxx), dxx), __dmul_rn(cy1, dxx)), cy0);
+    const uint16_t *pl = planes + (size_t)b * plane_stride;
+    const bool x_out = cix >= Wb || cix + 4 <= 0;
+    const bool x_in = (unsigned)cix < (unsigned)(Wb - 3 > 0 ? Wb - 3 : 0);
+
+    float win[4][4];               // [tap row][tap col]
+    int cur_iy = INT_MIN, cur_base = INT_MIN;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
     for (long r = r0; r < r1; ++r) {
         const AlignRow a = rows[r];
-        unsigned short res[4] = {0, 0, 0, 0};
+        unsigned res = 0;
         if (a.valid) {
-            if (a.base != cur_base) {           // new section: every window is stale
-                cur_base = a.base;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) cur_iy[b] = INT_MIN;
-            }
+            if (a.base != cur_base) { cur_base = a.base; cur_iy = INT_MIN; }       // new section: window stale
             const double yy = (double)((long)a.yrel * 4);
+            const double my = __dadd_rn(coly, yy) * 0.25;
+            const int sy = oip_cvround((float)my * 32.0f);
+            const int iy = oip_sat_short(sy >> 5) - 1;
+            const int fy = sy & 31;
+            if (iy == cur_iy + 1 && cur_iy != INT_MIN) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                double my = __dadd_rn(coly[b], yy) * 0.25;
-                int sy = oip_cvround((float)my * 32.0f);
-                int iy = oip_sat_short(sy >> 5) - 1;
-                int fy = sy & 31;
-                const int cix = ix[b];
-                const uint16_t *pl = planes + (size_t)b * plane_stride;
-                if (iy == cur_iy[b] + 1 && cur_iy[b] != INT_MIN) {
+                for (int t = 0; t < 3; ++t) {
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int j = 0; j < 4; ++j) win[t][j] = win[t + 1][j];
+                }
+                const int rr = iy + 3;
+                const long lr = (long)a.base + rr;
+                align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[3]);
+            } else if (iy != cur_iy) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) win[b][t][j] = win[b][t + 1][j];
-                    }
-                    const int rr = iy + 3;
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = iy + t;
                     const long lr = (long)a.base + rr;
-                    align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask[b], win[b][3]);
-                } else if (iy != cur_iy[b]) {
+                    align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[t]);
+                }
+            }
+            cur_iy = iy;
+            float sum;
+            if (x_out || iy >= a.lines || iy + 4 <= 0) {
+                sum = 0.f;
+            } else {
+                float wy[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
+                if (x_in && (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0)) {
+                    sum = oip_bicubic_interior(win, wx, wy);
+                } else {
+                    unsigned ymask = 0;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int rr = iy + t;
                         const long lr = (long)a.base + rr;
-                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask[b], win[b][t]);
+                        if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
                     }
+                    sum = oip_bicubic_border(win, wx, wy, xmask, ymask);
                 }
-                cur_iy[b] = iy;
-                float sum;
-                if (cix >= Wb || cix + 4 <= 0 || iy >= a.lines || iy + 4 <= 0) {
-                    sum = 0.f;
-                } else {
-                    float wy[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
-                    const bool inside = (unsigned)cix < (unsigned)(Wb - 3 > 0 ? Wb - 3 : 0) &&
-                                        (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0);
-                    if (inside) {
-                        sum = oip_bicubic_interior(win[b], wx[b], wy);
-                    } else {
-                        unsigned ymask = 0;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int rr = iy + t;
-                            const long lr = (long)a.base + rr;
-                            if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
-                        }
-                        sum = oip_bicubic_border(win[b], wx[b], wy, xmask[b], ymask);
-                    }
-                }
-                res[b] = (unsigned short)oip_sat_u16(sum);
             }
+            res = oip_sat_u16(sum);
         }
-        uint2 o;
-        o.x = (unsigned)res[0] | ((unsigned)res[1] << 16);
-        o.y = (unsigned)res[2] | ((unsigned)res[3] << 16);
-        *reinterpret_cast<uint2 *>(dst + ((size_t)r * Wb + x) * 4) = o;
+        dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
     }
 }
 
@@ -283,7 +274,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
                             src_row0, src_row0 + src_rows, first, last);
     }
     void *ws = nullptr;
-    int rc = oip_workspace(ctx, (size_t)out_rows * sizeof(AlignRow), &ws);
+    int rc = oip_workspace(ctx, (size_t)out_rows * sizeof(AlignRow) + 512, &ws);
     if (rc) return rc;
     AlignRow *rows = reinterpret_cast<AlignRow *>(ws);
     {
@@ -296,7 +287,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
     memcpy(co.cy, cy, sizeof co.cy);
     {
         OipProfScope prof(ctx, "align_mss_kernel");
-        int gx = (Wb + kBlock - 1) / kBlock;
+        int gx = (Wb * 4 + kBlock - 1) / kBlock;
         long want = (long)ctx->cu_count * 16 / gx;
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;

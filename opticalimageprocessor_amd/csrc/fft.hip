@@ -682,7 +682,8 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     long blocks = blocks_override > 0 ? blocks_override : pass_blocks(p);
     if (blocks <= 0 || blocks > 0x7fffffffL) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass grid too large");
     char pname[48];
-    snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d" : "fft_pass_kernel_F%d"), p.F);
+    snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d%s" : "fft_pass_kernel_F%d%s"), p.F,
+             io.load_kind == 1 ? "_pack" : (io.store_kind == 1 ? "_peak" : ""));
     OipProfScope prof(ctx, pname);
     if (p.fast >= 0) {
         p.ntiles = blocks;

@@ -145,23 +145,36 @@ __device__ void store_peak(const float2 *buf, int Vp, const OipFftPass &p, const
         if (peak_better(z.x, key, bv[0], bk[0])) { bv[0] = z.x; bk[0] = key; }
         if (peak_better(z.y, key, bv[1], bk[1])) { bv[1] = z.y; bk[1] = key; }
     }
+    // wave-level arg-max with shuffles, then one LDS hand-off between the waves of the block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kFftBlock >> 6;
+#pragma unroll
     for (int part = 0; part < 2; ++part) {
-        __syncthreads();
-        sval[threadIdx.x] = bv[part];
-        skey[threadIdx.x] = bk[part];
-        __syncthreads();
-        for (int s = kFftBlock / 2; s > 0; s >>= 1) {
-            if (threadIdx.x < s && peak_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
-                sval[threadIdx.x] = sval[threadIdx.x + s];
-                skey[threadIdx.x] = skey[threadIdx.x + s];
-            }
-            __syncthreads();
+        float v = bv[part];
+        long k = bk[part];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(v, off, 64);
+            const long ok = __shfl_xor(k, off, 64);
+            if (peak_better(ov, ok, v, k)) { v = ov; k = ok; }
         }
-        if (threadIdx.x == 0) {
-            OipPeakPartial &o = io.partials[(size_t)part * ntiles + tile];
-            o.val = sval[0];
-            o.key = skey[0];
-        }
+        bv[part] = v;
+        bk[part] = k;
+    }
+    __syncthreads();                          // every lane is done reading the tile: scratch may overlay it
+    if (lane == 0) {
+        sval[wave * 2] = bv[0]; sval[wave * 2 + 1] = bv[1];
+        skey[wave * 2] = bk[0]; skey[wave * 2 + 1] = bk[1];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int part = threadIdx.x;
+        float v = sval[part];
+        long k = skey[part];
+        for (int w = 1; w < nwaves; ++w)
+            if (peak_better(sval[w * 2 + part], skey[w * 2 + part], v, k)) { v = sval[w * 2 + part]; k = skey[w * 2 + part]; }
+        OipPeakPartial &o = io.partials[(size_t)part * ntiles + tile];
+        o.val = v;
+        o.key = k;
     }
 }
 
@@ -438,7 +451,7 @@ const FastKernel kFast[] = {
     // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors): 16 lanes = 128-byte
     // segments, 17 KiB of LDS per workgroup -> 8 workgroups per CU (measured faster than 32 lanes)
     {125, 4, 0, 256, false, fft_pass_ct_kernel<125, 4, 0, 256, false, 5, 5, 5>},
-    {128, 4, 0, 256, true, fft_pass_ct_kernel<128, 4, 0, 256, true, 8, 4, 4>},
+    {128, 4, 0, 256, false, fft_pass_ct_kernel<128, 4, 0, 256, false, 8, 4, 4>},
     {125, 5, 0, 256, false, fft_pass_ct_kernel<125, 5, 0, 256, false, 5, 5, 5>},
     {128, 5, 0, 256, false, fft_pass_ct_kernel<128, 5, 0, 256, false, 8, 4, 4>},
     {100, 4, 0, 256, false, fft_pass_ct_kernel<100, 4, 0, 256, false, 4, 5, 5>},
@@ -593,7 +606,11 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
     const int P = (N + 15) / 16 * 16;
     pl.P = P;
     if (!split_axis(N, 256, 4096, &pl.xf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor row length %d", N);
-    if (M == 16000) pl.yf = {125, 128};
+    // 16000 = 128 * 125 with the 128-point pass first: its points are 125 rows apart, an odd multiple of
+    // 512 B for the padded pitches, so a tile spreads over the HBM channels (125 * 128 would put all
+    // points of a tile 47 * 2^16 B apart -- same channel -- and ran at half the bandwidth)
+    static const char *envo = getenv("OIP_FFT_Y_ORDER");
+    if (M == 16000) pl.yf = (envo && atoi(envo) == 125) ? std::vector<int>{125, 128} : std::vector<int>{128, 125};
     else if (!split_axis(M, 256, 256, &pl.yf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor column length %d", M);
     // column (y) passes first: always mode A with lanes = x
     {

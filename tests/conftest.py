@@ -29,5 +29,11 @@ def ctx():
     import opticalimageprocessor_amd as oip
     assert torch.cuda.is_available(), "GPU test selected but no GPU visible"
     c = oip.Context(0)
+    # one stream for torch and the library: tensors produced by torch kernels (randint, copies)
+    # are ordered before the library's kernels that read them, and vice versa
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    c.set_stream(stream)
     yield c
+    torch.cuda.synchronize()
     c.close()

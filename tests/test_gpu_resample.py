@@ -353,3 +353,64 @@ def test_align_row_shards_equal_whole(ctx, oracle_mod, nshards):
         ctx.sync()
         got[o0:o1] = _u16(part)
     assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------- BASELINE sizes: size-independent properties
+def _rand_u16(shape, seed):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randint(-32768, 32768, shape, device="cuda", generator=g, dtype=torch.int32).to(torch.int16).view(torch.uint16)
+
+
+def test_full_size_remap_integer_shift_is_copy(ctx):
+    """30000 x 65536 (BASELINE config 2/3 width and length): an integer shift has phase 0, weights
+    [0,1,0,0], so every section body must be an exact shifted copy; the lines next to the 30000-row
+    section seams are exact too (the zeroed taps carry weight 0)."""
+    import torch
+    W, L, sx, sy = 30000, 65536, 7, 3
+    src = _rand_u16((L, W), 11)
+    dst = torch.empty_like(src)
+    ctx.remap_shift_bicubic_u16(src, dst, W, L, float(sx), float(sy))
+    ctx.sync()
+    bcut = sy + 1
+    body = L - bcut - sy           # lines whose source line exists
+    assert torch.equal(dst[:body, :W - sx].view(torch.int16), src[sy:sy + body, sx:].view(torch.int16))
+    assert int(dst[:body, W - sx:].view(torch.int16).count_nonzero()) == 0
+
+
+def test_full_size_align_zero_coefficients_interleaves_bands(ctx):
+    """MSS of BASELINE config 3 (4 x 7500 x 16384): zero polynomials map every pixel onto itself,
+    so the 16UC4 output is the band interleave of lines [overlap, L) (leading overlap dropped)."""
+    import torch
+    Wb, Lm = 7500, 16384
+    planes = _rand_u16((4, Lm, Wb), 12)
+    out = torch.empty(Lm - 520, Wb, 4, dtype=torch.uint16, device="cuda")
+    n = ctx.align_mss_bicubic_u16x4(planes, Lm * Wb, out, Wb, Lm, np.zeros((4, 2)), np.zeros((4, 3)))
+    ctx.sync()
+    assert n == Lm - 520
+    want = planes[:, 520:].permute(1, 2, 0).contiguous()
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+def test_full_size_stitch_columns(ctx):
+    """two 30000 x 65536 strips, fold 100: left part == left[:, :W-f], right part == right[:, f:]"""
+    import torch
+    W, L, f = 30000, 65536, 100
+    left, right = _rand_u16((L, W), 13), _rand_u16((L, W), 14)
+    out = torch.empty(L, 2 * (W - f), dtype=torch.uint16, device="cuda")
+    ctx.stitch_rows_u16(left, right, out, W, L, f)
+    ctx.sync()
+    assert torch.equal(out[:, :W - f].view(torch.int16), left[:, :W - f].view(torch.int16))
+    assert torch.equal(out[:, W - f:].view(torch.int16), right[:, f:].view(torch.int16))
+
+
+def test_full_size_mss_split_round_trip(ctx):
+    """BIL 30000 x 16384 -> 4 planar bands without RRC: re-interleaving gives the input back"""
+    import torch
+    W, L = 30000, 16384
+    bil = _rand_u16((L, W), 15)
+    planes = torch.empty(4, L, W // 4, dtype=torch.uint16, device="cuda")
+    ctx.mss_split_rrc_u16(bil, planes, L * (W // 4), W, L, None)
+    ctx.sync()
+    back = planes.permute(1, 0, 2).reshape(L, W)
+    assert torch.equal(back.view(torch.int16), bil.view(torch.int16))

@@ -53,6 +53,7 @@ struct Tile {
     int o1;         // mode 0: outer index 1
     int o2;         // mode 0: outer index 2
     long vec0;      // mode 1: first vector
+    long gtile;     // tile index over the whole pass (peak partial slot), independent of panelling
 };
 
 __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
@@ -60,16 +61,19 @@ __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
     Tile t;
     const int V = 1 << p.vshift;
     if (p.mode == 0) {
-        const int lt = (int)(bid % p.lane_tiles);
-        const long rest = bid / p.lane_tiles;
+        const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;          // lane-tile window of this launch (column panel)
+        const int lt = p.lt0 + (int)(bid % ltn);
+        const long rest = bid / ltn;
         t.o1 = (int)(rest % p.O1);
         t.o2 = (int)(rest / p.O1);
+        t.gtile = rest * p.lane_tiles + lt;
         t.lane0 = lt << p.vshift;
         t.nv = p.lanes - t.lane0 < V ? (int)(p.lanes - t.lane0) : V;
         t.base = (long)t.o2 * p.o2_stride + (long)t.o1 * p.o1_stride + t.lane0;
         t.vec0 = 0;
     } else {
         t.vec0 = bid << p.vshift;
+        t.gtile = bid;
         t.nv = p.lanes - t.vec0 < V ? (int)(p.lanes - t.vec0) : V;
         t.base = 0;                      // mode 1 addresses come from vec_offset()
         t.lane0 = t.o1 = t.o2 = 0;
@@ -197,6 +201,7 @@ __device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo 
     t->nv = p.lanes - t->lane0 < V ? (int)(p.lanes - t->lane0) : V;
     t->base = (long)t->o1 * p.o1_stride + t->lane0;
     t->vec0 = 0;
+    t->gtile = 0;
     return true;
 }
 
@@ -283,7 +288,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         Ns *= r;
     }
 
-    if (io.store_kind == 1) { store_peak(bufA, Vp, p, io, t, sval, skey, blockIdx.x, gridDim.x); return; }
+    if (io.store_kind == 1) { store_peak(bufA, Vp, p, io, t, sval, skey, t.gtile, p.total_tiles); return; }
     if (io.store_kind == 2) {
         if (threadIdx.x == 0) {
             float2 z = bufA[wn0 * Vp + wv0];
@@ -414,8 +419,8 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 
         if (io.store_kind == 1) {
             // the scan of the tile ends (barrier inside store_peak) before the scratch is written
-            store_peak(buf, Vp, p, io, t, reinterpret_cast<float *>(buf + kFftBlock), reinterpret_cast<long *>(buf), tile,
-                       ntiles, NT);
+            store_peak(buf, Vp, p, io, t, reinterpret_cast<float *>(buf + kFftBlock), reinterpret_cast<long *>(buf), t.gtile,
+                       p.total_tiles, NT);
         } else if (io.store_kind == 2) {
             if (threadIdx.x == 0) {
                 float2 z = buf[wn0 * Vp + wv0];
@@ -683,11 +688,16 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
 
 static long pass_blocks(const OipFftPass &p)
 {
-    if (p.mode == 0) return (long)p.lane_tiles * p.O1 * p.O2;
+    if (p.mode == 0) return (long)(p.ltn > 0 ? p.ltn : p.lane_tiles) * p.O1 * p.O2;
     return (p.lanes + (1 << p.vshift) - 1) >> p.vshift;
 }
 
-long oip_fft2d_last_pass_blocks(const OipFft2dPlan *pl) { return pass_blocks(pl->passes[0]); }
+long oip_fft2d_last_pass_blocks(const OipFft2dPlan *pl)
+{
+    OipFftPass p = pl->passes[0];
+    p.ltn = 0;
+    return pass_blocks(p);
+}
 
 static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, const OipFftIo &io, long blocks_override)
 {
@@ -696,6 +706,11 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     int rc = get_table(ctx, p.F, &twF);
     if (rc) return rc;
     if (p.tw_mode) { rc = get_table(ctx, p.T, &twT); if (rc) return rc; }
+    {
+        OipFftPass whole = p;
+        whole.ltn = 0;
+        p.total_tiles = pass_blocks(whole);
+    }
     long blocks = blocks_override > 0 ? blocks_override : pass_blocks(p);
     if (blocks <= 0 || blocks > 0x7fffffffL) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass grid too large");
     char pname[48];
@@ -724,31 +739,60 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
 //                 io->load_kind applies to the first pass
 //   inverse == 1: scrambled spectrum in, natural order out, unnormalised (rows, then columns);
 //                 io->store_kind applies to the last pass
-int oip_fft_table(oip_ctx *ctx, int T, const float2 **out) { return get_table(ctx, T, out); }
-
 int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inverse, const OipFftIo *io, int rows_done)
 {
     // rows_done (inverse only): the row passes were already applied by a fused kernel
     const int np = rows_done ? pl->n_y : (int)pl->passes.size();
     OipFftIo plain;
     memset(&plain, 0, sizeof plain);
+    // Column passes are independent per column, so they can run panel by panel (a fraction of
+    // the columns through all column passes, then the next fraction): the later pass then re-reads
+    // what the earlier one just wrote while it is still in the 256 MiB Infinity Cache.
+    static const char *envp = getenv("OIP_FFT_PANELS");
+    int panels = envp ? atoi(envp) : 1;
+    const int lane_tiles = pl->n_y > 0 ? pl->passes[0].lane_tiles : 1;
+    if (panels < 1) panels = 1;
+    if (panels > lane_tiles) panels = lane_tiles;
+    auto column_passes = [&](bool inv) -> int {
+        for (int pn = 0; pn < panels; ++pn) {
+            const int lt0 = (int)((long)lane_tiles * pn / panels), lt1 = (int)((long)lane_tiles * (pn + 1) / panels);
+            for (int k = 0; k < pl->n_y; ++k) {
+                const int i = inv ? pl->n_y - 1 - k : k;
+                OipFftPass p = pl->passes[i];
+                p.lt0 = lt0;
+                p.ltn = lt1 - lt0;
+                OipFftIo use = plain;
+                if (!inv && i == 0 && io) { use = *io; use.store_kind = 0; }
+                if (inv && i == 0 && io) { use.store_kind = io->store_kind; use.partials = io->partials; }
+                int rc = launch_pass(ctx, data, p, inv ? 1 : 0, use, 0);
+                if (rc) return rc;
+            }
+        }
+        return OIP_OK;
+    };
     if (!inverse) {
-        for (int i = 0; i < np; ++i) {
+        int rc = column_passes(false);
+        if (rc) return rc;
+        for (int i = pl->n_y; i < np; ++i) {
             OipFftIo use = plain;
             if (i == 0 && io) { use = *io; use.store_kind = 0; }
-            int rc = launch_pass(ctx, data, pl->passes[i], 0, use, 0);
+            rc = launch_pass(ctx, data, pl->passes[i], 0, use, 0);
             if (rc) return rc;
         }
     } else {
-        for (int i = np - 1; i >= 0; --i) {
+        for (int i = np - 1; i >= pl->n_y; --i) {
             OipFftIo use = plain;
             if (i == 0 && io) { use.store_kind = io->store_kind; use.partials = io->partials; }
             int rc = launch_pass(ctx, data, pl->passes[i], 1, use, 0);
             if (rc) return rc;
         }
+        int rc = column_passes(true);
+        if (rc) return rc;
     }
     return OIP_OK;
 }
+
+int oip_fft_table(oip_ctx *ctx, int T, const float2 **out) { return get_table(ctx, T, out); }
 
 int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, const OipFftIo *io)
 {

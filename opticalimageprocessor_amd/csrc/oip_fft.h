@@ -53,7 +53,9 @@ struct OipFftPass {
     int M;
     int P;              // row pitch in elements (N rounded up to whole 128-byte lines)
     int inverse;
-    long ntiles;        // tiles of the pass (persistent specialised kernels walk them)
+    long ntiles;        // tiles of this launch (persistent specialised kernels walk them)
+    long total_tiles;   // tiles of the whole pass (peak partial slots)
+    int lt0, ltn;       // lane-tile window of this launch (column panel); ltn == 0: all
     int fast;           // index of a compile-time specialised kernel, -1: generic
 };
 

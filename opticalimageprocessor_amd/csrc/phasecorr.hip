@@ -406,10 +406,10 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Workspace carve-up for one correlation unit
 struct PcWork {
-    float2 *z[3];
+    float2 *z[5];
     float2 *y[2];
     float *fa;          // base window, f32
-    float *fb[4];       // second images, f32 (up-sampled bands)
+    float *fb[8];       // second images, f32 (up-sampled bands; two units' worth)
     float *fsmall;      // MSS window before resize
     OipPeakPartial *partials;   // [2][npart]
     int npart;
@@ -430,10 +430,10 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     int rc = oip_workspace(ctx, total, &ws);
     if (rc) return rc;
     char *p = (char *)ws;
-    for (int i = 0; i < 3; ++i) { w->z[i] = i < nz ? (float2 *)p : nullptr; if (i < nz) p += zbytes; }
+    for (int i = 0; i < 5; ++i) { w->z[i] = i < nz ? (float2 *)p : nullptr; if (i < nz) p += zbytes; }
     for (int i = 0; i < 2; ++i) { w->y[i] = i < ny ? (float2 *)p : nullptr; if (i < ny) p += zbytes; }
     w->fa = (float *)p; p += fbytes;
-    for (int i = 0; i < 4; ++i) { w->fb[i] = i < nfb ? (float *)p : nullptr; if (i < nfb) p += fbytes; }
+    for (int i = 0; i < 8; ++i) { w->fb[i] = i < nfb ? (float *)p : nullptr; if (i < nfb) p += fbytes; }
     w->fsmall = (float *)p; p += sbytes;
     w->partials = (OipPeakPartial *)p; p += pbytes;
     w->keys = (long *)p; p += 256;
@@ -654,6 +654,40 @@ int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w,
     return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, f1);
 }
 
+// Two units (base image + four bands each) at once: the fourth bands of the two units share one
+// complex transform (b3 of unit A in the real slot, b3 of unit B in the imaginary slot), so the
+// pair costs 5 forward transforms instead of 6.  4 x 2 fused cross-power / inverse passes.
+int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc aA, float *const bA[4], RealSrc aB,
+                        float *const bB[4], int rows, int cols, double *d_resA /* 4 x 3 */, double *d_resB)
+{
+    int rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], aA, src_f32(bA[0]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(bA[1]), src_f32(bA[2]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], aB, src_f32(bB[0]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[3], src_f32(bB[1]), src_f32(bB[2]), rows, cols))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[4], src_f32(bA[3]), src_f32(bB[3]), rows, cols))) return rc;
+    for (int unit = 0; unit < 2; ++unit) {
+        float2 *zp = unit ? w.z[2] : w.z[0];          // (pan, b0)
+        float2 *zq = unit ? w.z[3] : w.z[1];          // (b1, b2)
+        XpowerJob j0, j1;
+        memset(&j0, 0, sizeof j0);
+        memset(&j1, 0, sizeof j1);
+        j0.ncorr = 2;
+        j0.a[0] = {zp, 0}; j0.b[0] = {zp, 1};
+        j0.a[1] = {zp, 0}; j0.b[1] = {zq, 0};
+        j1.ncorr = 2;
+        j1.a[0] = {zp, 0}; j1.b[0] = {zq, 1};
+        j1.a[1] = {zp, 0}; j1.b[1] = {w.z[4], unit};
+        double *res = unit ? d_resB : d_resA;
+        bool f0, f1;
+        if ((rc = launch_xpower_fused(ctx, w.y[0], j0, pl, &f0))) return rc;
+        if ((rc = launch_xpower_fused(ctx, w.y[1], j1, pl, &f1))) return rc;
+        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, res, f0))) return rc;
+        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[1], 2, res + 6, f1))) return rc;
+    }
+    return OIP_OK;
+}
+
 int fetch_results(oip_ctx *ctx, int count, double *host_out)
 {
     OIP_HIP(ctx, hipMemcpyAsync(ctx->h_small, ctx->d_small, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
@@ -774,27 +808,44 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, pl, baseRows, baseSliceCols, 0, 3, 2, 4, &w))) return rc;
+    if ((rc = carve(ctx, pl, baseRows, baseSliceCols, 0, 5, 2, 8, &w))) return rc;
     double *d_res = (double *)ctx->d_small;
     const int n = slices * sections;
     std::vector<int> have(n, 0);
+    struct Unit { int u; const uint16_t *pw; long bandRow0; int slice; };
+    std::vector<Unit> units;
     for (int sec = 0; sec < sections; ++sec) {
         const long secRowStart = baseRowGap + (long)sec * (baseRows + baseRowGap);        // preproc.h:257
         const long secBandRowStart = bandRowGap + (long)sec * (bandRows + bandRowGap);    // preproc.h:284
         if (secRowStart < prow0 || secRowStart + baseRows > prow0 + pn) continue;
         if (secBandRowStart < mrow0 || secBandRowStart + bandRows > mrow0 + mn) continue;
         for (int i = 0; i < slices; ++i) {
-            const int u = sec * slices + i;
-            have[u] = 1;
-            // PAN window: read as u16 by the FFT loader; MSS windows: up-sampled x4 straight from u16
-            const uint16_t *pw = d_pan + (size_t)(secRowStart - prow0) * W + (size_t)i * baseSliceCols;
-            for (int b = 0; b < OIP_MSS_BANDS; ++b) {
-                const uint16_t *bw = d_planes + (size_t)b * plane_stride + (size_t)(secBandRowStart - mrow0) * Wb +
-                                     (size_t)i * bandSliceCols;
-                if ((rc = launch_resize<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, w.fb[b], baseSliceCols, baseRows))) return rc;
-            }
-            if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(pw, W), w.fb, baseRows, baseSliceCols, d_res + 12 * u))) return rc;
+            have[sec * slices + i] = 1;
+            units.push_back(Unit{sec * slices + i, d_pan + (size_t)(secRowStart - prow0) * W + (size_t)i * baseSliceCols,
+                                 secBandRowStart - mrow0, i});
         }
+    }
+    // PAN window: read as u16 by the FFT loader; MSS windows: up-sampled x4 straight from u16
+    auto upsample = [&](const Unit &un, float *const fb[4]) -> int {
+        for (int b = 0; b < OIP_MSS_BANDS; ++b) {
+            const uint16_t *bw = d_planes + (size_t)b * plane_stride + (size_t)un.bandRow0 * Wb + (size_t)un.slice * bandSliceCols;
+            int rc2 = launch_resize<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, fb[b], baseSliceCols, baseRows);
+            if (rc2) return rc2;
+        }
+        return OIP_OK;
+    };
+    size_t k = 0;
+    for (; k + 1 < units.size(); k += 2) {
+        const Unit &A = units[k], &B = units[k + 1];
+        if ((rc = upsample(A, w.fb))) return rc;
+        if ((rc = upsample(B, w.fb + 4))) return rc;
+        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), w.fb, src_u16(B.pw, W), w.fb + 4, baseRows, baseSliceCols,
+                                      d_res + 12 * A.u, d_res + 12 * B.u))) return rc;
+    }
+    if (k < units.size()) {
+        const Unit &A = units[k];
+        if ((rc = upsample(A, w.fb))) return rc;
+        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), w.fb, baseRows, baseSliceCols, d_res + 12 * A.u))) return rc;
     }
     std::vector<double> r(12 * n);
     if ((rc = fetch_results(ctx, 12 * n, r.data()))) return rc;

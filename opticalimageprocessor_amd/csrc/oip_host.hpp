@@ -5,8 +5,8 @@
 //
 // Differences kept deliberately small:
 //   * the line width is a constructor/run-time argument (reference: PIXELS_PER_LINE 12288);
-//   * TIFF output is not implemented yet (SURVEY 8f "next"): the aligned MSS image is written
-//     as headerless 16UC4 RAW (<stem>.ALIGNED.RAW) and `stitch` writes RAW only;
+//   * TIFF output goes through a dependency-free uncompressed TIFF/BigTIFF writer (oip_tiff.hpp)
+//     instead of GDAL / cv::imwrite; TIFF *input* (stitching two ALIGNED.TIFF files) is not built;
 //   * timing lines are logged like the reference's (seconds, MBps) through a plain logger.
 #pragma once
 
@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "oip_c.h"
+#include "oip_tiff.hpp"
 
 namespace OIPGPU {
 
@@ -268,12 +269,13 @@ public:
         const size_t bytesPerLine = (size_t)pixelPerLine * BYTES_PER_PIXEL;
         const long imageLines = (long)(szl / bytesPerLine);
         const int outputFullLinePixels = (pixelPerLine - foldColPixels) * 2;
+        bool outputIsTiff = true;                                      // imageop.h:297-306
         std::string outputFilePath = stitchedFilePath;
         if (stitchedFilePath.empty()) {
             outputFilePath = (std::filesystem::current_path() /
-                              ("stitched_" + std::to_string(outputFullLinePixels) + "n" + std::to_string(BYTES_PER_PIXEL * 8) + "b.RAW")).string();
-        } else if (to_lower(std::filesystem::path(stitchedFilePath).extension().string()) == ".tiff") {
-            throw std::invalid_argument("Stitch(): TIFF output is not available in this build, use a .RAW output path");
+                              ("stitched_" + std::to_string(outputFullLinePixels) + "n" + std::to_string(BYTES_PER_PIXEL * 8) + "b.TIFF")).string();
+        } else {
+            outputIsTiff = to_lower(std::filesystem::path(stitchedFilePath).extension().string()) == ".tiff";
         }
         std::unique_ptr<char[]> l((char *)LoadRawImage(leftImagePath, 0, 0, szl)), r((char *)LoadRawImage(rightImagePath, 0, 0, szr));
         OLOG("Begin stitching two images ...");
@@ -285,9 +287,57 @@ public:
         Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, pixelPerLine, imageLines, foldColPixels));
         std::unique_ptr<uint16_t[]> out(new uint16_t[nout]);
         dout.download(out.get(), nout);
-        WriteBufferToFile((const char *)out.get(), nout * 2, outputFilePath);
+        if (outputIsTiff) write_tiff_u16(outputFilePath, out.get(), outputFullLinePixels, imageLines, 1, false);   // 1-band GTiff (imageop.h:316-328)
+        else WriteBufferToFile((const char *)out.get(), nout * 2, outputFilePath);
         double es = sw.tick();
         OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", nout * 2, es, nout * 2 / es / (1024.0 * 1024.0));
+        return outputFilePath;
+    }
+
+    // imageop.h:365-457 (+ StitchTiffGDAL :460-567): two 16UC4 images -> column-range concat.  cv::imread
+    // hands the reference BGRA-ordered Mats, i.e. the original channel order c0..c3; the same is rebuilt
+    // here from the on-disk RGBA order.  Without -g the result is re-encoded like cv::imwrite; with -g
+    // GDAL writes band b from channel bandMap[b]-1 (imageop.h:529).
+    static std::string StitchTiff(const std::string &leftImagePath, const std::string &rightImagePath,
+                                  const std::string &stitchedFilePath, int foldColPixels, bool useGDAL = false,
+                                  const int *bandMap = nullptr)
+    {
+        std::string outputFilePath = stitchedFilePath;
+        if (stitchedFilePath.empty()) outputFilePath = (std::filesystem::current_path() / "stitched.TIFF").string();
+        else if (to_lower(std::filesystem::path(stitchedFilePath).extension().string()) != ".tiff")
+            throw std::invalid_argument("Output file should be a tiff image");
+        int wl, wr, sl, sr;
+        long hl, hr;
+        std::vector<uint16_t> L, R;
+        OLOG("Reading tiff image from file `%s' ...", leftImagePath.c_str());
+        read_tiff_u16(leftImagePath, &wl, &hl, &sl, &L);
+        OLOG("Reading tiff image from file `%s' ...", rightImagePath.c_str());
+        read_tiff_u16(rightImagePath, &wr, &hr, &sr, &R);
+        if (hl != hr || wl != wr) throw std::runtime_error("images have different sizes");
+        if (sl != MSS_BANDS || sr != MSS_BANDS) throw std::runtime_error("StitchTiff(): 4-channel 16-bit images expected");
+        if (foldColPixels < 0 || foldColPixels >= wl) throw std::invalid_argument("fold columns exceed the image width");
+        // the stitch itself: 4 interleaved samples per pixel are just 4x wider u16 lines
+        const int W4 = wl * 4, fold4 = foldColPixels * 4;
+        const size_t nin = (size_t)W4 * hl, nout = (size_t)2 * (W4 - fold4) * hl;
+        DevBuf<uint16_t> dl(nin), dr(nin), dout(nout);
+        dl.upload(L.data(), nin);
+        dr.upload(R.data(), nin);
+        Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, W4, hl, fold4));
+        std::vector<uint16_t> out(nout);
+        dout.download(out.data(), nout);
+        const int ow = 2 * (wl - foldColPixels);
+        OLOG("Write stitched image to file '%s' ...", outputFilePath.c_str());
+        // file order is RGBA = (c2, c1, c0, c3) of the reference's Mat
+        const size_t bytes = nout * 2;
+        if (!useGDAL && bytes / 2 < 4000000000ull) {
+            int ident[4] = {0, 1, 2, 3};                       // same on-disk order in and out
+            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, ident);
+        } else {
+            const int mat2file[4] = {2, 1, 0, 3};              // Mat channel c lives at file sample mat2file[c]
+            int order[4];
+            for (int b = 0; b < 4; ++b) order[b] = mat2file[bandMap ? bandMap[b] - 1 : b];
+            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, order);
+        }
         return outputFilePath;
     }
 };
@@ -298,14 +348,15 @@ class Stitcher {
 public:
     // stitcher.h:21-46; foldCols is the already-halved value (main.cpp:189)
     static std::string Stitch(const std::string &leftImagePath, const std::string &rightImagePath,
-                              const std::string &outputPath = "", int foldCols = 0, int pixelsPerLine = OIP_PIXELS_PER_LINE)
+                              const std::string &outputPath = "", int foldCols = 0, int pixelsPerLine = OIP_PIXELS_PER_LINE,
+                              bool useGDAL = false, const int *bandMap = nullptr)
     {
         std::string leftExt = to_lower(std::filesystem::path(leftImagePath).extension().string());
         std::string rightExt = to_lower(std::filesystem::path(rightImagePath).extension().string());
         if (leftExt != rightExt) throw std::invalid_argument("Stitch(): two images should be same type");
         if (leftExt != ".tiff" && leftExt != ".raw") throw std::invalid_argument("Stitch(): only RAW and TIFF image supported");
         if (leftExt == ".raw") return IMO::StitchBigRaw(leftImagePath, rightImagePath, outputPath, pixelsPerLine, foldCols);
-        throw std::invalid_argument("Stitch(): TIFF stitching is not available in this build (SURVEY 8f)");
+        return IMO::StitchTiff(leftImagePath, rightImagePath, outputPath, foldCols, useGDAL, bandMap);
     }
 
     Stitcher(const std::string &pan1, const std::string &pan2, const std::string &rrc1, const std::string &rrc2,
@@ -505,7 +556,7 @@ public:
         if (autoUnloadPAN) mPAN.release();
     }
 
-    // preproc.h:351-425 (+ inner :428-468); writes <stem>.ALIGNED.RAW (16UC4) instead of the TIFF
+    // preproc.h:351-425 (+ inner :428-468); writes <stem>.ALIGNED.TIFF
     void DoInterBandAlignment(int linePerSection, int lineOffset = 0, int sectionOverlap = OIP_IBPA_DEFAULT_LINEOVERLAP,
                               bool keepLeadingLines = false, bool autoUnloadRawMSS = true)
     {
@@ -524,9 +575,10 @@ public:
         out.download(h.get(), (size_t)rows * Wb * MSS_BANDS);
         double es = sw.tick();
         OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", es, processed, rows);
-        auto save = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".RAW");
-        OLOG("Outputing aligned image (16UC4 RAW, %d x %ld) to [%s] ...", Wb, rows, save.c_str());
-        IMO::WriteBufferToFile((const char *)h.get(), (size_t)rows * Wb * MSS_BANDS * 2, save);
+        // preproc.h:167-185 WriteAlignedMSS_TIFF: 4-channel 16-bit TIFF, samples in OpenCV's on-disk order
+        auto save = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
+        OLOG("Outputing aligned TIFF image (%d x %ld x 4) to [%s] ...", Wb, rows, save.c_str());
+        write_tiff_u16(save, h.get(), Wb, rows, MSS_BANDS, true);
         OLOG("Output done.");
         if (autoUnloadRawMSS) mPlanes.release();
         OLOG("DoInterBandAlignment(): done.");

@@ -7,7 +7,8 @@
 //       --ibc-sections --ibc-threshold --line-offset --lines-section --overlap-lines -k]   (:193-252)
 //   oip -v | --version          prints 1.1
 // plus --width N (pixels per PAN line; the reference hard-codes 12288, oipshared.h:28).
-// `auxsep`, TIFF input/output, -g/--GDAL and -m/--band-map are outside this build.
+// `auxsep` is outside this build.  TIFF output and (uncompressed) TIFF input go through oip_tiff.hpp;
+// LZW-compressed inputs such as cv::imwrite's are refused, not decoded.
 //
 // Exit codes as the reference: usage_error -> "USAGE ERROR" + 254; any std::exception -> 2; unknown
 // -> 1; help/version -> 255 (CLI11's Success + 255, main.cpp:262-263); argument errors -> CLI11's
@@ -153,9 +154,16 @@ int run_stitch(const std::vector<std::string> &args, int width)
     width = p.integer("--width", width);
     const int foldCols = p.integer("--fold-cols", 0);
     if (foldCols < 2) throw cli_error(105, "--fold-cols: fold column value too small");                           // main.cpp:166-170
-    if (p.has("--GDAL") || p.has("--band-map"))
-        throw std::invalid_argument("Stitch(): GDAL/TIFF output is not available in this build (SURVEY 8f)");
-    Stitcher::Stitch(p.str("--image1"), p.str("--image2"), p.str("--out"), foldCols / 2, width);                  // main.cpp:189
+    if (p.has("--band-map") && !p.has("--GDAL")) throw cli_error(107, "--band-map requires --GDAL");              // ->needs(gdal)
+    int map[MSS_BANDS] = {0, 0, 0, 0};
+    const std::string bandMap = p.str("--band-map");
+    if (!bandMap.empty()) {                                                                                      // main.cpp:177-188
+        if (sscanf(bandMap.c_str(), "%d,%d,%d,%d", map, map + 1, map + 2, map + 3) != 4) throw cli_error(105, "-m: need 4 band indices");
+        for (int i = 0; i < MSS_BANDS; ++i)
+            if (map[i] <= 0 || map[i] > MSS_BANDS) throw cli_error(105, "-m: invalid band index");
+    }
+    Stitcher::Stitch(p.str("--image1"), p.str("--image2"), p.str("--out"), foldCols / 2, width, p.has("--GDAL"),
+                     bandMap.empty() ? nullptr : map);                                                           // main.cpp:189
     return 0;
 }
 

@@ -55,3 +55,71 @@ def test_runtime_errors_exit_2(files):
     # PAN must be 4x the MSS size (preproc.h:565-567)
     r = run(["--pan", "a.raw", "--mss", "b.raw", "--no-rrc4mss"], files)
     assert r.returncode == 2 and "PAN file size does not match MSS file size" in r.stdout
+
+
+def test_tiff_writer_roundtrip(tmp_path):
+    """csrc/oip_tiff.hpp through a tiny driver: classic TIFF, 1 and 4 samples, odd sizes, many strips"""
+    import numpy as np
+    import _tiff
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "oip_tiff.hpp"\n#include <cstdlib>\n#include <vector>\nint main(int c, char** v){int w=atoi(v[2]);long h=atol(v[3]);int s=atoi(v[4]);'
+                   'std::vector<uint16_t> d((size_t)w*h*s);for(size_t i=0;i<d.size();++i)d[i]=(uint16_t)(i*2654435761u>>7);'
+                   'OIPGPU::write_tiff_u16(v[1],d.data(),w,h,s,s==4);return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    for w, h, spp in [(7, 5, 1), (1001, 333, 4), (3000, 3000, 1), (7500, 700, 4)]:
+        out = tmp_path / ("o_%d_%d_%d.tiff" % (w, h, spp))
+        subprocess.run([str(exe), str(out), str(w), str(h), str(spp)], check=True)
+        img, tags, big = _tiff.read_tiff_u16(str(out))
+        n = w * h * spp
+        want = ((np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)) >> 7).astype(np.uint16)
+        want = want.reshape(h, w, spp) if spp > 1 else want.reshape(h, w)
+        if spp == 4:
+            want = want[:, :, [2, 1, 0, 3]]
+        assert not big and np.array_equal(img, want), (w, h, spp)
+        if spp == 1:
+            from PIL import Image
+            with Image.open(str(out)) as im:
+                assert np.array_equal(np.asarray(im), want)
+
+
+def test_tiff_reader(tmp_path):
+    """oip_tiff.hpp reader: its own files, a foreign uncompressed file, and a refused LZW file"""
+    import numpy as np
+    import _tiff
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "r.cpp"
+    src.write_text('#include "oip_tiff.hpp"\n#include <cstdlib>\n#include <vector>\nint main(int c, char** v){int w,s;long h;std::vector<uint16_t> d;'
+                   'try{OIPGPU::read_tiff_u16(v[1],&w,&h,&s,&d);}catch(std::exception&e){printf("ERR %s\\n",e.what());return 3;}'
+                   'if(c>3){OIPGPU::write_tiff_u16(v[3],d.data(),w,h,s,false);}'
+                   'FILE*f=fopen(v[2],"wb");fwrite(d.data(),2,d.size(),f);fclose(f);printf("%d %ld %d\\n",w,h,s);return 0;}\n')
+    exe = tmp_path / "r"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    rng = np.random.default_rng(3)
+    for shape in [(5, 7), (333, 1001, 4), (900, 7500, 4)]:
+        a = rng.integers(0, 65536, shape).astype(np.uint16)
+        p = tmp_path / "in.tiff"
+        _tiff.write_tiff_u16(str(p), a)
+        r = subprocess.run([str(exe), str(p), str(tmp_path / "o.raw"), str(tmp_path / "rt.tiff")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout
+        w, h, s = map(int, r.stdout.split())
+        assert (h, w) == shape[:2] and s == (shape[2] if len(shape) == 3 else 1)
+        assert np.array_equal(np.fromfile(tmp_path / "o.raw", np.uint16).reshape(shape), a)
+        # written again by the C++ writer (many strips for the large case) and read back by both readers
+        back, _, _ = _tiff.read_tiff_u16(str(tmp_path / "rt.tiff"))
+        assert np.array_equal(back.reshape(shape), a)
+        r = subprocess.run([str(exe), str(tmp_path / "rt.tiff"), str(tmp_path / "o2.raw")], capture_output=True, text=True)
+        assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o2.raw", np.uint16).reshape(shape), a)
+    # Pillow writes 16-bit gray; uncompressed is accepted, LZW is refused with a clear message
+    g = rng.integers(0, 65536, (40, 50)).astype(np.uint16)
+    Image.fromarray(g).save(str(tmp_path / "pil.tiff"))
+    r = subprocess.run([str(exe), str(tmp_path / "pil.tiff"), str(tmp_path / "o3.raw")], capture_output=True, text=True)
+    assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o3.raw", np.uint16).reshape(40, 50), g)
+    Image.fromarray(g).save(str(tmp_path / "lzw.tiff"), compression="tiff_lzw")
+    r = subprocess.run([str(exe), str(tmp_path / "lzw.tiff"), str(tmp_path / "o4.raw")], capture_output=True, text=True)
+    assert r.returncode == 3 and "compressed TIFF input" in r.stdout
+    (tmp_path / "bad.tiff").write_bytes(b"not a tiff at all")
+    r = subprocess.run([str(exe), str(tmp_path / "bad.tiff"), str(tmp_path / "o5.raw")], capture_output=True, text=True)
+    assert r.returncode == 3

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import _synth
+import _tiff
 
 pytestmark = pytest.mark.gpu
 OIP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "opticalimageprocessor_amd", "lib", "oip")
@@ -61,6 +62,16 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     st = np.fromfile(os.path.join(d, "stitched-PAN.RAW"), np.uint16).reshape(L, 2 * (W - 20))
     assert np.array_equal(st, oracle_mod.stitch_raw(rrc1, got, 20))
+    # ... and as the reference's default output type: a 1-band 16-bit TIFF (imageop.h:299-328)
+    r = subprocess.run([OIP, "stitch", "--width", str(W), "--image1", "S_PAN-1.RRC.RAW", "--image2", "S_PAN-2.RRC.PRESTT.RAW",
+                        "--fold-cols", "40"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tif, tags, big = _tiff.read_tiff_u16(os.path.join(d, "stitched_%dn16b.TIFF" % (2 * (W - 20))))
+    assert not big and tags[262] == [1] and np.array_equal(tif, st)
+    from PIL import Image
+    Image.MAX_IMAGE_PIXELS = None
+    with Image.open(os.path.join(d, "stitched_%dn16b.TIFF" % (2 * (W - 20)))) as im:      # independent reader
+        assert im.size == (2 * (W - 20), L) and np.array_equal(np.asarray(im), st)
 
     # ---- step 3: default action on (RRC'd PAN, raw MSS)
     shifts_true = [(2, -1), (1, 1), (-1, -2), (-2, 1)]
@@ -82,6 +93,30 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     sh = ctx.interband_correlate(_cuda(pan), L, 0, L, planes, Lm * Wb, 0, Lm, W, 8, 1, 16000)
     cx, cy = oip.filter_and_fit(sh, 0.0, 5)
     want, nvalid = oracle_mod.align_mss(cbands, cx, cy, 3000, 0, 100, False, 1500)
-    got = np.fromfile(os.path.join(d, "T_MSS.ALIGNED.RAW"), np.uint16).reshape(want.shape)
+    tif, tags, _ = _tiff.read_tiff_u16(os.path.join(d, "T_MSS.ALIGNED.TIFF"))
+    assert tags[262] == [2] and tags[338] == [2]            # RGB + unassociated alpha, as cv::imwrite(16UC4)
+    got = tif[:, :, [2, 1, 0, 3]]                           # stored in OpenCV's on-disk order (BGRA -> RGBA)
     assert np.array_equal(got, want)
     assert "%d lines valid" % nvalid in r.stdout
+
+    # ---- step 4: stitch two aligned 4-channel TIFFs (imageop.h:365-457; -g/-m: :460-567)
+    import shutil
+    shutil.copy(os.path.join(d, "T_MSS.ALIGNED.TIFF"), os.path.join(d, "T2_MSS.ALIGNED.TIFF"))
+    rolled = np.roll(tif, 7, axis=0)                         # a second, different image in file order
+    _tiff.write_tiff_u16(os.path.join(d, "T2_MSS.ALIGNED.TIFF"), rolled)
+    r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "--fold-cols", "12",
+                        "-o", "stitched-MSS.TIFF"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out, _, _ = _tiff.read_tiff_u16(os.path.join(d, "stitched-MSS.TIFF"))
+    fold = 6
+    assert np.array_equal(out, np.concatenate([tif[:, :Wb - fold], rolled[:, fold:]], axis=1))
+    # GDAL flavour with a band map: band b <- Mat channel map[b]-1, the Mat being (c0..c3) = file samples (2,1,0,3)
+    r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "--fold-cols", "12",
+                        "-g", "-m", "3,2,1,4", "-o", "stitched-MSS-g.TIFF"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    outg, _, _ = _tiff.read_tiff_u16(os.path.join(d, "stitched-MSS-g.TIFF"))
+    mat = np.concatenate([tif[:, :Wb - fold], rolled[:, fold:]], axis=1)[:, :, [2, 1, 0, 3]]
+    assert np.array_equal(outg, mat[:, :, [2, 1, 0, 3]])
+    r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "-g", "-m", "3,2,9,4",
+                        "--fold-cols", "12", "-o", "x.TIFF"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 105

@@ -55,7 +55,7 @@ def parse():
 
 # algorithmic HBM bytes per launch of each kernel, keyed by the name the
 # library's profiler and rocprofv3 both report
-def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
+def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_arrays=5.0):
     mb, Wb = pb // 4, W // 4
     MN = M * N
     win = base_rows * base_cols
@@ -64,7 +64,10 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local):
         "rrc_u16_flat_kernel": 4.0 * W * pb,
         "mss_split_rrc_kernel": 4.0 * W * mb,
         "cross_power_kernel": 8.0 * MN * 3.5,                 # 2 or 3 spectra in, 1 out
-        "xpower_inverse_row_kernel": 8.0 * MN * 3.5,          # same traffic, the inverse row FFT rides along
+        "xpower_rows_kernel": 8.0 * MN * 3.5,                 # same traffic, the inverse row FFT rides along
+        # whole row stage (forward rows + cross-power + inverse rows): every spectrum of the job read
+        # once, every output written once -- 3 in + 2 out for a PAN-vs-4-bands unit, 1 + 1 for a CCD pair
+        "corr_rows_kernel": 8.0 * MN * rows_arrays,
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out
         "resize_cubic_x4_kernel": 4.0 * win + 2.0 * win / 16.0,
         "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
@@ -324,7 +327,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pix_per_rank * world * args.steps / elapsed / 1e6
-        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local)
+        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local, 5.0 if args.workload == "default" else 2.0)
         kernels = {}
         for name, (ms, n) in prof.items():
             avg = ms / max(n, 1)

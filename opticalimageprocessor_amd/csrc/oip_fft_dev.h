@@ -7,8 +7,14 @@
 
 namespace oipfft {
 
+// The transform is not part of the bit-exact contract (its factorisation already differs from
+// OpenCV's), so multiply-adds may fuse here -- and only here: the library is built with
+// -ffp-contract=off and every other kernel rounds after each multiply and add.
+#define OIP_FFT_FMA _Pragma("clang fp contract(fast)")
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
+    OIP_FFT_FMA
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -25,6 +31,7 @@ __device__ __forceinline__ void bf2(float2 *x)
 }
 __device__ __forceinline__ void bf3(float2 *x)
 {
+    OIP_FFT_FMA
     const float s = 0.86602540378443864676f;
     float2 t = cadd(x[1], x[2]);
     float2 d = cscale(cmuli_neg(csub(x[1], x[2])), s);
@@ -44,6 +51,7 @@ __device__ __forceinline__ void bf4(float2 *x)
 }
 __device__ __forceinline__ void bf5(float2 *x)
 {
+    OIP_FFT_FMA
     const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
     const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
     float2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]);
@@ -60,6 +68,7 @@ __device__ __forceinline__ void bf5(float2 *x)
 }
 __device__ __forceinline__ void bf8(float2 *x)
 {
+    OIP_FFT_FMA
     const float h = 0.70710678118654752440f;
     float2 e[4] = {x[0], x[2], x[4], x[6]};
     float2 o[4] = {x[1], x[3], x[5], x[7]};
@@ -154,5 +163,74 @@ template <int F, int VS, int VP, int NT, int Ns, int R, int... Rest> struct Stag
     }
 };
 
+
+// One Stockham stage over NA independent two-line buffers (buffer a at buf + a * 2F), software
+// pipelined across the buffers: while buffer a is being combined and stored, the loads of buffer
+// a+1 are already issued.  One barrier per buffer and stage; only two buffers' worth of points live
+// in registers.  Entry: all writers of the buffers are behind a barrier.  Exit: the stores of the
+// LAST buffer are not yet behind a barrier (the next stage starts on buffer 0, whose stores are).
+template <int F, int NT, int Ns, int R> struct StageOps {
+    static constexpr int NB = F / R;
+    static constexpr int ITEMS = NB * 2;
+    static constexpr int PER = (ITEMS + NT - 1) / NT;
+    static constexpr int TWSTEP = F / (Ns * R);
+    static __device__ __forceinline__ void load(const float2 *__restrict__ buf, float2 (&x)[PER][R], int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = tid + i * NT;
+            if (ITEMS % NT == 0 || item < ITEMS) {
+                const int v = item & 1, b = item >> 1;
+#pragma unroll
+                for (int m = 0; m < R; ++m) x[i][m] = buf[(b + m * NB) * 2 + v];
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(float2 *__restrict__ buf, const float2 *__restrict__ tw, float2 (&x)[PER][R], int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = tid + i * NT;
+            if (ITEMS % NT == 0 || item < ITEMS) {
+                const int v = item & 1, b = item >> 1;
+                const int k = b % Ns;
+                if (Ns > 1) {
+                    const float2 w1 = tw[k * TWSTEP];
+                    float2 w = w1;
+#pragma unroll
+                    for (int m = 1; m < R; ++m) {
+                        x[i][m] = cmul(x[i][m], w);
+                        if (m + 1 < R) w = cmul(w, w1);
+                    }
+                }
+                butterfly<R>(x[i]);
+                const int j0 = (b - k) * R + k;
+#pragma unroll
+                for (int m = 0; m < R; ++m) buf[(j0 + m * Ns) * 2 + v] = x[i][m];
+            }
+        }
+    }
+};
+
+template <int F, int NT, int NA, int Ns, int... Rs> struct StagesPipe;
+template <int F, int NT, int NA, int Ns> struct StagesPipe<F, NT, NA, Ns> {
+    static __device__ __forceinline__ void run(float2 *, const float2 *, int) { if (NA > 1) __syncthreads(); }
+};
+template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesPipe<F, NT, NA, Ns, R, Rest...> {
+    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw, int tid)
+    {
+        using Ops = StageOps<F, NT, Ns, R>;
+        float2 x[2][Ops::PER][R];
+        Ops::load(buf, x[0], tid);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            __syncthreads();
+            if (a + 1 < NA) Ops::load(buf + (a + 1) * 2 * F, x[(a + 1) & 1], tid);
+            Ops::store(buf + a * 2 * F, tw, x[a & 1], tid);
+        }
+        if (NA == 1) __syncthreads();
+        StagesPipe<F, NT, NA, Ns * R, Rest...>::run(buf, tw, tid);
+    }
+};
 
 }  // namespace oipfft

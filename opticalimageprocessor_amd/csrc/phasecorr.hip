@@ -191,6 +191,24 @@ __device__ __forceinline__ float2 cross_power_bin(float2 A, float2 B, bool real_
     return make_float2((float)__ddiv_rn(re, denom), (float)__ddiv_rn(im, denom));
 }
 
+// The same bin for the fused row stage.  The spectra feeding it already differ from OpenCV's in
+// their last bits (another FFT factorisation), so correctly rounded double-precision sqrt and
+// divisions buy nothing there; what must survive is the structure: the magnitude formed in double
+// (no overflow before the float rounding), mag * mag and p * mag rounded to float (where the
+// reference overflows to inf and produces 0 or NaN), the + eps, and the special bins.  sqrt and the
+// reciprocal use the hardware approximations (relative error about 1e-7, below the FFT round-off);
+// inf and NaN propagate as in the division: x * (1 / inf) = 0, inf * 0 = NaN.
+__device__ __forceinline__ float2 cross_power_bin_fast(float2 A, float2 B, bool real_bin, bool edge_col)
+{
+    if (real_bin || edge_col) return cross_power_bin(A, B, real_bin, edge_col);
+    const float eps = FLT_EPSILON;
+    float pr = __fadd_rn(__fmul_rn(A.x, B.x), __fmul_rn(A.y, B.y));
+    float pi = __fsub_rn(__fmul_rn(A.y, B.x), __fmul_rn(A.x, B.y));
+    float mag = (float)__builtin_amdgcn_sqrt(__dadd_rn(__dmul_rn((double)pr, (double)pr), __dmul_rn((double)pi, (double)pi)));
+    float r = __builtin_amdgcn_rcpf(__fadd_rn(__fmul_rn(mag, mag), eps));
+    return make_float2(__fmul_rn(__fmul_rn(pr, mag), r), __fmul_rn(__fmul_rn(pi, mag), r));
+}
+
 // One workgroup row handles the spectrum line of frequency ky AND its mirror -ky: every input
 // line is read once, C(k) is computed once and written as Y(k) and Y(-k) = conj(C1) + i conj(C2).
 // The x axis of the reference shapes is a single pass (natural order), so the mirrored
@@ -233,23 +251,31 @@ __global__ __launch_bounds__(kBlock) void cross_power_kernel(float2 *__restrict_
     if (r1 != r2) out[r2 + px2] = ym;
 }
 
-// XpowerJob flattened on the host: distinct spectra and, per correlation, which of them and
-// which slot (real/imaginary) hold A and B
+// Cross-power jobs flattened on the host: up to three distinct packed spectra, up to two output
+// arrays, each output Y = C(a0,b0) + i C(a1,b1); per correlation which spectrum and which slot
+// (real/imaginary) hold A and B
 struct FusedJob {
     const float2 *z[3];
-    int narr, ncorr;
-    int ia0, ib0, pa0, pb0, ia1, ib1, pa1, pb1;
+    float2 *out[2];
+    int narr, nout;
+    int ncorr[2];
+    int ia[4], ib[4], pa[4], pb[4];     // correlation 2*o + c of output o
+    int dbg;                            // experiment mask (OIP_ROWS_DBG): skip phases to time the rest; results are wrong
 };
 
-// Cross-power spectrum fused with the first inverse pass (the row pass) for shapes whose row
-// axis is a single factor (natural order along x): the workgroup of frequency line ky forms
-// Y(ky, .) and its mirror Y(-ky, .) in LDS straight from the spectra -- every input line read
-// once, Y never written in the spectral domain -- runs the two F-point inverse transforms and
-// stores both lines.  Replaces cross_power_kernel + one fft pass (a write and a read of the
-// whole Y array).
-template <int F, int NT, int... Rs>
-__global__ __launch_bounds__(NT) void xpower_inverse_row_kernel(float2 *__restrict__ out, FusedJob fj, int M, int P,
-                                                                OipAxisDigits yd, const float2 *__restrict__ twF)
+// Row stage of the whole correlation in one kernel, for shapes whose row axis is a single factor
+// (natural order along x).  The workgroup of frequency line ky owns the lines ky and -ky of every
+// spectrum of the job:
+//   FWD: the spectra arrive with only their column passes done; each pair of lines is staged in
+//        LDS, row-transformed (both lines in one Stockham network) and picked up into registers
+//        -- the forward row pass never touches HBM;
+//   the cross-power lines Y(ky,.) and Y(-ky,.) of each output are formed in LDS straight from the
+//   registers, inverse row-transformed and stored -- Y never exists in the spectral domain.
+// Against separate kernels this saves a read + write of every spectrum (forward rows), a write +
+// read of every Y (cross-power), and the second read of spectra shared by two outputs.
+template <int F, int NT, int WPE, bool FWD, int... Rs>
+__global__ __launch_bounds__(NT, WPE) void xpower_rows_kernel(FusedJob fj, int M, int P, OipAxisDigits yd,
+                                                         const float2 *__restrict__ twF)
 {
     constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
     constexpr int N = F;
@@ -261,69 +287,262 @@ __global__ __launch_bounds__(NT) void xpower_inverse_row_kernel(float2 *__restri
     const long r1 = (long)oip_freq_to_pos(yd, ky) * P, r2 = (long)oip_freq_to_pos(yd, nky) * P;
     const bool pair = r1 != r2;
     for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
-    // distinct input spectra and who uses which: fixed-size, statically indexed (no scratch)
-    const float2 *z0 = fj.z[0], *z1 = fj.z[1], *z2 = fj.z[2];
     const int narr = fj.narr;
-    // all spectrum loads of the two lines are issued before the arithmetic starts
-    float2 zk0[NIT], zk1[NIT], zk2[NIT], zm0[NIT], zm1[NIT], zm2[NIT];    // one array per spectrum: static indices only
+    // one register array per spectrum and line: static indices only (no scratch)
+    float2 zk0[NIT], zk1[NIT], zk2[NIT], zm0[NIT], zm1[NIT], zm2[NIT];
+    const float2 zero = make_float2(0.f, 0.f);
+    if (FWD) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int kx = threadIdx.x + it * NT;
-        const int nkx = kx ? N - kx : 0;
-        const float2 zero = make_float2(0.f, 0.f);
-        const bool ok = kx < N;
-        zk0[it] = ok ? z0[r1 + kx] : zero;
-        zm0[it] = ok ? z0[r2 + nkx] : zero;
-        zk1[it] = ok && narr > 1 ? z1[r1 + kx] : zero;
-        zm1[it] = ok && narr > 1 ? z1[r2 + nkx] : zero;
-        zk2[it] = ok && narr > 2 ? z2[r1 + kx] : zero;
-        zm2[it] = ok && narr > 2 ? z2[r2 + nkx] : zero;
+        for (int s = 0; s < 3; ++s) {
+            if (s >= narr) break;
+            const float2 *zs = fj.z[s];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int x = threadIdx.x + it * NT;
+                if (x < N) { buf[2 * x] = zs[r1 + x]; buf[2 * x + 1] = zs[r2 + x]; }
+            }
+            __syncthreads();
+            oipfft::Stages<F, 1, 2, NT, 1, Rs...>::run(buf, tw);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int kx = threadIdx.x + it * NT;
+                const bool ok = kx < N;
+                const int nkx = kx ? N - kx : 0;
+                const float2 a = ok ? buf[2 * kx] : zero, b = ok ? buf[2 * nkx + 1] : zero;
+                if (s == 0) { zk0[it] = a; zm0[it] = b; }
+                else if (s == 1) { zk1[it] = a; zm1[it] = b; }
+                else { zk2[it] = a; zm2[it] = b; }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (narr < 2) { zk1[it] = zero; zm1[it] = zero; }
+            if (narr < 3) { zk2[it] = zero; zm2[it] = zero; }
+        }
+    } else {
+        const float2 *z0 = fj.z[0], *z1 = fj.z[1], *z2 = fj.z[2];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kx = threadIdx.x + it * NT;
+            const int nkx = kx ? N - kx : 0;
+            const bool ok = kx < N;
+            zk0[it] = ok ? z0[r1 + kx] : zero;
+            zm0[it] = ok ? z0[r2 + nkx] : zero;
+            zk1[it] = ok && narr > 1 ? z1[r1 + kx] : zero;
+            zm1[it] = ok && narr > 1 ? z1[r2 + nkx] : zero;
+            zk2[it] = ok && narr > 2 ? z2[r1 + kx] : zero;
+            zm2[it] = ok && narr > 2 ? z2[r2 + nkx] : zero;
+        }
     }
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int kx = threadIdx.x + it * NT;
-        if (kx >= N) continue;
-        const int nkx = kx ? N - kx : 0;
-        const bool edge_col = (kx == 0) || (2 * kx == N);
-        const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
-        float2 y = make_float2(0.f, 0.f), ym = make_float2(0.f, 0.f);
+    for (int o = 0; o < 2; ++o) {
+        if (o >= fj.nout) break;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (c >= fj.ncorr) break;
-            const int ia = c ? fj.ia1 : fj.ia0, ib = c ? fj.ib1 : fj.ib0;
-            const int pa = c ? fj.pa1 : fj.pa0, pb = c ? fj.pb1 : fj.pb0;
-            float2 zka = ia == 0 ? zk0[it] : (ia == 1 ? zk1[it] : zk2[it]);
-            float2 zma = ia == 0 ? zm0[it] : (ia == 1 ? zm1[it] : zm2[it]);
-            float2 zkb = ib == 0 ? zk0[it] : (ib == 1 ? zk1[it] : zk2[it]);
-            float2 zmb = ib == 0 ? zm0[it] : (ib == 1 ? zm1[it] : zm2[it]);
-            float2 A = spec_of(pa, zka, zma);
-            float2 B = spec_of(pb, zkb, zmb);
-            float2 C = cross_power_bin(A, B, real_bin, edge_col);
-            if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }
-            else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }
+        for (int it = 0; it < NIT; ++it) {
+            const int kx = threadIdx.x + it * NT;
+            if (kx >= N) continue;
+            const int nkx = kx ? N - kx : 0;
+            const bool edge_col = (kx == 0) || (2 * kx == N);
+            const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+            float2 y = zero, ym = zero;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c >= fj.ncorr[o]) break;
+                const int ia = fj.ia[2 * o + c], ib = fj.ib[2 * o + c];
+                const int pa = fj.pa[2 * o + c], pb = fj.pb[2 * o + c];
+                float2 zka = ia == 0 ? zk0[it] : (ia == 1 ? zk1[it] : zk2[it]);
+                float2 zma = ia == 0 ? zm0[it] : (ia == 1 ? zm1[it] : zm2[it]);
+                float2 zkb = ib == 0 ? zk0[it] : (ib == 1 ? zk1[it] : zk2[it]);
+                float2 zmb = ib == 0 ? zm0[it] : (ib == 1 ? zm1[it] : zm2[it]);
+                float2 A = spec_of(pa, zka, zma);
+                float2 B = spec_of(pb, zkb, zmb);
+                float2 C = cross_power_bin(A, B, real_bin, edge_col);
+                if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }        // Y = C1 + i C2
+                else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }               // i*conj(C2) = (C2.y, C2.x)
+            }
+            // inverse = conj(forward(conj(.)))
+            buf[2 * kx] = make_float2(y.x, -y.y);
+            buf[2 * nkx + 1] = pair ? make_float2(ym.x, -ym.y) : zero;
         }
-        // inverse = conj(forward(conj(.)))
-        buf[2 * kx] = make_float2(y.x, -y.y);
-        buf[2 * nkx + 1] = pair ? make_float2(ym.x, -ym.y) : make_float2(0.f, 0.f);
+        __syncthreads();
+        oipfft::Stages<F, 1, 2, NT, 1, Rs...>::run(buf, tw);        // both lines in one Stockham network
+        float2 *out = fj.out[o];
+        for (int e = threadIdx.x; e < 2 * N; e += NT) {
+            const int line = e >= N, x = e - line * N;
+            if (line && !pair) break;
+            float2 a = buf[2 * x + line];
+            out[(line ? r2 : r1) + x] = make_float2(a.x, -a.y);
+        }
+        __syncthreads();
+    }
+}
+
+// Row stage of the whole correlation in one persistent kernel, for shapes whose row axis is a single
+// factor (natural order along x).  The spectra arrive with only their column passes done.  A
+// workgroup owns the lines ky and -ky of every spectrum of the job, each spectrum in its own
+// two-line LDS buffer:
+//   1. the prefetched lines (registers) go to LDS; the loads of the workgroup's NEXT line pair are
+//      issued and stay in flight under everything below;
+//   2. forward row transform of all spectra together (one barrier pair per stage);
+//   3. cross-power in place: the thread of column kx is the only reader of bins (kx, ky) and
+//      (-kx, -ky), so Y_o(kx, ky) / Y_o(-kx, -ky) overwrite them in buffer o;
+//   4. inverse row transform of the outputs together; both lines of each output are stored.
+// Against separate passes this saves a read + write of every spectrum (forward rows), a write +
+// read of every Y (cross-power) and the re-read of spectra shared by two outputs; one workgroup
+// per CU (3 x 48 KB of LDS at F = 3000) hides HBM latency by the register prefetch instead of
+// occupancy.
+template <int F, int NT, int NARR, int NOUT, int... Rs>
+__global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P, OipAxisDigits yd,
+                                                       const float2 *__restrict__ twF)
+{
+    constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
+    constexpr int N = F;
+    constexpr int NIT = (N + NT - 1) / NT;
+    __shared__ float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
+    __shared__ float2 tw[TWN];
+    const int dbg = fj.dbg;
+    const int half = M / 2;
+    int ky = blockIdx.x;
+    if (ky > half) return;
+    for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
+    const float2 zero = make_float2(0.f, 0.f);
+    float2 la[NARR][NIT], lb[NARR][NIT];
+    // rows of the line pair whose loads are in la/lb (n1, n2) and of the pair in LDS (s1, s2)
+    long n1 = (long)oip_freq_to_pos(yd, ky) * P, n2 = (long)oip_freq_to_pos(yd, ky ? M - ky : 0) * P;
+    auto fetch = [&](int tid) {
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int x = tid + it * NT;
+                const bool ok = x < N;
+                la[a][it] = ok ? fj.z[a][n1 + x] : zero;
+                lb[a][it] = ok ? fj.z[a][n2 + x] : zero;
+            }
+        }
+    };
+    auto commit = [&](int tid) {
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int x = tid + it * NT;
+                if (x < N) { buf[a * 2 * F + 2 * x] = la[a][it]; buf[a * 2 * F + 2 * x + 1] = lb[a][it]; }
+            }
+        }
+    };
+    fetch(threadIdx.x);
+    commit(threadIdx.x);
+    long s1 = n1, s2 = n2;
+    if (ky + (int)gridDim.x <= half) {
+        const int kn = ky + gridDim.x;
+        n1 = (long)oip_freq_to_pos(yd, kn) * P;
+        n2 = (long)oip_freq_to_pos(yd, M - kn) * P;
+        fetch(threadIdx.x);
     }
     __syncthreads();
-    oipfft::Stages<F, 1, 2, NT, 1, Rs...>::run(buf, tw);        // both lines in one Stockham network
-    for (int e = threadIdx.x; e < 2 * N; e += NT) {
-        const int line = e >= N, x = e - line * N;
-        if (line && !pair) break;
-        float2 a = buf[2 * x + line];
-        out[(line ? r2 : r1) + x] = make_float2(a.x, -a.y);
+    for (; ky <= half; ky += gridDim.x) {
+        // opaque per iteration: keeps the stage address arithmetic from being hoisted out of this
+        // loop, where it would occupy registers for the whole kernel
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const bool pair = s1 != s2;
+        if (!(dbg & 1)) oipfft::StagesPipe<F, NT, NARR, 1, Rs...>::run(buf, tw, tid);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int kx = tid + it * NT;
+            if (kx >= N || (dbg & 2)) continue;
+            const int nkx = kx ? N - kx : 0;
+            const bool edge_col = (kx == 0) || (2 * kx == N);
+            const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+            float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
+            float2 zk1 = zero, zm1 = zero, zk2 = zero, zm2 = zero;
+            if (NARR > 1) { zk1 = buf[2 * F + 2 * kx]; zm1 = buf[2 * F + 2 * nkx + 1]; }
+            if (NARR > 2) { zk2 = buf[4 * F + 2 * kx]; zm2 = buf[4 * F + 2 * nkx + 1]; }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float2 y = zero, ym = zero;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (c >= fj.ncorr[o]) break;
+                    const int ia = fj.ia[2 * o + c], ib = fj.ib[2 * o + c];
+                    const int pa = fj.pa[2 * o + c], pb = fj.pb[2 * o + c];
+                    float2 zka = ia == 0 ? zk0 : (ia == 1 ? zk1 : zk2);
+                    float2 zma = ia == 0 ? zm0 : (ia == 1 ? zm1 : zm2);
+                    float2 zkb = ib == 0 ? zk0 : (ib == 1 ? zk1 : zk2);
+                    float2 zmb = ib == 0 ? zm0 : (ib == 1 ? zm1 : zm2);
+                    float2 A = spec_of(pa, zka, zma);
+                    float2 B = spec_of(pb, zkb, zmb);
+                    float2 C = cross_power_bin_fast(A, B, real_bin, edge_col);
+                    if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }        // Y = C1 + i C2
+                    else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }               // i*conj(C2) = (C2.y, C2.x)
+                }
+                // inverse = conj(forward(conj(.)))
+                buf[o * 2 * F + 2 * kx] = make_float2(y.x, -y.y);
+                buf[o * 2 * F + 2 * nkx + 1] = pair ? make_float2(ym.x, -ym.y) : zero;
+            }
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        if (!(dbg & 4)) oipfft::StagesPipe<F, NT, NOUT, 1, Rs...>::run(buf, tw, tid);
+        if (NOUT == 1) __syncthreads();
+        // Results leave LDS through registers so that the next pair can be committed BEFORE the
+        // stores are issued: the commit then waits on loads that were issued a whole iteration ago,
+        // with nothing younger queued behind them, and both the stores and the following prefetch
+        // stay in flight under the next iteration's arithmetic.
+        float2 ya[NOUT][NIT], yb[NOUT][NIT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int x = tid + it * NT;
+                if (x < N) { ya[o][it] = buf[o * 2 * F + 2 * x]; yb[o][it] = buf[o * 2 * F + 2 * x + 1]; }
+            }
+        }
+        __syncthreads();
+        const int kn = ky + gridDim.x;
+        if (kn <= half) commit(tid);
+        if (!(dbg & 16)) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float2 *out = fj.out[o];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int x = tid + it * NT;
+                    if (x < N) {
+                        out[s1 + x] = make_float2(ya[o][it].x, -ya[o][it].y);
+                        if (pair) out[s2 + x] = make_float2(yb[o][it].x, -yb[o][it].y);
+                    }
+                }
+            }
+        }
+        s1 = n1; s2 = n2;
+        const int kf = kn + gridDim.x;
+        if (kf <= half && !(dbg & 8)) {
+            n1 = (long)oip_freq_to_pos(yd, kf) * P;
+            n2 = (long)oip_freq_to_pos(yd, M - kf) * P;
+            fetch(tid);
+        }
+        __syncthreads();
     }
 }
 
 struct FusedRow {
-    int F, threads;
-    void (*fn)(float2 *, FusedJob, int, int, OipAxisDigits, const float2 *);
+    int F, threads, fwd_threads;
+    void (*fwd1)(FusedJob, int, int, OipAxisDigits, const float2 *);      // one spectrum -> one output
+    void (*fwd3)(FusedJob, int, int, OipAxisDigits, const float2 *);      // three spectra -> two outputs
+    void (*inv)(FusedJob, int, int, OipAxisDigits, const float2 *);
 };
+// power-of-two radices last: their stores are then contiguous in LDS (a leading radix-8 stage
+// stores at a 128-byte stride, an 8-way bank conflict for ds_write_b64)
 const FusedRow kFusedRow[] = {
-    {3000, 512, xpower_inverse_row_kernel<3000, 512, 3, 8, 5, 5, 5>},
-    {1250, 256, xpower_inverse_row_kernel<1250, 256, 2, 5, 5, 5, 5>},
-    {200, 256, xpower_inverse_row_kernel<200, 256, 8, 5, 5>},
+    {3000, 512, 768, corr_rows_kernel<3000, 768, 1, 1, 3, 5, 5, 5, 8>, corr_rows_kernel<3000, 768, 3, 2, 3, 5, 5, 5, 8>,
+     xpower_rows_kernel<3000, 512, 2, false, 3, 8, 5, 5, 5>},
+    {1250, 256, 512, corr_rows_kernel<1250, 512, 1, 1, 5, 5, 5, 5, 2>, corr_rows_kernel<1250, 512, 3, 2, 5, 5, 5, 5, 2>,
+     xpower_rows_kernel<1250, 256, 2, false, 2, 5, 5, 5, 5>},
+    {200, 256, 256, corr_rows_kernel<200, 256, 1, 1, 5, 5, 8>, corr_rows_kernel<200, 256, 3, 2, 5, 5, 8>,
+     xpower_rows_kernel<200, 256, 2, false, 8, 5, 5>},
 };
 
 // ---- peak: first maximum of the fftShift-ed surface + 5x5 weighted centroid ----------------------
@@ -528,8 +747,9 @@ inline RealSrc src_f32(const float *p) { return RealSrc{p, nullptr, 0}; }
 inline RealSrc src_u16(const uint16_t *p, long pitch) { return RealSrc{nullptr, p, pitch}; }
 inline RealSrc src_none() { return RealSrc{nullptr, nullptr, 0}; }
 
-// forward transform of z = re + i im, the two f32 images read directly by the first pass
-int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, RealSrc im, int rows, int cols)
+// forward transform of z = re + i im, the two f32 images read directly by the first pass;
+// skip_rows: leave the row passes to the fused row-stage kernel
+int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, RealSrc im, int rows, int cols, bool skip_rows)
 {
     OipFftIo io;
     memset(&io, 0, sizeof io);
@@ -537,7 +757,7 @@ int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, 
     io.re = re.f32; io.re16 = re.u16; io.pitch_re16 = re.pitch16;
     io.im = im.f32; io.im16 = im.u16; io.pitch_im16 = im.pitch16;
     io.rows = rows; io.cols = cols;
-    return oip_fft2d_exec(ctx, pl, z, 0, &io);
+    return oip_fft2d_exec(ctx, pl, z, 0, &io, skip_rows ? 1 : 0);
 }
 
 int launch_xpower(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2dPlan *pl)
@@ -549,36 +769,82 @@ int launch_xpower(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2
     return OIP_OK;
 }
 
-// cross-power + inverse row pass in one kernel when the shape allows; *fused tells the caller
-// that the row passes of the inverse are done
-int launch_xpower_fused(oip_ctx *ctx, float2 *out, const XpowerJob &job, const OipFft2dPlan *pl, bool *fused)
+// How the row stage runs for this plan: 2 = forward rows + cross-power + inverse rows in one kernel,
+// 1 = cross-power + inverse rows fused (forward rows as a separate pass), 0 = nothing fused.
+// OIP_FUSED_ROWS=0|1|2 is an experiment knob.
+struct RowStage {
+    const FusedRow *k;
+    int level;
+};
+RowStage row_stage(const OipFft2dPlan *pl)
 {
-    *fused = false;
-    static const char *env = getenv("OIP_NO_FUSED_XPOWER");              // experiment knob
-    if (env || pl->xf.size() != 1) return launch_xpower(ctx, out, job, pl);
+    static const char *env = getenv("OIP_FUSED_ROWS");
+    int level = env ? atoi(env) : 2;
+    RowStage rs{nullptr, 0};
+    if (level <= 0 || pl->xf.size() != 1) return rs;
     for (const FusedRow &k : kFusedRow)
-        if (k.F == pl->N) {
-            const float2 *twF;
-            int rc = oip_fft_table(ctx, k.F, &twF);
+        if (k.F == pl->N) { rs.k = &k; rs.level = level > 1 ? 2 : 1; }
+    return rs;
+}
+
+// Cross-power of ncorr (A, B) spectrum pairs into nout = ceil(ncorr / 2) arrays y[o] =
+// C(2o) + i C(2o+1), with whatever row-stage fusion the plan allows.  At most three distinct
+// spectra per call.
+int xpower_stage(oip_ctx *ctx, const OipFft2dPlan *pl, const RowStage &rs, const SpecRef *a, const SpecRef *b, int ncorr,
+                 float2 *const y[2])
+{
+    const int nout = (ncorr + 1) / 2;
+    if (!rs.k) {
+        for (int o = 0; o < nout; ++o) {
+            XpowerJob job;
+            memset(&job, 0, sizeof job);
+            job.ncorr = ncorr - 2 * o > 1 ? 2 : 1;
+            for (int c = 0; c < job.ncorr; ++c) { job.a[c] = a[2 * o + c]; job.b[c] = b[2 * o + c]; }
+            int rc = launch_xpower(ctx, y[o], job, pl);
             if (rc) return rc;
-            FusedJob fj;
-            memset(&fj, 0, sizeof fj);
-            fj.ncorr = job.ncorr;
-            auto slot = [&](const float2 *z) {
-                for (int i = 0; i < fj.narr; ++i) if (fj.z[i] == z) return i;
-                fj.z[fj.narr] = z;
-                return fj.narr++;
-            };
-            fj.ia0 = slot(job.a[0].z); fj.ib0 = slot(job.b[0].z); fj.pa0 = job.a[0].part; fj.pb0 = job.b[0].part;
-            if (job.ncorr > 1) { fj.ia1 = slot(job.a[1].z); fj.ib1 = slot(job.b[1].z); fj.pa1 = job.a[1].part; fj.pb1 = job.b[1].part; }
-            OipProfScope prof(ctx, "xpower_inverse_row_kernel");
-            hipLaunchKernelGGL(k.fn, dim3(pl->M / 2 + 1), dim3(k.threads), 0, ctx->stream, out, fj, pl->M, pl->P,
-                               digits_of(pl->yf, pl->M), twF);
-            OIP_HIP(ctx, hipGetLastError());
-            *fused = true;
-            return OIP_OK;
         }
-    return launch_xpower(ctx, out, job, pl);
+        return OIP_OK;
+    }
+    const float2 *twF;
+    int rc = oip_fft_table(ctx, rs.k->F, &twF);
+    if (rc) return rc;
+    FusedJob fj;
+    memset(&fj, 0, sizeof fj);
+    fj.nout = nout;
+    auto slot = [&](const float2 *z) {
+        for (int i = 0; i < fj.narr; ++i) if (fj.z[i] == z) return i;
+        if (fj.narr == 3) return -1;
+        fj.z[fj.narr] = z;
+        return fj.narr++;
+    };
+    for (int c = 0; c < ncorr; ++c) {
+        fj.ia[c] = slot(a[c].z); fj.pa[c] = a[c].part;
+        fj.ib[c] = slot(b[c].z); fj.pb[c] = b[c].part;
+        if (fj.ia[c] < 0 || fj.ib[c] < 0) return oip_fail(ctx, OIP_E_RUNTIME, "xpower_stage: more than three spectra");
+        fj.ncorr[c / 2]++;
+    }
+    for (int o = 0; o < nout; ++o) fj.out[o] = y[o];
+    { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
+    if (rs.level == 2) {
+        // persistent: as many workgroups as fit the CUs at once (LDS- or thread-limited)
+        const bool one = fj.narr == 1 && fj.nout == 1, three = fj.narr == 3 && fj.nout == 2;
+        if (!one && !three) return oip_fail(ctx, OIP_E_RUNTIME, "xpower_stage: unsupported job shape");
+        const size_t lds = sizeof(float2) * ((size_t)fj.narr * 2 * rs.k->F + rs.k->F / 2);
+        long per_cu = (long)(160 * 1024 / lds);
+        if (per_cu > 2048 / rs.k->fwd_threads) per_cu = 2048 / rs.k->fwd_threads;
+        if (per_cu < 1) per_cu = 1;
+        long grid = (long)ctx->cu_count * per_cu;
+        if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
+        OipProfScope prof(ctx, "corr_rows_kernel");
+        hipLaunchKernelGGL(one ? rs.k->fwd1 : rs.k->fwd3, dim3((unsigned)grid), dim3(rs.k->fwd_threads), 0, ctx->stream, fj, pl->M,
+                           pl->P, digits_of(pl->yf, pl->M), twF);
+    } else {
+        OipProfScope prof(ctx, "xpower_rows_kernel");
+        hipLaunchKernelGGL(rs.k->inv, dim3(pl->M / 2 + 1), dim3(rs.k->threads), 0, ctx->stream, fj, pl->M, pl->P,
+                           digits_of(pl->yf, pl->M), twF);
+    }
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
 }
 
 // inverse transform of y whose last pass only leaves per-tile maxima, then for each wanted part:
@@ -618,74 +884,57 @@ int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, flo
 int correlate_pair(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, RealSrc b, int rows,
                    int cols, double *d_result)
 {
-    int rc = forward_packed(ctx, pl, w.z[0], a, b, rows, cols);
+    const RowStage rs = row_stage(pl);
+    int rc = forward_packed(ctx, pl, w.z[0], a, b, rows, cols, rs.level == 2);
     if (rc) return rc;
-    XpowerJob job;
-    memset(&job, 0, sizeof job);
-    job.ncorr = 1;
-    job.a[0] = {w.z[0], 0};
-    job.b[0] = {w.z[0], 1};
-    bool fused;
-    if ((rc = launch_xpower_fused(ctx, w.y[0], job, pl, &fused))) return rc;
-    return inverse_and_peaks(ctx, pl, w, w.y[0], 1, d_result, fused);
+    const SpecRef sa[1] = {{w.z[0], 0}}, sb[1] = {{w.z[0], 1}};
+    float2 *const y[2] = {w.y[0], nullptr};
+    if ((rc = xpower_stage(ctx, pl, rs, sa, sb, 1, y))) return rc;
+    return inverse_and_peaks(ctx, pl, w, w.y[0], 1, d_result, rs.k != nullptr);
+}
+
+// base image (real slot of zp) against (imag slot of zp, both slots of zq, slot `last_part` of zl)
+int correlate_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, const RowStage &rs, float2 *zp, float2 *zq,
+                   float2 *zl, int last_part, double *d_results /* 4 x 3 */)
+{
+    const SpecRef sa[4] = {{zp, 0}, {zp, 0}, {zp, 0}, {zp, 0}};
+    const SpecRef sb[4] = {{zp, 1}, {zq, 0}, {zq, 1}, {zl, last_part}};
+    float2 *const y[2] = {w.y[0], w.y[1]};
+    int rc;
+    if ((rc = xpower_stage(ctx, pl, rs, sa, sb, 4, y))) return rc;
+    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results, rs.k != nullptr))) return rc;
+    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, rs.k != nullptr);
 }
 
 // base image a against four images b0..b3: 3 forward + 2 inverse complex transforms
 int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, float *const b[4],
                           int rows, int cols, double *d_results /* 4 x 3 */)
 {
+    const RowStage rs = row_stage(pl);
+    const bool skip = rs.level == 2;
     int rc;
-    if ((rc = forward_packed(ctx, pl, w.z[0], a, src_f32(b[0]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(b[1]), src_f32(b[2]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[2], src_f32(b[3]), src_none(), rows, cols))) return rc;
-    XpowerJob j0, j1;
-    memset(&j0, 0, sizeof j0);
-    memset(&j1, 0, sizeof j1);
-    j0.ncorr = 2;
-    j0.a[0] = {w.z[0], 0}; j0.b[0] = {w.z[0], 1};
-    j0.a[1] = {w.z[0], 0}; j0.b[1] = {w.z[1], 0};
-    j1.ncorr = 2;
-    j1.a[0] = {w.z[0], 0}; j1.b[0] = {w.z[1], 1};
-    j1.a[1] = {w.z[0], 0}; j1.b[1] = {w.z[2], 0};
-    bool f0, f1;
-    if ((rc = launch_xpower_fused(ctx, w.y[0], j0, pl, &f0))) return rc;
-    if ((rc = launch_xpower_fused(ctx, w.y[1], j1, pl, &f1))) return rc;
-    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results, f0))) return rc;
-    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, f1);
+    if ((rc = forward_packed(ctx, pl, w.z[0], a, src_f32(b[0]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(b[1]), src_f32(b[2]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], src_f32(b[3]), src_none(), rows, cols, skip))) return rc;
+    return correlate_four(ctx, pl, w, rs, w.z[0], w.z[1], w.z[2], 0, d_results);
 }
 
 // Two units (base image + four bands each) at once: the fourth bands of the two units share one
 // complex transform (b3 of unit A in the real slot, b3 of unit B in the imaginary slot), so the
-// pair costs 5 forward transforms instead of 6.  4 x 2 fused cross-power / inverse passes.
+// pair costs 5 forward transforms instead of 6.
 int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc aA, float *const bA[4], RealSrc aB,
                         float *const bB[4], int rows, int cols, double *d_resA /* 4 x 3 */, double *d_resB)
 {
+    const RowStage rs = row_stage(pl);
+    const bool skip = rs.level == 2;
     int rc;
-    if ((rc = forward_packed(ctx, pl, w.z[0], aA, src_f32(bA[0]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(bA[1]), src_f32(bA[2]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[2], aB, src_f32(bB[0]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[3], src_f32(bB[1]), src_f32(bB[2]), rows, cols))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[4], src_f32(bA[3]), src_f32(bB[3]), rows, cols))) return rc;
-    for (int unit = 0; unit < 2; ++unit) {
-        float2 *zp = unit ? w.z[2] : w.z[0];          // (pan, b0)
-        float2 *zq = unit ? w.z[3] : w.z[1];          // (b1, b2)
-        XpowerJob j0, j1;
-        memset(&j0, 0, sizeof j0);
-        memset(&j1, 0, sizeof j1);
-        j0.ncorr = 2;
-        j0.a[0] = {zp, 0}; j0.b[0] = {zp, 1};
-        j0.a[1] = {zp, 0}; j0.b[1] = {zq, 0};
-        j1.ncorr = 2;
-        j1.a[0] = {zp, 0}; j1.b[0] = {zq, 1};
-        j1.a[1] = {zp, 0}; j1.b[1] = {w.z[4], unit};
-        double *res = unit ? d_resB : d_resA;
-        bool f0, f1;
-        if ((rc = launch_xpower_fused(ctx, w.y[0], j0, pl, &f0))) return rc;
-        if ((rc = launch_xpower_fused(ctx, w.y[1], j1, pl, &f1))) return rc;
-        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, res, f0))) return rc;
-        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[1], 2, res + 6, f1))) return rc;
-    }
-    return OIP_OK;
+    if ((rc = forward_packed(ctx, pl, w.z[0], aA, src_f32(bA[0]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(bA[1]), src_f32(bA[2]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], aB, src_f32(bB[0]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[3], src_f32(bB[1]), src_f32(bB[2]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[4], src_f32(bA[3]), src_f32(bB[3]), rows, cols, skip))) return rc;
+    if ((rc = correlate_four(ctx, pl, w, rs, w.z[0], w.z[1], w.z[4], 0, d_resA))) return rc;
+    return correlate_four(ctx, pl, w, rs, w.z[2], w.z[3], w.z[4], 1, d_resB);
 }
 
 int fetch_results(oip_ctx *ctx, int count, double *host_out)

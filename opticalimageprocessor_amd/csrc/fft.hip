@@ -183,9 +183,11 @@ __device__ void store_peak(const float2 *buf, int Vp, const OipFftPass &p, const
 }
 
 // store_kind 2: which tile holds window element w of the 5x5 window around the peak
-__device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo &io, int w, Tile *t, int *n0, int *v0)
+__device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo &io, int blk, Tile *t, int *n0, int *v0)
 {
-    const long key = *io.peak_key;
+    // block = 25 * part + w: the windows of all parts of one array go in a single launch
+    const int w = blk % 25;
+    const long key = io.peak_key[blk / 25];
     const int py = (int)(key / p.N), px = (int)(key - (long)py * p.N);
     const int ys = py - 2 + w / 5, xs = px - 2 + w % 5;
     if (ys < 0 || ys >= p.M || xs < 0 || xs >= p.N) return false;     // weightedCentroid clamps the window
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
     int wn0 = 0, wv0 = 0;
     if (io.store_kind == 2) {
         if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
-            if (threadIdx.x == 0) io.window[blockIdx.x] = NAN;
+            if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
     } else {
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
     if (io.store_kind == 2) {
         if (threadIdx.x == 0) {
             float2 z = bufA[wn0 * Vp + wv0];
-            io.window[blockIdx.x] = io.part ? -z.y : z.x;
+            io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = (blockIdx.x / 25) ? -z.y : z.x;
         }
         return;
     }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
     int wn0 = 0, wv0 = 0;
     if (io.store_kind == 2) {
         if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
-            if (threadIdx.x == 0) io.window[blockIdx.x] = NAN;
+            if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
     } else {
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
         } else if (io.store_kind == 2) {
             if (threadIdx.x == 0) {
                 float2 z = buf[wn0 * Vp + wv0];
-                io.window[blockIdx.x] = io.part ? -z.y : z.x;
+                io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = (blockIdx.x / 25) ? -z.y : z.x;
             }
         } else {
             for (int e = threadIdx.x; e < TOTAL; e += kFftBlock) {
@@ -802,5 +804,5 @@ int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, const O
     use.peak_key = io->peak_key;
     use.window = io->window;
     use.part = io->part;
-    return launch_pass(ctx, data, pl->passes[0], 1, use, 25);
+    return launch_pass(ctx, data, pl->passes[0], 1, use, 25L * (io->part > 0 ? io->part : 1));
 }

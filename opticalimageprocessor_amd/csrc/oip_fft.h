@@ -28,7 +28,7 @@ struct OipFftIo {
     OipPeakPartial *partials;   // store_kind 1: [2][grid] (real part, imaginary part)
     const long *peak_key;       // store_kind 2: shifted key of the peak (device)
     float *window;              // store_kind 2: [25] values, row-major dy,dx (NaN = outside image)
-    int part;                   // store_kind 2: 0 real / 1 imaginary part of the surface
+    int part;                   // store_kind 2: number of parts (1: real surface only, 2: real and imaginary), 25 tiles each
 };
 
 struct OipFftPass {

@@ -555,6 +555,8 @@ __global__ __launch_bounds__(kPeakBlock) void peak_final_kernel(const OipPeakPar
 {
     __shared__ float sval[kPeakBlock];
     __shared__ long skey[kPeakBlock];
+    partials += (size_t)blockIdx.x * npart;          // one block per part
+    key_out += blockIdx.x;
     float bv = -INFINITY;
     long bk = mn;
     for (int i = threadIdx.x; i < npart; i += kPeakBlock)
@@ -577,7 +579,10 @@ __global__ __launch_bounds__(kPeakBlock) void peak_final_kernel(const OipPeakPar
 __global__ void centroid_kernel(const float *__restrict__ window, const long *__restrict__ key, int M, int N,
                                 double *__restrict__ result)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
+    window += 32 * blockIdx.x;                       // one block per part
+    key += blockIdx.x;
+    result += 3 * blockIdx.x;
     const int py = (int)(*key / N), px = (int)(*key - (long)py * N);
     double cxs = 0.0, cys = 0.0, si = 0.0;
     for (int dy = 0; dy < 5; ++dy)
@@ -858,25 +863,23 @@ int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, flo
     io.partials = w.partials;
     int rc = oip_fft2d_exec(ctx, pl, y, 1, &io, rows_done ? 1 : 0);
     if (rc) return rc;
-    for (int part = 0; part < nparts; ++part) {
-        {
-            OipProfScope prof(ctx, "peak_final_kernel");
-            hipLaunchKernelGGL(peak_final_kernel, dim3(1), dim3(kPeakBlock), 0, ctx->stream, w.partials + (size_t)part * w.npart,
-                               w.npart, (long)pl->M * pl->N, w.keys + part);
-        }
-        OipFftIo wio;
-        memset(&wio, 0, sizeof wio);
-        wio.peak_key = w.keys + part;
-        wio.window = w.window + 32 * part;
-        wio.part = part;
-        if ((rc = oip_fft2d_window(ctx, pl, y, &wio))) return rc;
-        {
-            OipProfScope prof(ctx, "centroid_kernel");
-            hipLaunchKernelGGL(centroid_kernel, dim3(1), dim3(64), 0, ctx->stream, w.window + 32 * part, w.keys + part,
-                               pl->M, pl->N, d_results + 3 * part);
-        }
-        OIP_HIP(ctx, hipGetLastError());
+    // all parts (the real and imaginary surface of y) in one launch each
+    {
+        OipProfScope prof(ctx, "peak_final_kernel");
+        hipLaunchKernelGGL(peak_final_kernel, dim3(nparts), dim3(kPeakBlock), 0, ctx->stream, w.partials, w.npart,
+                           (long)pl->M * pl->N, w.keys);
     }
+    OipFftIo wio;
+    memset(&wio, 0, sizeof wio);
+    wio.peak_key = w.keys;
+    wio.window = w.window;
+    wio.part = nparts;
+    if ((rc = oip_fft2d_window(ctx, pl, y, &wio))) return rc;
+    {
+        OipProfScope prof(ctx, "centroid_kernel");
+        hipLaunchKernelGGL(centroid_kernel, dim3(nparts), dim3(64), 0, ctx->stream, w.window, w.keys, pl->M, pl->N, d_results);
+    }
+    OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
 

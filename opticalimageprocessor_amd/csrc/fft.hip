@@ -106,6 +106,26 @@ __device__ __forceinline__ void elem_coord(const OipFftPass &p, const Tile &t, i
     }
 }
 
+// horizontal four cubic taps on an image whose vertical up-sampling is already done: the four
+// values sit in one 16- or 28-byte run of row y, so a 16-lane tile row reads a single cache line
+__device__ __forceinline__ float hresize_tap(const float *__restrict__ V, const OipFftIo &io, int y, int x)
+{
+    const int sx = io.xofs[x];
+    const float4 a = reinterpret_cast<const float4 *>(io.alpha)[x];
+    const int last = io.v_cols - 1;
+    int c0 = sx - 1, c1 = sx, c2 = sx + 1, c3 = sx + 2;
+    c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+    c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+    c2 = c2 < 0 ? 0 : (c2 > last ? last : c2);
+    c3 = c3 < 0 ? 0 : (c3 > last ? last : c3);
+    const float *row = V + (size_t)y * io.v_cols;
+    float v = __fmul_rn(row[c0], a.x);
+    v = __fadd_rn(v, __fmul_rn(row[c1], a.y));
+    v = __fadd_rn(v, __fmul_rn(row[c2], a.z));
+    v = __fadd_rn(v, __fmul_rn(row[c3], a.w));
+    return v;
+}
+
 __device__ __forceinline__ float2 load_elem(const float2 *__restrict__ data, const OipFftPass &p, const OipFftIo &io,
                                             const Tile &t, int n, int v, long off)
 {
@@ -117,8 +137,10 @@ __device__ __forceinline__ float2 load_elem(const float2 *__restrict__ data, con
         const size_t i = (size_t)y * io.cols + x;
         if (io.re) z.x = io.re[i];
         else if (io.re16) z.x = (float)io.re16[(size_t)y * io.pitch_re16 + x];
+        else if (io.re_v) z.x = hresize_tap(io.re_v, io, y, x);
         if (io.im) z.y = io.im[i];
         else if (io.im16) z.y = (float)io.im16[(size_t)y * io.pitch_im16 + x];
+        else if (io.im_v) z.y = hresize_tap(io.im_v, io, y, x);
     }
     return z;
 }
@@ -324,8 +346,10 @@ __device__ __forceinline__ float2 load_elem_raw(const float2 *__restrict__ data,
         const size_t i = (size_t)y * io.cols + x;
         if (io.re) z.x = io.re[i];
         else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+        else if (io.re_v) z.x = hresize_tap(io.re_v, io, y, x);
         if (io.im) z.y = io.im[i];
         else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+        else if (io.im_v) z.y = hresize_tap(io.im_v, io, y, x);
     }
     return z;
 }
@@ -334,7 +358,11 @@ __device__ __forceinline__ float2 load_elem_raw(const float2 *__restrict__ data,
 // NEXT tile into registers right after the current tile has been committed to LDS, so they are
 // in flight while the butterflies run.  It costs ~50 VGPRs; measured on MI355X it pays for the
 // 128-point column pass (5.1 TB/s) and loses occupancy elsewhere, so it is a per-kernel choice.
-template <int F, int VS, int MODE, int NT, bool PERSIST, int... Rs>
+// IOK 0: plain pass (complex array in, complex array out); 1: fused loader (io.load_kind 1), plain
+// store; 2: plain load, fused store (io.store_kind 1 or 2).  Separate instantiations because the
+// kernel arguments of the fusions cost scalar registers -- past 100 a wave of occupancy goes, and
+// these passes are latency-bound enough to lose 15-20 % with it.
+template <int F, int VS, int MODE, int NT, bool PERSIST, int IOK, int... Rs>
 __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
                                                          const float2 *__restrict__ twF,
                                                          const float2 *__restrict__ twT)
@@ -350,12 +378,12 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
     __shared__ float2 twj[MODE == 0 ? F : 1];       // inter-pass twiddles of this tile (column passes)
     static_assert(sizeof(float2) * F * Vp >= kFftBlock * 12 + 16, "tile too small to host the reduction scratch");
 
-    const long ntiles = io.store_kind == 2 ? gridDim.x : p.ntiles;
+    const long ntiles = (IOK == 2 && io.store_kind == 2) ? gridDim.x : p.ntiles;
     long tile = blockIdx.x;
     if (tile >= ntiles) return;
     Tile t;
     int wn0 = 0, wv0 = 0;
-    if (io.store_kind == 2) {
+    if ((IOK == 2 && io.store_kind == 2)) {
         if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
             if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
@@ -364,11 +392,113 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
         t = decode_tile(p, tile);
     }
     const bool tile_tw = MODE == 0 && p.tw_mode == 2;
-    const bool raw_re16 = io.load_kind == 1 && !io.re && io.re16;
-    const bool raw_im16 = io.load_kind == 1 && !io.im && io.im16;
+    const bool raw_re16 = (IOK == 1 && io.load_kind == 1) && !io.re && io.re16;
+    const bool raw_im16 = (IOK == 1 && io.load_kind == 1) && !io.im && io.im16;
 
     float2 zz[NLD];
     auto issue_loads = [&](const Tile &tt) {
+        if (IOK == 1 && MODE == 0 && kFftBlock % V == 0 && (io.re_v || io.im_v) && p.axis == 1) {
+            // Fused loader with horizontal cubic taps: a thread's elements all sit in one image
+            // column x, so the four clamped source columns and weights are formed once.
+            const int v = threadIdx.x & (V - 1);
+            const int x = tt.lane0 + v;
+            const bool xin = v < tt.nv && x < io.cols;
+            int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xin) {
+                const int sx = io.xofs[x];
+                const int last = io.v_cols - 1;
+                a = reinterpret_cast<const float4 *>(io.alpha)[x];
+                c0 = sx - 1; c1 = sx; c2 = sx + 1; c3 = sx + 2;
+                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+                c2 = c2 < 0 ? 0 : (c2 > last ? last : c2);
+                c3 = c3 < 0 ? 0 : (c3 > last ? last : c3);
+            }
+            const int y0 = tt.o2 * p.T + tt.o1;
+            // The taps of a 16-lane tile row come from at most kSeg consecutive source columns
+            // (8 for the x4 geometry).  Staging those runs in LDS -- the tile buffer is still free --
+            // replaces four gathers per element and source by 1/4 staging load; per-lane gathers
+            // stay as the fall-back for wider footprints.
+            constexpr int kSeg = 8;
+            const int xl = tt.lane0, xr = tt.lane0 + tt.nv - 1 < io.cols - 1 ? tt.lane0 + tt.nv - 1 : io.cols - 1;
+            int cbase = 0, cend = -1;
+            if (xl < io.cols) {
+                const int lastc = io.v_cols - 1;
+                int f = io.xofs[xl] - 1, l = io.xofs[xr] + 2;
+                cbase = f < 0 ? 0 : (f > lastc ? lastc : f);
+                cend = l < 0 ? 0 : (l > lastc ? lastc : l);
+            }
+            const bool staged = cend - cbase < kSeg && F * kSeg * 2 * sizeof(float) <= sizeof(float2) * F * Vp;
+            if (staged) {
+                float *seg = reinterpret_cast<float *>(buf);            // [2][F][kSeg]
+                constexpr int PERS = (F * kSeg + kFftBlock - 1) / kFftBlock;
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const float *__restrict__ Vs = sl ? io.im_v : io.re_v;
+                    if (!Vs) continue;
+#pragma unroll
+                    for (int i = 0; i < PERS; ++i) {
+                        const int e = threadIdx.x + i * kFftBlock;
+                        const int n = e / kSeg, j = e % kSeg;
+                        const int y = y0 + n * p.S;
+                        if ((F * kSeg % kFftBlock == 0 || n < F) && y < io.rows) {
+                            const int c = cbase + j < io.v_cols ? cbase + j : io.v_cols - 1;
+                            seg[(sl * F + n) * kSeg + j] = Vs[(size_t)y * io.v_cols + c];
+                        }
+                    }
+                }
+                __syncthreads();
+                const int r0 = c0 - cbase, r1 = c1 - cbase, r2 = c2 - cbase, r3 = c3 - cbase;
+                auto taps = [&](const float *__restrict__ row) {
+                    float r = __fmul_rn(row[r0], a.x);
+                    r = __fadd_rn(r, __fmul_rn(row[r1], a.y));
+                    r = __fadd_rn(r, __fmul_rn(row[r2], a.z));
+                    r = __fadd_rn(r, __fmul_rn(row[r3], a.w));
+                    return r;
+                };
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int n = (threadIdx.x >> VS) + i * (kFftBlock >> VS);
+                    const int y = y0 + n * p.S;
+                    float2 z = make_float2(0.f, 0.f);
+                    if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
+                        if (io.re_v) z.x = taps(seg + n * kSeg);
+                        else if (io.re) z.x = io.re[(size_t)y * io.cols + x];
+                        else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+                        if (io.im_v) z.y = taps(seg + (F + n) * kSeg);
+                        else if (io.im) z.y = io.im[(size_t)y * io.cols + x];
+                        else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+                    }
+                    zz[i] = z;
+                }
+                __syncthreads();            // the staging area is the tile buffer the commit overwrites
+                return;
+            }
+            auto taps = [&](const float *__restrict__ row) {
+                float r = __fmul_rn(row[c0], a.x);
+                r = __fadd_rn(r, __fmul_rn(row[c1], a.y));
+                r = __fadd_rn(r, __fmul_rn(row[c2], a.z));
+                r = __fadd_rn(r, __fmul_rn(row[c3], a.w));
+                return r;
+            };
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int n = (threadIdx.x >> VS) + i * (kFftBlock >> VS);
+                const int y = y0 + n * p.S;
+                float2 z = make_float2(0.f, 0.f);
+                if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
+                    if (io.re_v) z.x = taps(io.re_v + (size_t)y * io.v_cols);
+                    else if (io.re) z.x = io.re[(size_t)y * io.cols + x];
+                    else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+                    if (io.im_v) z.y = taps(io.im_v + (size_t)y * io.v_cols);
+                    else if (io.im) z.y = io.im[(size_t)y * io.cols + x];
+                    else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+                }
+                zz[i] = z;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = threadIdx.x + i * kFftBlock;
@@ -377,7 +507,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             zz[i] = make_float2(0.f, 0.f);
             if ((TOTAL % kFftBlock == 0 || e < TOTAL) && v < tt.nv) {
                 const long off = MODE == 0 ? tt.base + (long)n * p.nstride + v : vec_offset(p, tt, n, v);
-                zz[i] = load_elem_raw(data, p, io, tt, n, v, off);
+                zz[i] = IOK == 1 ? load_elem_raw(data, p, io, tt, n, v, off) : data[off];
             }
         }
     };
@@ -419,11 +549,11 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 
         Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw);
 
-        if (io.store_kind == 1) {
+        if ((IOK == 2 && io.store_kind == 1)) {
             // the scan of the tile ends (barrier inside store_peak) before the scratch is written
             store_peak(buf, Vp, p, io, t, reinterpret_cast<float *>(buf + kFftBlock), reinterpret_cast<long *>(buf), t.gtile,
                        p.total_tiles, NT);
-        } else if (io.store_kind == 2) {
+        } else if ((IOK == 2 && io.store_kind == 2)) {
             if (threadIdx.x == 0) {
                 float2 z = buf[wn0 * Vp + wv0];
                 io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = (blockIdx.x / 25) ? -z.y : z.x;
@@ -452,24 +582,24 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 struct FastKernel {
     int F, vshift, mode, threads;
     bool persist;
-    void (*fn)(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);
+    void (*fn[3])(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);         // by IOK: plain, fused load, fused store
 };
 const FastKernel kFast[] = {
     // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors): 16 lanes = 128-byte
     // segments, 17 KiB of LDS per workgroup -> 8 workgroups per CU (measured faster than 32 lanes)
-    {125, 4, 0, 256, false, fft_pass_ct_kernel<125, 4, 0, 256, false, 5, 5, 5>},
-    {128, 4, 0, 256, false, fft_pass_ct_kernel<128, 4, 0, 256, false, 8, 4, 4>},
-    {125, 5, 0, 256, false, fft_pass_ct_kernel<125, 5, 0, 256, false, 5, 5, 5>},
-    {128, 5, 0, 256, false, fft_pass_ct_kernel<128, 5, 0, 256, false, 8, 4, 4>},
-    {100, 4, 0, 256, false, fft_pass_ct_kernel<100, 4, 0, 256, false, 4, 5, 5>},
-    {160, 4, 0, 256, false, fft_pass_ct_kernel<160, 4, 0, 256, false, 4, 8, 5>},
-    {64, 5, 0, 256, false, fft_pass_ct_kernel<64, 5, 0, 256, false, 4, 4, 4>},
+    {125, 4, 0, 256, false, {fft_pass_ct_kernel<125, 4, 0, 256, false, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, false, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, false, 2, 5, 5, 5>}},
+    {128, 4, 0, 256, false, {fft_pass_ct_kernel<128, 4, 0, 256, false, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, false, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, false, 2, 8, 4, 4>}},
+    {125, 5, 0, 256, false, {fft_pass_ct_kernel<125, 5, 0, 256, false, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, false, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, false, 2, 5, 5, 5>}},
+    {128, 5, 0, 256, false, {fft_pass_ct_kernel<128, 5, 0, 256, false, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, false, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, false, 2, 8, 4, 4>}},
+    {100, 4, 0, 256, false, {fft_pass_ct_kernel<100, 4, 0, 256, false, 0, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, false, 1, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, false, 2, 4, 5, 5>}},
+    {160, 4, 0, 256, false, {fft_pass_ct_kernel<160, 4, 0, 256, false, 0, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, false, 1, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, false, 2, 4, 8, 5>}},
+    {64, 5, 0, 256, false, {fft_pass_ct_kernel<64, 5, 0, 256, false, 0, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, false, 1, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, false, 2, 4, 4, 4>}},
     // row passes: 30000/10, 12288/10 -> 1250, the 200-column stitch overlap
-    {3000, 1, 1, 512, false, fft_pass_ct_kernel<3000, 1, 1, 512, false, 3, 8, 5, 5, 5>},
-    {3000, 0, 1, 512, false, fft_pass_ct_kernel<3000, 0, 1, 512, false, 3, 8, 5, 5, 5>},
-    {3000, 0, 1, 256, false, fft_pass_ct_kernel<3000, 0, 1, 256, false, 3, 8, 5, 5, 5>},
-    {1250, 1, 1, 256, false, fft_pass_ct_kernel<1250, 1, 1, 256, false, 2, 5, 5, 5, 5>},
-    {200, 4, 1, 256, false, fft_pass_ct_kernel<200, 4, 1, 256, false, 8, 5, 5>},
+    {3000, 1, 1, 512, false, {fft_pass_ct_kernel<3000, 1, 1, 512, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, false, 2, 3, 8, 5, 5, 5>}},
+    {3000, 0, 1, 512, false, {fft_pass_ct_kernel<3000, 0, 1, 512, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, false, 2, 3, 8, 5, 5, 5>}},
+    {3000, 0, 1, 256, false, {fft_pass_ct_kernel<3000, 0, 1, 256, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, false, 2, 3, 8, 5, 5, 5>}},
+    {1250, 1, 1, 256, false, {fft_pass_ct_kernel<1250, 1, 1, 256, false, 0, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, false, 1, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, false, 2, 2, 5, 5, 5, 5>}},
+    {200, 4, 1, 256, false, {fft_pass_ct_kernel<200, 4, 1, 256, false, 0, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, false, 1, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, false, 2, 8, 5, 5>}},
 };
 constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
@@ -727,7 +857,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
             const long cap = (long)ctx->cu_count * (envg ? atoi(envg) : 8);
             if (grid > cap) grid = cap;
         }
-        hipLaunchKernelGGL(kFast[p.fast].fn, dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
+        hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
         hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);

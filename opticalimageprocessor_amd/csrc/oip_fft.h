@@ -22,6 +22,14 @@ struct OipFftIo {
     const uint16_t *re16;   // ... or a u16 raster window (pointer at its first pixel, own pitch)
     const uint16_t *im16;
     long pitch_re16, pitch_im16;
+    // ... or an image that is only vertically up-sampled so far: V is rows x v_cols f32 (pitch ==
+    // v_cols) and the loader applies the horizontal four cubic taps
+    // value(y, x) = sum_j alpha[x][j] * V[y][clamp(xofs[x] - 1 + j)]
+    const float *re_v;
+    const float *im_v;
+    int v_cols;
+    const int *xofs;
+    const float *alpha; // [cols][4]
     int rows, cols;     // extent of the real images
     int store_kind;     // 0: the complex array; 1: peak partials only (nothing stored);
                         // 2: 5x5 window around a known peak (25 workgroups, nothing else stored)

@@ -85,6 +85,40 @@ __global__ __launch_bounds__(kBlock) void resize_cubic_kernel(const SrcT *__rest
     dst[(size_t)dy * dw + dx] = o;
 }
 
+// Vertical half of the cubic up-sampling only: V[dy][x] = sum_k beta[dy][k] * S[clamp(yofs[dy] - 1 + k)][x].
+// The horizontal half is applied by the loader of the first FFT pass (OipFftIo::re_v / im_v), so the
+// fully up-sampled image -- 16x the band window -- never exists in memory; V is 4x the window, written
+// once and read once.  cv::resize interpolates horizontally first; doing the vertical taps first
+// changes the f32 rounding of an output by an ulp or so, far inside what the FFT's own round-off
+// already does to the correlation (the separate oip_resize_cubic_f32 entry keeps cv::resize's order
+// bit for bit).
+constexpr int kVRows = 4;       // output rows per thread of the vertical pass (they share most source rows)
+template <typename SrcT>
+__global__ __launch_bounds__(kBlock) void resize_cubic_v_kernel(const SrcT *__restrict__ src, long spitch, int sw, int sh,
+                                                                float *__restrict__ dst, int dh,
+                                                                const int *__restrict__ yofs, const float4 *__restrict__ beta)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    if (x >= sw) return;
+#pragma unroll
+    for (int j = 0; j < kVRows; ++j) {
+        const int dy = blockIdx.y * kVRows + j;
+        if (dy >= dh) break;
+        const int sy = yofs[dy];
+        const float4 b = beta[dy];
+        int y0 = sy - 1, y1 = sy, y2 = sy + 1, y3 = sy + 2;
+        y0 = y0 < 0 ? 0 : (y0 > sh - 1 ? sh - 1 : y0);
+        y1 = y1 < 0 ? 0 : (y1 > sh - 1 ? sh - 1 : y1);
+        y2 = y2 < 0 ? 0 : (y2 > sh - 1 ? sh - 1 : y2);
+        y3 = y3 < 0 ? 0 : (y3 > sh - 1 ? sh - 1 : y3);
+        float v = __fmul_rn((float)src[(size_t)y0 * spitch + x], b.x);
+        v = __fadd_rn(v, __fmul_rn((float)src[(size_t)y1 * spitch + x], b.y));
+        v = __fadd_rn(v, __fmul_rn((float)src[(size_t)y2 * spitch + x], b.z));
+        v = __fadd_rn(v, __fmul_rn((float)src[(size_t)y3 * spitch + x], b.w));
+        dst[(size_t)dy * sw + x] = v;
+    }
+}
+
 // Exact x4 up-sampling (the reference geometry: MSS GSD = 4 x PAN GSD).  One lane owns one
 // source pixel (q, p) and produces its 4x4 block of outputs from the 5x5 source neighbourhood:
 // the four outputs of a row share their horizontal taps, the four rows share the horizontal
@@ -742,25 +776,53 @@ int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, fl
     return OIP_OK;
 }
 
+// vertical half only (see resize_cubic_v_kernel); *tab carries the horizontal taps for the FFT loader
+template <typename SrcT>
+int launch_resize_v(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, float *dst, int dw, int dh, const OipResizeTab **tab)
+{
+    int rc = resize_tables(ctx, sw, sh, dw, dh, tab);
+    if (rc) return rc;
+    OipProfScope prof(ctx, "resize_cubic_v_kernel");
+    hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows), dim3(kBlock), 0, ctx->stream, src, spitch,
+                       sw, sh, dst, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
+
 // one real image of a packed pair: an f32 image (pitch == cols) or a u16 raster window
 struct RealSrc {
     const float *f32;
     const uint16_t *u16;
     long pitch16;
+    const float *v;     // vertically up-sampled image; the horizontal taps are applied by the loader
 };
-inline RealSrc src_f32(const float *p) { return RealSrc{p, nullptr, 0}; }
-inline RealSrc src_u16(const uint16_t *p, long pitch) { return RealSrc{nullptr, p, pitch}; }
-inline RealSrc src_none() { return RealSrc{nullptr, nullptr, 0}; }
+inline RealSrc src_f32(const float *p) { return RealSrc{p, nullptr, 0, nullptr}; }
+inline RealSrc src_u16(const uint16_t *p, long pitch) { return RealSrc{nullptr, p, pitch, nullptr}; }
+inline RealSrc src_v(const float *p) { return RealSrc{nullptr, nullptr, 0, p}; }
+inline RealSrc src_none() { return RealSrc{nullptr, nullptr, 0, nullptr}; }
+
+// horizontal-tap tables of the V sources of a forward_packed call (all V sources of one call share them)
+struct HTaps {
+    int v_cols;
+    const int *xofs;
+    const float *alpha;
+};
 
 // forward transform of z = re + i im, the two f32 images read directly by the first pass;
 // skip_rows: leave the row passes to the fused row-stage kernel
-int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, RealSrc im, int rows, int cols, bool skip_rows)
+int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, RealSrc im, int rows, int cols, bool skip_rows,
+                   const HTaps *vt = nullptr)
 {
     OipFftIo io;
     memset(&io, 0, sizeof io);
     io.load_kind = 1;
     io.re = re.f32; io.re16 = re.u16; io.pitch_re16 = re.pitch16;
     io.im = im.f32; io.im16 = im.u16; io.pitch_im16 = im.pitch16;
+    if (re.v || im.v) {
+        if (!vt) return oip_fail(ctx, OIP_E_RUNTIME, "forward_packed: V source without horizontal taps");
+        io.re_v = re.v; io.im_v = im.v;
+        io.v_cols = vt->v_cols; io.xofs = vt->xofs; io.alpha = vt->alpha;
+    }
     io.rows = rows; io.cols = cols;
     return oip_fft2d_exec(ctx, pl, z, 0, &io, skip_rows ? 1 : 0);
 }
@@ -910,32 +972,32 @@ int correlate_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, const 
 }
 
 // base image a against four images b0..b3: 3 forward + 2 inverse complex transforms
-int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, float *const b[4],
-                          int rows, int cols, double *d_results /* 4 x 3 */)
+int correlate_one_to_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc a, const RealSrc b[4],
+                          int rows, int cols, double *d_results /* 4 x 3 */, const HTaps *vt)
 {
     const RowStage rs = row_stage(pl);
     const bool skip = rs.level == 2;
     int rc;
-    if ((rc = forward_packed(ctx, pl, w.z[0], a, src_f32(b[0]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(b[1]), src_f32(b[2]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[2], src_f32(b[3]), src_none(), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], a, b[0], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], b[1], b[2], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], b[3], src_none(), rows, cols, skip, vt))) return rc;
     return correlate_four(ctx, pl, w, rs, w.z[0], w.z[1], w.z[2], 0, d_results);
 }
 
 // Two units (base image + four bands each) at once: the fourth bands of the two units share one
 // complex transform (b3 of unit A in the real slot, b3 of unit B in the imaginary slot), so the
 // pair costs 5 forward transforms instead of 6.
-int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc aA, float *const bA[4], RealSrc aB,
-                        float *const bB[4], int rows, int cols, double *d_resA /* 4 x 3 */, double *d_resB)
+int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, RealSrc aA, const RealSrc bA[4], RealSrc aB,
+                        const RealSrc bB[4], int rows, int cols, double *d_resA /* 4 x 3 */, double *d_resB, const HTaps *vt)
 {
     const RowStage rs = row_stage(pl);
     const bool skip = rs.level == 2;
     int rc;
-    if ((rc = forward_packed(ctx, pl, w.z[0], aA, src_f32(bA[0]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[1], src_f32(bA[1]), src_f32(bA[2]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[2], aB, src_f32(bB[0]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[3], src_f32(bB[1]), src_f32(bB[2]), rows, cols, skip))) return rc;
-    if ((rc = forward_packed(ctx, pl, w.z[4], src_f32(bA[3]), src_f32(bB[3]), rows, cols, skip))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], aA, bA[0], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[1], bA[1], bA[2], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[2], aB, bB[0], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[3], bB[1], bB[2], rows, cols, skip, vt))) return rc;
+    if ((rc = forward_packed(ctx, pl, w.z[4], bA[3], bB[3], rows, cols, skip, vt))) return rc;
     if ((rc = correlate_four(ctx, pl, w, rs, w.z[0], w.z[1], w.z[4], 0, d_resA))) return rc;
     return correlate_four(ctx, pl, w, rs, w.z[2], w.z[3], w.z[4], 1, d_resB);
 }
@@ -1060,7 +1122,7 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, pl, baseRows, baseSliceCols, 0, 5, 2, 8, &w))) return rc;
+    if ((rc = carve(ctx, pl, baseRows, bandSliceCols, 0, 5, 2, 8, &w))) return rc;      // f32 scratch: the V images
     double *d_res = (double *)ctx->d_small;
     const int n = slices * sections;
     std::vector<int> have(n, 0);
@@ -1077,27 +1139,33 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
                                  secBandRowStart - mrow0, i});
         }
     }
-    // PAN window: read as u16 by the FFT loader; MSS windows: up-sampled x4 straight from u16
-    auto upsample = [&](const Unit &un, float *const fb[4]) -> int {
+    // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
+    // (u16 -> f32, baseRows x bandSliceCols), the horizontal pass inside the FFT loader.
+    const OipResizeTab *tab = nullptr;
+    auto upsample = [&](const Unit &un, float *const fb[4], RealSrc out[4]) -> int {
         for (int b = 0; b < OIP_MSS_BANDS; ++b) {
             const uint16_t *bw = d_planes + (size_t)b * plane_stride + (size_t)un.bandRow0 * Wb + (size_t)un.slice * bandSliceCols;
-            int rc2 = launch_resize<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, fb[b], baseSliceCols, baseRows);
+            int rc2 = launch_resize_v<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, fb[b], baseSliceCols, baseRows, &tab);
             if (rc2) return rc2;
+            out[b] = src_v(fb[b]);
         }
         return OIP_OK;
     };
     size_t k = 0;
+    RealSrc sA[4], sB[4];
     for (; k + 1 < units.size(); k += 2) {
         const Unit &A = units[k], &B = units[k + 1];
-        if ((rc = upsample(A, w.fb))) return rc;
-        if ((rc = upsample(B, w.fb + 4))) return rc;
-        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), w.fb, src_u16(B.pw, W), w.fb + 4, baseRows, baseSliceCols,
-                                      d_res + 12 * A.u, d_res + 12 * B.u))) return rc;
+        if ((rc = upsample(A, w.fb, sA))) return rc;
+        if ((rc = upsample(B, w.fb + 4, sB))) return rc;
+        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha};
+        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), sA, src_u16(B.pw, W), sB, baseRows, baseSliceCols,
+                                      d_res + 12 * A.u, d_res + 12 * B.u, &vt))) return rc;
     }
     if (k < units.size()) {
         const Unit &A = units[k];
-        if ((rc = upsample(A, w.fb))) return rc;
-        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), w.fb, baseRows, baseSliceCols, d_res + 12 * A.u))) return rc;
+        if ((rc = upsample(A, w.fb, sA))) return rc;
+        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha};
+        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), sA, baseRows, baseSliceCols, d_res + 12 * A.u, &vt))) return rc;
     }
     std::vector<double> r(12 * n);
     if ((rc = fetch_results(ctx, 12 * n, r.data()))) return rc;

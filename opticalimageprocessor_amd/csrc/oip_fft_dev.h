@@ -12,11 +12,46 @@ namespace oipfft {
 // -ffp-contract=off and every other kernel rounds after each multiply and add.
 #define OIP_FFT_FMA _Pragma("clang fp contract(fast)")
 
+// Complex helpers on packed-f32 instructions.  A float2 lives in a 64-bit register pair, and the
+// VOP3P modifiers pick (op_sel / op_sel_hi) and negate (neg_lo / neg_hi) the halves each result lane
+// reads, so a complex product is two instructions and "add i times" is one -- the compiler gets the
+// arithmetic right but builds the swapped operands with v_mov (a quarter of the VALU work of a stage).
+typedef float oip_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ oip_v2f to_v(float2 a) { oip_v2f r = {a.x, a.y}; return r; }
+__device__ __forceinline__ float2 to_f2(oip_v2f a) { return make_float2(a.x, a.y); }
+
+#ifndef OIP_FFT_NO_ASM
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    oip_v2f t, r;
+    // t = (a.x b.x, a.x b.y);  r = (-a.y b.y + t.x, a.y b.x + t.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(to_v(a)), "v"(to_v(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t));
+    return to_f2(r);
+}
+// m + (-i) u = (m.x + u.y, m.y - u.x)
+__device__ __forceinline__ float2 cadd_rot(float2 m, float2 u)
+{
+    oip_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(to_v(m)), "v"(to_v(u)));
+    return to_f2(r);
+}
+// m - (-i) u = (m.x - u.y, m.y + u.x)
+__device__ __forceinline__ float2 csub_rot(float2 m, float2 u)
+{
+    oip_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(to_v(m)), "v"(to_v(u)));
+    return to_f2(r);
+}
+#else
 __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     OIP_FFT_FMA
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
+__device__ __forceinline__ float2 cadd_rot(float2 m, float2 u) { return make_float2(m.x + u.y, m.y - u.x); }
+__device__ __forceinline__ float2 csub_rot(float2 m, float2 u) { return make_float2(m.x - u.y, m.y + u.x); }
+#endif
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmuli_neg(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
@@ -34,20 +69,20 @@ __device__ __forceinline__ void bf3(float2 *x)
     OIP_FFT_FMA
     const float s = 0.86602540378443864676f;
     float2 t = cadd(x[1], x[2]);
-    float2 d = cscale(cmuli_neg(csub(x[1], x[2])), s);
+    float2 d = cscale(csub(x[1], x[2]), s);
     float2 m = make_float2(x[0].x - 0.5f * t.x, x[0].y - 0.5f * t.y);
     x[0] = cadd(x[0], t);
-    x[1] = cadd(m, d);
-    x[2] = csub(m, d);
+    x[1] = cadd_rot(m, d);
+    x[2] = csub_rot(m, d);
 }
 __device__ __forceinline__ void bf4(float2 *x)
 {
     float2 s02 = cadd(x[0], x[2]), d02 = csub(x[0], x[2]);
-    float2 s13 = cadd(x[1], x[3]), d13 = cmuli_neg(csub(x[1], x[3]));
+    float2 s13 = cadd(x[1], x[3]), d13 = csub(x[1], x[3]);
     x[0] = cadd(s02, s13);
     x[2] = csub(s02, s13);
-    x[1] = cadd(d02, d13);
-    x[3] = csub(d02, d13);
+    x[1] = cadd_rot(d02, d13);
+    x[3] = csub_rot(d02, d13);
 }
 __device__ __forceinline__ void bf5(float2 *x)
 {
@@ -58,13 +93,13 @@ __device__ __forceinline__ void bf5(float2 *x)
     float2 t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
     float2 m1 = make_float2(x[0].x + c1 * t1.x + c2 * t2.x, x[0].y + c1 * t1.y + c2 * t2.y);
     float2 m2 = make_float2(x[0].x + c2 * t1.x + c1 * t2.x, x[0].y + c2 * t1.y + c1 * t2.y);
-    float2 u1 = cmuli_neg(make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));
-    float2 u2 = cmuli_neg(make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));
+    float2 u1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    float2 u2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
     x[0] = cadd(x[0], cadd(t1, t2));
-    x[1] = cadd(m1, u1);
-    x[4] = csub(m1, u1);
-    x[2] = cadd(m2, u2);
-    x[3] = csub(m2, u2);
+    x[1] = cadd_rot(m1, u1);
+    x[4] = csub_rot(m1, u1);
+    x[2] = cadd_rot(m2, u2);
+    x[3] = csub_rot(m2, u2);
 }
 __device__ __forceinline__ void bf8(float2 *x)
 {
@@ -74,14 +109,16 @@ __device__ __forceinline__ void bf8(float2 *x)
     float2 o[4] = {x[1], x[3], x[5], x[7]};
     bf4(e);
     bf4(o);
-    o[1] = make_float2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));      // * w8
-    o[2] = cmuli_neg(o[2]);                                                // * w8^2
-    o[3] = make_float2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));     // * w8^3
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        x[k] = cadd(e[k], o[k]);
-        x[k + 4] = csub(e[k], o[k]);
-    }
+    const float2 o1 = cscale(cadd_rot(o[1], o[1]), h);       // o1 * w8   = h (o.x + o.y, o.y - o.x)
+    const float2 o3 = cscale(csub_rot(o[3], o[3]), h);       // -o3 * w8^3 = h (o.x - o.y, o.x + o.y)
+    x[0] = cadd(e[0], o[0]);
+    x[4] = csub(e[0], o[0]);
+    x[1] = cadd(e[1], o1);
+    x[5] = csub(e[1], o1);
+    x[2] = cadd_rot(e[2], o[2]);                             // o2 * w8^2 = -i o2
+    x[6] = csub_rot(e[2], o[2]);
+    x[3] = csub(e[3], o3);
+    x[7] = cadd(e[3], o3);
 }
 template <int R> __device__ __forceinline__ void butterfly(float2 *x)
 {

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
             if (xin) {
-                const int sx = io.xofs[x];
+                const int sx = io.x4 ? (x - 2) >> 2 : io.xofs[x];
                 const int last = io.v_cols - 1;
                 a = reinterpret_cast<const float4 *>(io.alpha)[x];
                 c0 = sx - 1; c1 = sx; c2 = sx + 1; c3 = sx + 2;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             int cbase = 0, cend = -1;
             if (xl < io.cols) {
                 const int lastc = io.v_cols - 1;
-                int f = io.xofs[xl] - 1, l = io.xofs[xr] + 2;
+                int f = (io.x4 ? (xl - 2) >> 2 : io.xofs[xl]) - 1, l = (io.x4 ? (xr - 2) >> 2 : io.xofs[xr]) + 2;
                 cbase = f < 0 ? 0 : (f > lastc ? lastc : f);
                 cend = l < 0 ? 0 : (l > lastc ? lastc : l);
             }

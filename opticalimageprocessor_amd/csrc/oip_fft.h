@@ -30,6 +30,7 @@ struct OipFftIo {
     int v_cols;
     const int *xofs;
     const float *alpha; // [cols][4]
+    int x4;             // exact x4 geometry (host-verified): xofs[x] == (x - 2) >> 2, no table look-up needed
     int rows, cols;     // extent of the real images
     int store_kind;     // 0: the complex array; 1: peak partials only (nothing stored);
                         // 2: 5x5 window around a known peak (25 workgroups, nothing else stored)

@@ -28,6 +28,7 @@ struct oip_fft_state;   // fft.hip
 struct OipResizeTab {
     int sw, sh, dw, dh;
     bool x4;            // exact x4 up-sampling: the 4x4-per-lane kernel applies
+    int x4h;            // xofs[dx] == (dx - 2) >> 2 for every dx: the FFT loader needs no xofs look-up
     int *d_xofs;
     float *d_alpha;     // dw x 4
     int *d_yofs;

@@ -741,6 +741,8 @@ int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeT
     t.x4 = dw == 4 * sw && dh == 4 * sh;
     for (int dx = 0; dx < dw && t.x4; ++dx) { int o = (xofs[dx] - 1) - (dx / 4 - 2); t.x4 = o == 0 || o == 1; }
     for (int dy = 0; dy < dh && t.x4; ++dy) { int o = (yofs[dy] - 1) - (dy / 4 - 2); t.x4 = o == 0 || o == 1; }
+    t.x4h = 1;
+    for (int dx = 0; dx < dw && t.x4h; ++dx) t.x4h = xofs[dx] == ((dx - 2) >> 2);
     OIP_HIP(ctx, hipMalloc((void **)&t.d_xofs, sizeof(int) * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_alpha, sizeof(float) * 4 * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_yofs, sizeof(int) * dh));
@@ -806,6 +808,7 @@ struct HTaps {
     int v_cols;
     const int *xofs;
     const float *alpha;
+    int x4;
 };
 
 // forward transform of z = re + i im, the two f32 images read directly by the first pass;
@@ -821,7 +824,7 @@ int forward_packed(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *z, RealSrc re, 
     if (re.v || im.v) {
         if (!vt) return oip_fail(ctx, OIP_E_RUNTIME, "forward_packed: V source without horizontal taps");
         io.re_v = re.v; io.im_v = im.v;
-        io.v_cols = vt->v_cols; io.xofs = vt->xofs; io.alpha = vt->alpha;
+        io.v_cols = vt->v_cols; io.xofs = vt->xofs; io.alpha = vt->alpha; io.x4 = vt->x4;
     }
     io.rows = rows; io.cols = cols;
     return oip_fft2d_exec(ctx, pl, z, 0, &io, skip_rows ? 1 : 0);
@@ -1157,14 +1160,14 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
         const Unit &A = units[k], &B = units[k + 1];
         if ((rc = upsample(A, w.fb, sA))) return rc;
         if ((rc = upsample(B, w.fb + 4, sB))) return rc;
-        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha};
+        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
         if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), sA, src_u16(B.pw, W), sB, baseRows, baseSliceCols,
                                       d_res + 12 * A.u, d_res + 12 * B.u, &vt))) return rc;
     }
     if (k < units.size()) {
         const Unit &A = units[k];
         if ((rc = upsample(A, w.fb, sA))) return rc;
-        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha};
+        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
         if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), sA, baseRows, baseSliceCols, d_res + 12 * A.u, &vt))) return rc;
     }
     std::vector<double> r(12 * n);

@@ -61,11 +61,22 @@ __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
     Tile t;
     const int V = 1 << p.vshift;
     if (p.mode == 0) {
-        const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;          // lane-tile window of this launch (column panel)
-        const int lt = p.lt0 + (int)(bid % ltn);
-        const long rest = bid / ltn;
-        t.o1 = (int)(rest % p.O1);
-        t.o2 = (int)(rest / p.O1);
+        int lt;
+        long rest;
+        if (p.grid3) {
+            // (lane tile, o1, o2) straight from the grid: two 64-bit divisions by run-time values are
+            // ~150 scalar instructions, and these passes issue about as many scalar as vector ones
+            lt = p.lt0 + blockIdx.x;
+            t.o1 = blockIdx.y;
+            t.o2 = blockIdx.z;
+            rest = (long)(t.o2 * p.O1 + t.o1);
+        } else {
+            const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;      // lane-tile window of this launch (column panel)
+            lt = p.lt0 + (int)(bid % ltn);
+            rest = bid / ltn;
+            t.o1 = (int)(rest % p.O1);
+            t.o2 = (int)(rest / p.O1);
+        }
         t.gtile = rest * p.lane_tiles + lt;
         t.lane0 = lt << p.vshift;
         t.nv = p.lanes - t.lane0 < V ? (int)(p.lanes - t.lane0) : V;
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 
     const long ntiles = (IOK == 2 && io.store_kind == 2) ? gridDim.x : p.ntiles;
     long tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    if (!(MODE == 0 && !PERSIST) && tile >= ntiles) return;
     Tile t;
     int wn0 = 0, wv0 = 0;
     if ((IOK == 2 && io.store_kind == 2)) {
@@ -388,6 +399,10 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
+    } else if (MODE == 0 && !PERSIST) {
+        OipFftPass pg = p;
+        pg.grid3 = 1;                  // launch_pass always gives non-persistent mode-0 passes the 3-D grid
+        t = decode_tile(pg, 0);
     } else {
         t = decode_tile(p, tile);
     }
@@ -433,6 +448,23 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             if (staged) {
                 float *seg = reinterpret_cast<float *>(buf);            // [2][F][kSeg]
                 constexpr int PERS = (F * kSeg + kFftBlock - 1) / kFftBlock;
+                // directly readable components first: their loads and the staging loads below are
+                // then one round of memory latency, not two
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int n = (threadIdx.x >> VS) + i * (kFftBlock >> VS);
+                    const int y = y0 + n * p.S;
+                    float2 z = make_float2(0.f, 0.f);
+                    if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
+                        if (io.re_v) {}
+                        else if (io.re) z.x = io.re[(size_t)y * io.cols + x];
+                        else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+                        if (io.im_v) {}
+                        else if (io.im) z.y = io.im[(size_t)y * io.cols + x];
+                        else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+                    }
+                    zz[i] = z;
+                }
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     const float *__restrict__ Vs = sl ? io.im_v : io.re_v;
@@ -461,16 +493,10 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
                 for (int i = 0; i < NLD; ++i) {
                     const int n = (threadIdx.x >> VS) + i * (kFftBlock >> VS);
                     const int y = y0 + n * p.S;
-                    float2 z = make_float2(0.f, 0.f);
                     if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
-                        if (io.re_v) z.x = taps(seg + n * kSeg);
-                        else if (io.re) z.x = io.re[(size_t)y * io.cols + x];
-                        else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
-                        if (io.im_v) z.y = taps(seg + (F + n) * kSeg);
-                        else if (io.im) z.y = io.im[(size_t)y * io.cols + x];
-                        else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
+                        if (io.re_v) zz[i].x = taps(seg + n * kSeg);
+                        if (io.im_v) zz[i].y = taps(seg + (F + n) * kSeg);
                     }
-                    zz[i] = z;
                 }
                 __syncthreads();            // the staging area is the tile buffer the commit overwrites
                 return;
@@ -849,6 +875,13 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d%s" : "fft_pass_kernel_F%d%s"), p.F,
              io.load_kind == 1 ? "_pack" : (io.store_kind == 1 ? "_peak" : ""));
     OipProfScope prof(ctx, pname);
+    dim3 grid3((unsigned)blocks);
+    p.grid3 = 0;
+    if (p.mode == 0 && (p.O1 > 65535 || p.O2 > 65535)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass: more than 65535 rows or blocks");
+    if (p.mode == 0 && blocks_override <= 0 && !(p.fast >= 0 && kFast[p.fast].persist)) {
+        p.grid3 = 1;
+        grid3 = dim3((unsigned)(p.ltn > 0 ? p.ltn : p.lane_tiles), (unsigned)p.O1, (unsigned)p.O2);
+    }
     if (p.fast >= 0) {
         p.ntiles = blocks;
         long grid = blocks;
@@ -857,10 +890,10 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
             const long cap = (long)ctx->cu_count * (envg ? atoi(envg) : 8);
             if (grid > cap) grid = cap;
         }
-        hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
+        hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
-        hipLaunchKernelGGL(fft_pass_kernel, dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);
+        hipLaunchKernelGGL(fft_pass_kernel, p.grid3 ? grid3 : dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;

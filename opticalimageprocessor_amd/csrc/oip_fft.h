@@ -66,6 +66,7 @@ struct OipFftPass {
     long total_tiles;   // tiles of the whole pass (peak partial slots)
     int lt0, ltn;       // lane-tile window of this launch (column panel); ltn == 0: all
     int fast;           // index of a compile-time specialised kernel, -1: generic
+    int grid3;          // mode 0 launched as a (lane tile, o1, o2) grid: the tile needs no divisions to decode
 };
 
 struct OipFft2dPlan {

@@ -66,7 +66,14 @@ __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
         if (p.grid3) {
             // (lane tile, o1, o2) straight from the grid: two 64-bit divisions by run-time values are
             // ~150 scalar instructions, and these passes issue about as many scalar as vector ones
-            lt = p.lt0 + blockIdx.x;
+            // Workgroups go to the 8 XCDs round-robin in launch order and every XCD has its own L2.
+            // Neighbouring lane tiles share cache lines whenever a tile row is narrower than a line
+            // (2-byte PAN pixels: 32 B per row; the 32-byte tap runs of the up-sampled bands), so XCD j
+            // is given the contiguous lane tiles [j * chunk, (j + 1) * chunk) instead of every eighth
+            // one: the sharing becomes L2 hits instead of 2-4x over-fetch from the fabric.  The grid's
+            // x extent is padded to 8 * chunk; surplus workgroups leave before any barrier.
+            const int rel = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+            lt = p.lt0 + rel;
             t.o1 = blockIdx.y;
             t.o2 = blockIdx.z;
             rest = (long)(t.o2 * p.O1 + t.o1);
@@ -80,6 +87,7 @@ __device__ __forceinline__ Tile decode_tile(const OipFftPass &p, long bid)
         t.gtile = rest * p.lane_tiles + lt;
         t.lane0 = lt << p.vshift;
         t.nv = p.lanes - t.lane0 < V ? (int)(p.lanes - t.lane0) : V;
+        if (p.grid3 && lt - p.lt0 >= (p.ltn > 0 ? p.ltn : p.lane_tiles)) t.nv = 0;      // padding workgroup
         t.base = (long)t.o2 * p.o2_stride + (long)t.o1 * p.o1_stride + t.lane0;
         t.vec0 = 0;
     } else {
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
         }
     } else {
         t = decode_tile(p, blockIdx.x);
+        if (p.grid3 && t.nv <= 0) return;       // padding workgroup of the XCD-chunked grid
     }
     for (int i = threadIdx.x; i < F; i += kFftBlock) tw[i] = twF[i];
 
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
         OipFftPass pg = p;
         pg.grid3 = 1;                  // launch_pass always gives non-persistent mode-0 passes the 3-D grid
         t = decode_tile(pg, 0);
+        if (t.nv <= 0) return;         // padding workgroup of the XCD-chunked grid
     } else {
         t = decode_tile(p, tile);
     }
@@ -880,7 +890,9 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     if (p.mode == 0 && (p.O1 > 65535 || p.O2 > 65535)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass: more than 65535 rows or blocks");
     if (p.mode == 0 && blocks_override <= 0 && !(p.fast >= 0 && kFast[p.fast].persist)) {
         p.grid3 = 1;
-        grid3 = dim3((unsigned)(p.ltn > 0 ? p.ltn : p.lane_tiles), (unsigned)p.O1, (unsigned)p.O2);
+        const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
+        p.xcd_chunk = (ltn + 7) / 8;
+        grid3 = dim3((unsigned)(8 * p.xcd_chunk), (unsigned)p.O1, (unsigned)p.O2);
     }
     if (p.fast >= 0) {
         p.ntiles = blocks;

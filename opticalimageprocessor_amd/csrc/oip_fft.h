@@ -67,6 +67,7 @@ struct OipFftPass {
     int lt0, ltn;       // lane-tile window of this launch (column panel); ltn == 0: all
     int fast;           // index of a compile-time specialised kernel, -1: generic
     int grid3;          // mode 0 launched as a (lane tile, o1, o2) grid: the tile needs no divisions to decode
+    int xcd_chunk;      // grid3: lane tiles per XCD (grid x = 8 * xcd_chunk >= lane tiles); see decode_tile
 };
 
 struct OipFft2dPlan {

@@ -175,21 +175,32 @@ __device__ void store_peak(const float2 *buf, int Vp, const OipFftPass &p, const
     const int total = p.F << p.vshift;
     const int ym = p.M >> 1, xm = p.N >> 1;
     float bv[2] = {-INFINITY, -INFINITY};
-    long bk[2] = {(long)p.M * p.N, (long)p.M * p.N};
+    const long none = (long)p.M * p.N;
+    // the scan keeps the tile-local element index of the best value; the 64-bit key of the shifted
+    // position is only formed for the winner (and in the rare exact ties, where the smaller key wins)
+    auto key_of = [&](int e) -> long {
+        if (e < 0) return none;
+        const int v = p.mode == 0 ? (e & (V - 1)) : e / p.F;
+        const int n = p.mode == 0 ? (e >> p.vshift) : e - v * p.F;
+        int y, x;
+        elem_coord(p, t, n, v, &y, &x);
+        int ys = y + ym; if (ys >= p.M) ys -= p.M;
+        int xs = x + xm; if (xs >= p.N) xs -= p.N;
+        return (long)ys * p.N + xs;
+    };
+    int be[2] = {-1, -1};
     for (int e = threadIdx.x; e < total; e += kFftBlock) {
         const int v = p.mode == 0 ? (e & (V - 1)) : e / p.F;
         const int n = p.mode == 0 ? (e >> p.vshift) : e - v * p.F;
         if (v >= t.nv) continue;
         float2 z = buf[n * Vp + v];
         z.y = -z.y;                              // inverse = conj(forward(conj))
-        int y, x;
-        elem_coord(p, t, n, v, &y, &x);
-        int ys = y + ym; if (ys >= p.M) ys -= p.M;
-        int xs = x + xm; if (xs >= p.N) xs -= p.N;
-        const long key = (long)ys * p.N + xs;
-        if (peak_better(z.x, key, bv[0], bk[0])) { bv[0] = z.x; bk[0] = key; }
-        if (peak_better(z.y, key, bv[1], bk[1])) { bv[1] = z.y; bk[1] = key; }
+        if (z.x > bv[0]) { bv[0] = z.x; be[0] = e; }
+        else if (z.x == bv[0] && key_of(e) < key_of(be[0])) be[0] = e;
+        if (z.y > bv[1]) { bv[1] = z.y; be[1] = e; }
+        else if (z.y == bv[1] && key_of(e) < key_of(be[1])) be[1] = e;
     }
+    long bk[2] = {key_of(be[0]), key_of(be[1])};
     // wave-level arg-max with shuffles, then one LDS hand-off between the waves of the block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = kFftBlock >> 6;
 #pragma unroll
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             // (8 for the x4 geometry).  Staging those runs in LDS -- the tile buffer is still free --
             // replaces four gathers per element and source by 1/4 staging load; per-lane gathers
             // stay as the fall-back for wider footprints.
-            constexpr int kSeg = 8;
+            constexpr int kSeg = V >= 16 ? V / 2 : 8;
             const int xl = tt.lane0, xr = tt.lane0 + tt.nv - 1 < io.cols - 1 ? tt.lane0 + tt.nv - 1 : io.cols - 1;
             int cbase = 0, cend = -1;
             if (xl < io.cols) {

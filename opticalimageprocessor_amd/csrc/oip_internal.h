@@ -20,6 +20,7 @@ struct oip_prof_entry {
 struct oip_prof_pending {
     int entry;
     hipEvent_t e0, e1;
+    bool own_e0;        // false: e0 is the previous scope's e1 (back-to-back kernels share the event)
 };
 
 struct oip_fft_state;   // fft.hip
@@ -77,6 +78,7 @@ struct oip_ctx {
     bool prof_on = false;
     std::vector<oip_prof_entry> prof;
     std::vector<oip_prof_pending> prof_pending;
+    hipEvent_t prof_chain = nullptr;    // end event of the previous scope while nothing else has been enqueued since
 };
 
 int oip_fail(oip_ctx *ctx, int code, const char *fmt, ...);
@@ -96,6 +98,7 @@ void oip_fft_destroy(oip_ctx *ctx);
 #define OIP_CHECK_CTX(ctx)                                                              \
     do {                                                                                \
         if (!(ctx)) return OIP_E_INVALID;                                               \
+        (ctx)->prof_chain = nullptr; /* the caller may have put its own work on the stream */ \
     } while (0)
 
 // scoped profiling region around one or more launches

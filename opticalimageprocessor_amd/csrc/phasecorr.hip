@@ -1007,6 +1007,7 @@ int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, R
 
 int fetch_results(oip_ctx *ctx, int count, double *host_out)
 {
+    ctx->prof_chain = nullptr;
     OIP_HIP(ctx, hipMemcpyAsync(ctx->h_small, ctx->d_small, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     OIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(host_out, ctx->h_small, sizeof(double) * count);

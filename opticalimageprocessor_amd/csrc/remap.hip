@@ -399,6 +399,7 @@ extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, 
     int *d_bad_rows = d_bad_count + 64;
     int *d_bad_groups = d_bad_rows + kMaxBadRows;
     if (v8) {
+        ctx->prof_chain = nullptr;
         OIP_HIP(ctx, hipMemsetAsync(d_bad_count, 0, sizeof(int), ctx->stream));
         if (!bad_groups.empty())
             OIP_HIP(ctx, hipMemcpyAsync(d_bad_groups, bad_groups.data(), sizeof(int) * bad_groups.size(), hipMemcpyHostToDevice, ctx->stream));

@@ -49,9 +49,10 @@ __global__ void align_rows_kernel(AlignRow *rows, OipAlignGeom g, long out_row0,
     rows[r] = a;
 }
 
-// One lane = one (output column, band): lane 4p+b of a wave handles pixel p, band b, so a wave
-// writes 128 contiguous bytes of the interleaved 16UC4 line and keeps a single 4x4 source
-// window per lane (~50 VGPRs instead of ~190 for four bands per lane: 8 waves/SIMD instead of 2).
+// One lane = one (output column, band): lane 16b+p of a wave handles pixel p, band b, so a wave
+// writes 128 contiguous bytes of the interleaved 16UC4 line (as 2-byte stores 8 bytes apart per
+// 16-lane group) and keeps a single 4x4 source window per lane (~50 VGPRs instead of ~190 for four
+// bands per lane: 8 waves/SIMD instead of 2).
 // For a fixed column the first tap line iy advances by exactly one per output line except where
 // the f32 rounding of mapY flips (rare) or a section seam restarts the section-relative line,
 // so the window normally loads only the newest source line (4 taps per pixel instead of 16).
@@ -66,14 +67,18 @@ __device__ __forceinline__ void align_load_row(const uint16_t *__restrict__ pl, 
     }
 }
 
+template <int KB>
 __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
                                                            long src_rows, uint16_t *__restrict__ dst,
                                                            const AlignRow *__restrict__ rows, int Wb, long out_rows,
                                                            AlignCoef co, const float *__restrict__ tab1d,
                                                            int rows_per_block)
 {
+    // lane = 16 * band + pixel: the 2-byte taps of a 16-lane group are 32 contiguous bytes of one
+    // plane (band-minor lanes put the four lanes of every quad on four different planes, which the
+    // texture addresser serialises -- measured 2.4x slower)
     const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int x = gid >> 2, b = gid & 3;
+    const int x = (gid >> 6) * 16 + (gid & 15), b = (gid >> 4) & 3;
     if (x >= Wb) return;
     const int xx = x * 4;
     const double dxx = (double)xx;
@@ -106,16 +111,46 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
-    for (long r = r0; r < r1; ++r) {
-        const AlignRow a = rows[r];
+
+    // first-tap line and y phase of output line r for this lane's column and band
+    auto map_y = [&](const AlignRow &a, int *iy, int *fy) {
+        const double yy = (double)((long)a.yrel * 4);
+        const double my = __dadd_rn(coly, yy) * 0.25;
+        const int sy = oip_cvround((float)my * 32.0f);
+        *iy = oip_sat_short(sy >> 5) - 1;
+        *fy = sy & 31;
+    };
+    // the 16-tap sum for the window as it stands (interior / border / fully outside)
+    auto resample = [&](const AlignRow &a, int iy, int fy) -> unsigned {
+        float sum;
+        if (x_out || iy >= a.lines || iy + 4 <= 0) {
+            sum = 0.f;
+        } else {
+            float wy[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
+            if (x_in && (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0)) {
+                sum = oip_bicubic_interior(win, wx, wy);
+            } else {
+                unsigned ymask = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = iy + t;
+                    const long lr = (long)a.base + rr;
+                    if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
+                }
+                sum = oip_bicubic_border(win, wx, wy, xmask, ymask);
+            }
+        }
+        return oip_sat_u16(sum);
+    };
+    // one output line the careful way: any jump of the first tap line reloads what is missing
+    auto one_row = [&](long r, const AlignRow &a) {
         unsigned res = 0;
         if (a.valid) {
             if (a.base != cur_base) { cur_base = a.base; cur_iy = INT_MIN; }       // new section: window stale
-            const double yy = (double)((long)a.yrel * 4);
-            const double my = __dadd_rn(coly, yy) * 0.25;
-            const int sy = oip_cvround((float)my * 32.0f);
-            const int iy = oip_sat_short(sy >> 5) - 1;
-            const int fy = sy & 31;
+            int iy, fy;
+            map_y(a, &iy, &fy);
             if (iy == cur_iy + 1 && cur_iy != INT_MIN) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -134,30 +169,53 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
                 }
             }
             cur_iy = iy;
-            float sum;
-            if (x_out || iy >= a.lines || iy + 4 <= 0) {
-                sum = 0.f;
-            } else {
-                float wy[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
-                if (x_in && (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0)) {
-                    sum = oip_bicubic_interior(win, wx, wy);
-                } else {
-                    unsigned ymask = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int rr = iy + t;
-                        const long lr = (long)a.base + rr;
-                        if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
-                    }
-                    sum = oip_bicubic_border(win, wx, wy, xmask, ymask);
-                }
-            }
-            res = oip_sat_u16(sum);
+            res = resample(a, iy, fy);
         }
         dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
+    };
+
+    // Lines can be taken KB at a time: in the regular case -- same section, first tap line advancing
+    // by one per output line, window already primed -- the new source lines are known before any of
+    // them is used, so their loads go out together.  Measured, the extra registers cost more
+    // (occupancy) than the shorter dependency chains gain, so KB = 1 is the default.
+    constexpr int kBatch = KB;
+    long r = r0;
+    for (; r + kBatch <= r1; r += kBatch) {
+        AlignRow a[kBatch];
+        int iy[kBatch], fy[kBatch];
+        bool regular = cur_iy != INT_MIN;
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            a[k] = rows[r + k];
+            map_y(a[k], &iy[k], &fy[k]);
+            regular = regular && a[k].valid && a[k].base == cur_base && iy[k] == cur_iy + 1 + k;
+        }
+        if (regular) {
+            float nl[kBatch][4];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int rr = iy[k] + 3;
+                const long lr = (long)a[k].base + rr;
+                align_load_row(pl, lr, rr >= 0 && rr < a[k].lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, nl[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) win[t][j] = win[t + 1][j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) win[3][j] = nl[k][j];
+                cur_iy = iy[k];
+                dst[((size_t)(r + k) * Wb + x) * 4 + b] = (uint16_t)resample(a[k], iy[k], fy[k]);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < kBatch; ++k) one_row(r + k, a[k]);
+        }
     }
+    for (; r < r1; ++r) one_row(r, rows[r]);
 }
 
 // host mirror of the kernel's first-tap line for one band/column/line (range queries)
@@ -287,14 +345,17 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
     memcpy(co.cy, cy, sizeof co.cy);
     {
         OipProfScope prof(ctx, "align_mss_kernel");
-        int gx = (Wb * 4 + kBlock - 1) / kBlock;
+        int gx = (Wb + kBlock / 4 - 1) / (kBlock / 4);          // 16 pixels x 4 bands per wave
         long want = (long)ctx->cu_count * 16 / gx;
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
         if (rpb < 32) rpb = 32;
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
-        hipLaunchKernelGGL(align_mss_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
+        static const char *envb = getenv("OIP_ALIGN_BATCH");                 // experiment knob
+        const int kb = envb ? atoi(envb) : 1;       // measured on MI355X: 4.4 / 5.4 / 6.8 ms for 1 / 2 / 4 (VGPRs cost occupancy)
+        auto fn = kb == 1 ? align_mss_kernel<1> : (kb == 2 ? align_mss_kernel<2> : align_mss_kernel<4>);
+        hipLaunchKernelGGL(fn, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
                            src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpb);
     }
     OIP_HIP(ctx, hipGetLastError());

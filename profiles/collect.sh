@@ -1,0 +1,24 @@
+#!/bin/bash
+# Evidence run for one round tag (e.g. r01_e): bench lines, rocprofv3 kernel stats and the two PMC passes
+# for the three workloads.  Run on the GPU box from the repo root:  bash profiles/collect.sh r01_e
+# Outputs go to gpurun_out/<tag>/; profiles/summarise.py turns them into the committed summaries.
+set -e -o pipefail
+TAG=${1:-r01_x}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for W in default prestitch rrc; do
+  echo "== bench $W"; date
+  timeout -k 10 400 python3 bench.py --workload $W --steps 5 --warmup 1 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  echo "== kernel trace $W"; date
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_${W}_under_rocprof.json 2> $OUT/trace_$W.err
+  for C in FETCH_SIZE WRITE_SIZE; do
+    echo "== pmc $C $W"; date
+    timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -o pmc -- python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_${C}_$W.err
+  done
+done
+python3 profiles/summarise.py $TAG
+# the raw traces are large; only the summaries travel back
+rm -rf $OUT/trace_* $OUT/pmc_*_default $OUT/pmc_*_prestitch $OUT/pmc_*_rrc
+tail -n 3 $OUT/*.err | tail -n 40
+echo done; date

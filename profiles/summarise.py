@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output of profiles/collect.sh into the small summaries that are committed:
+   profiles/<tag>_<workload>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats, kernel rows only)
+   profiles/<tag>_bench_<workload>.json          (the bench line)
+   profiles/<tag>_pmc_raw.json                   (per kernel: launches, mean FETCH_SIZE / WRITE_SIZE in KiB)
+   profiles/traffic.json                         (HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, keyed like bench.py)
+"""
+import csv, glob, json, os, re, shutil, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "gpurun_out", tag)
+prof = os.path.join(out, "summary")          # copied into profiles/ by hand after the run (gpurun returns gpurun_out/ only)
+os.makedirs(prof, exist_ok=True)
+
+
+def bench_name(kernel):
+    """library profiler name (bench.py's key) of a demangled kernel symbol"""
+    m = re.search(r"fft_pass_ct_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(?:false|true|0|1), *(\d+)", kernel)
+    if m:
+        F, iok = int(m.group(1)), int(m.group(5))
+        return "fft_pass_ct_kernel_F%d%s" % (F, {0: "", 1: "_pack", 2: "_peak"}[iok])
+    m = re.search(r"([A-Za-z_0-9]+_kernel)\b", kernel)
+    return m.group(1) if m else kernel
+
+
+raw, traffic = {}, {}
+for w in ("default", "prestitch", "rrc"):
+    b = os.path.join(out, "bench_%s.json" % w)
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(prof, "%s_bench_%s.json" % (tag, w)))
+    st = glob.glob(os.path.join(out, "trace_%s" % w, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(prof, "%s_%s_kernel_stats.csv" % (tag, w)))
+    per = defaultdict(lambda: defaultdict(list))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob(os.path.join(out, "pmc_%s_%s" % (c, w), "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") != c:
+                    continue
+                name = bench_name(row["Kernel_Name"])
+                grid = int(row.get("Grid_Size", 0) or 0)
+                if name.endswith("_peak") and grid <= 50 * 256:
+                    name = "fft_window_F" + name.split("_F")[1].split("_")[0]          # 25-tile window launches
+                per[name][c].append(float(row["Counter_Value"]))
+    raw[w], traffic[w] = {}, {}
+    for name, d in per.items():
+        f = d.get("FETCH_SIZE", [])
+        wr = d.get("WRITE_SIZE", [])
+        if not f or not wr:
+            continue
+        fm, wm = sum(f) / len(f), sum(wr) / len(wr)
+        raw[w][name] = {"launches": len(f), "FETCH_SIZE_KiB_mean": fm, "WRITE_SIZE_KiB_mean": wm}
+        traffic[w][name] = (2 * fm + wm) * 1024
+about = ("HBM bytes per launch from rocprofv3 PMC counters on MI355X (gfx950, ROCm 7.2), collected in separate passes "
+         "(--pmc FETCH_SIZE, then --pmc WRITE_SIZE) of the same bench.py command (profiles/collect.sh); traffic = "
+         "(2*FETCH_SIZE + WRITE_SIZE)*1024 B: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream "
+         "(MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  Kernels whose loads are narrower than 16 B/lane "
+         "(align, mss_split, the 2-byte PAN reads of the first FFT pass) are uncalibrated on the read side.  "
+         "Raw: profiles/%s_pmc_raw.json" % tag)
+json.dump(raw, open(os.path.join(prof, "%s_pmc_raw.json" % tag), "w"), indent=1, sort_keys=True)
+t = {"_about": about}
+t.update(traffic)
+json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1, sort_keys=True)
+print("summaries written for", tag, {w: len(v) for w, v in traffic.items()})

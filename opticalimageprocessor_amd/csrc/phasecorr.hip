@@ -433,26 +433,32 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
     constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
     constexpr int N = F;
     constexpr int NIT = (N + NT - 1) / NT;
-    __shared__ float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
+    __shared__ __align__(16) float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
     __shared__ float2 tw[TWN];
     const int dbg = fj.dbg;
     const int half = M / 2;
     int ky = blockIdx.x;
     if (ky > half) return;
     for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
-    const float2 zero = make_float2(0.f, 0.f);
-    float2 la[NARR][NIT], lb[NARR][NIT];
+    // Lines move 16 bytes (two points) per lane: half the vector-memory and LDS instructions of 8-byte
+    // accesses -- their operand traffic shares the SIMD-to-LDS path with the stages' ds_writes.
+    static_assert(N % 2 == 0, "two points per lane");
+    constexpr int NIT2 = (N / 2 + NT - 1) / NT;
+    float4 la[NARR][NIT2], lb[NARR][NIT2];
+    float4 *buf4 = reinterpret_cast<float4 *>(buf);
     // rows of the line pair whose loads are in la/lb (n1, n2) and of the pair in LDS (s1, s2)
     long n1 = (long)oip_freq_to_pos(yd, ky) * P, n2 = (long)oip_freq_to_pos(yd, ky ? M - ky : 0) * P;
     auto fetch = [&](int tid) {
 #pragma unroll
         for (int a = 0; a < NARR; ++a) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int x = tid + it * NT;
-                const bool ok = x < N;
-                la[a][it] = ok ? fj.z[a][n1 + x] : zero;
-                lb[a][it] = ok ? fj.z[a][n2 + x] : zero;
+            for (int it = 0; it < NIT2; ++it) {
+                // lanes past the end of the line re-read its last pair (never committed): a select on
+                // the loaded value would need the load to have completed -- a wait inside the prefetch
+                int q = tid + it * NT;
+                q = q < N / 2 ? q : N / 2 - 1;
+                la[a][it] = *reinterpret_cast<const float4 *>(fj.z[a] + n1 + 2 * q);
+                lb[a][it] = *reinterpret_cast<const float4 *>(fj.z[a] + n2 + 2 * q);
             }
         }
     };
@@ -460,21 +466,25 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
 #pragma unroll
         for (int a = 0; a < NARR; ++a) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int x = tid + it * NT;
-                if (x < N) { buf[a * 2 * F + 2 * x] = la[a][it]; buf[a * 2 * F + 2 * x + 1] = lb[a][it]; }
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < N / 2) {
+                    // [point][line] interleave: (2q, line 0), (2q, line 1), (2q+1, line 0), (2q+1, line 1).
+                    // Four 8-byte writes straight from the halves of the loaded registers: packing
+                    // (la.xy, lb.xy) into one 16-byte write makes the compiler shuffle registers right
+                    // after the loads -- i.e. wait for them at the point of issue.
+                    float2 *dst = buf + a * 2 * F + 4 * q;
+                    dst[0] = make_float2(la[a][it].x, la[a][it].y);
+                    dst[1] = make_float2(lb[a][it].x, lb[a][it].y);
+                    dst[2] = make_float2(la[a][it].z, la[a][it].w);
+                    dst[3] = make_float2(lb[a][it].z, lb[a][it].w);
+                }
             }
         }
     };
     fetch(threadIdx.x);
     commit(threadIdx.x);
     long s1 = n1, s2 = n2;
-    if (ky + (int)gridDim.x <= half) {
-        const int kn = ky + gridDim.x;
-        n1 = (long)oip_freq_to_pos(yd, kn) * P;
-        n2 = (long)oip_freq_to_pos(yd, M - kn) * P;
-        fetch(threadIdx.x);
-    }
     __syncthreads();
     for (; ky <= half; ky += gridDim.x) {
         // opaque per iteration: keeps the stage address arithmetic from being hoisted out of this
@@ -482,6 +492,18 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const bool pair = s1 != s2;
+        // The lines of the NEXT pair are requested first and committed at the bottom of this same
+        // iteration: the registers holding them then never cross the loop's back edge.  (Carried across
+        // it, the register allocator gave the loop-header values other registers than the loads'
+        // destinations and copied right after the loads -- waiting for them at the point of issue.)
+        const int kn = ky + gridDim.x;
+        const bool more = kn <= half;
+        if (more && !(dbg & 8)) {
+            n1 = (long)oip_freq_to_pos(yd, kn) * P;
+            n2 = (long)oip_freq_to_pos(yd, M - kn) * P;
+            fetch(tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 1)) oipfft::StagesPipe<F, NT, NARR, 1, Rs...>::run(buf, tw, tid);
 #pragma unroll 1
         for (int it = 0; it < NIT; ++it) {
@@ -490,73 +512,75 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
             const int nkx = kx ? N - kx : 0;
             const bool edge_col = (kx == 0) || (2 * kx == N);
             const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
-            float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
-            float2 zk1 = zero, zm1 = zero, zk2 = zero, zm2 = zero;
-            if (NARR > 1) { zk1 = buf[2 * F + 2 * kx]; zm1 = buf[2 * F + 2 * nkx + 1]; }
-            if (NARR > 2) { zk2 = buf[4 * F + 2 * kx]; zm2 = buf[4 * F + 2 * nkx + 1]; }
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                float2 y = zero, ym = zero;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    if (c >= fj.ncorr[o]) break;
-                    const int ia = fj.ia[2 * o + c], ib = fj.ib[2 * o + c];
-                    const int pa = fj.pa[2 * o + c], pb = fj.pb[2 * o + c];
-                    float2 zka = ia == 0 ? zk0 : (ia == 1 ? zk1 : zk2);
-                    float2 zma = ia == 0 ? zm0 : (ia == 1 ? zm1 : zm2);
-                    float2 zkb = ib == 0 ? zk0 : (ib == 1 ? zk1 : zk2);
-                    float2 zmb = ib == 0 ? zm0 : (ib == 1 ? zm1 : zm2);
-                    float2 A = spec_of(pa, zka, zma);
-                    float2 B = spec_of(pb, zkb, zmb);
-                    float2 C = cross_power_bin_fast(A, B, real_bin, edge_col);
-                    if (c == 0) { y.x += C.x; y.y += C.y; ym.x += C.x; ym.y -= C.y; }        // Y = C1 + i C2
-                    else { y.x -= C.y; y.y += C.x; ym.x += C.y; ym.y += C.x; }               // i*conj(C2) = (C2.y, C2.x)
-                }
-                // inverse = conj(forward(conj(.)))
-                buf[o * 2 * F + 2 * kx] = make_float2(y.x, -y.y);
-                buf[o * 2 * F + 2 * nkx + 1] = pair ? make_float2(ym.x, -ym.y) : zero;
+            // The two job shapes are fixed (xpower_stage checks them on the host), so which spectrum and
+            // slot feeds which correlation is known here -- no run-time selects:
+            //   1 spectrum : Y0 = C(z0.re, z0.im)
+            //   3 spectra  : A = z0.re against z0.im, z1.re | z1.im, z2.(re or im: fj.pb[3])
+            const float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
+            const float2 A = spec_of(0, zk0, zm0);
+            float2 y0, y0m, y1 = make_float2(0.f, 0.f), y1m = make_float2(0.f, 0.f);
+            {
+                const float2 C = cross_power_bin_fast(A, spec_of(1, zk0, zm0), real_bin, edge_col);
+                y0 = C;
+                y0m = make_float2(C.x, -C.y);
+            }
+            if (NARR == 3) {
+                const float2 zk1 = buf[2 * F + 2 * kx], zm1 = buf[2 * F + 2 * nkx + 1];
+                const float2 zk2 = buf[4 * F + 2 * kx], zm2 = buf[4 * F + 2 * nkx + 1];
+                float2 C = cross_power_bin_fast(A, spec_of(0, zk1, zm1), real_bin, edge_col);
+                y0.x -= C.y; y0.y += C.x; y0m.x += C.y; y0m.y += C.x;                        // + i C, + i conj(C)
+                C = cross_power_bin_fast(A, spec_of(1, zk1, zm1), real_bin, edge_col);
+                y1 = C;
+                y1m = make_float2(C.x, -C.y);
+                const float2 B3 = fj.pb[3] ? spec_of(1, zk2, zm2) : spec_of(0, zk2, zm2);
+                C = cross_power_bin_fast(A, B3, real_bin, edge_col);
+                y1.x -= C.y; y1.y += C.x; y1m.x += C.y; y1m.y += C.x;
+            }
+            // inverse = conj(forward(conj(.)))
+            buf[2 * kx] = make_float2(y0.x, -y0.y);
+            buf[2 * nkx + 1] = pair ? make_float2(y0m.x, -y0m.y) : make_float2(0.f, 0.f);
+            if (NOUT == 2) {
+                buf[2 * F + 2 * kx] = make_float2(y1.x, -y1.y);
+                buf[2 * F + 2 * nkx + 1] = pair ? make_float2(y1m.x, -y1m.y) : make_float2(0.f, 0.f);
             }
         }
         __syncthreads();
         asm volatile("" : "+v"(tid));
         if (!(dbg & 4)) oipfft::StagesPipe<F, NT, NOUT, 1, Rs...>::run(buf, tw, tid);
         if (NOUT == 1) __syncthreads();
-        // Results leave LDS through registers so that the next pair can be committed BEFORE the
-        // stores are issued: the commit then waits on loads that were issued a whole iteration ago,
-        // with nothing younger queued behind them, and both the stores and the following prefetch
-        // stay in flight under the next iteration's arithmetic.
-        float2 ya[NOUT][NIT], yb[NOUT][NIT];
+        // Results leave LDS through registers so that the next pair can be committed before the stores
+        // are issued.
+        float4 ya[NOUT][NIT2], yb[NOUT][NIT2];      // line ky / line -ky, two points each
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int x = tid + it * NT;
-                if (x < N) { ya[o][it] = buf[o * 2 * F + 2 * x]; yb[o][it] = buf[o * 2 * F + 2 * x + 1]; }
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < N / 2) {
+                    const float4 u = buf4[o * F + 2 * q], v = buf4[o * F + 2 * q + 1];
+                    ya[o][it] = make_float4(u.x, -u.y, v.x, -v.y);
+                    yb[o][it] = make_float4(u.z, -u.w, v.z, -v.w);
+                }
             }
         }
         __syncthreads();
-        const int kn = ky + gridDim.x;
-        if (kn <= half) commit(tid);
+        if (more) commit(tid);
+        __builtin_amdgcn_sched_barrier(0);
+        const long o1 = s1, o2 = s2;
+        s1 = n1; s2 = n2;
         if (!(dbg & 16)) {
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 float2 *out = fj.out[o];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int x = tid + it * NT;
-                    if (x < N) {
-                        out[s1 + x] = make_float2(ya[o][it].x, -ya[o][it].y);
-                        if (pair) out[s2 + x] = make_float2(yb[o][it].x, -yb[o][it].y);
+                for (int it = 0; it < NIT2; ++it) {
+                    const int q = tid + it * NT;
+                    if (q < N / 2) {
+                        *reinterpret_cast<float4 *>(out + o1 + 2 * q) = ya[o][it];
+                        if (pair) *reinterpret_cast<float4 *>(out + o2 + 2 * q) = yb[o][it];
                     }
                 }
             }
-        }
-        s1 = n1; s2 = n2;
-        const int kf = kn + gridDim.x;
-        if (kf <= half && !(dbg & 8)) {
-            n1 = (long)oip_freq_to_pos(yd, kf) * P;
-            n2 = (long)oip_freq_to_pos(yd, M - kf) * P;
-            fetch(tid);
         }
         __syncthreads();
     }
@@ -897,7 +921,12 @@ int xpower_stage(oip_ctx *ctx, const OipFft2dPlan *pl, const RowStage &rs, const
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
     if (rs.level == 2) {
         // persistent: as many workgroups as fit the CUs at once (LDS- or thread-limited)
-        const bool one = fj.narr == 1 && fj.nout == 1, three = fj.narr == 3 && fj.nout == 2;
+        // the kernel hard-wires which spectrum and slot feeds which correlation
+        const bool one = fj.narr == 1 && fj.nout == 1 && ncorr == 1 && fj.ia[0] == 0 && fj.pa[0] == 0 && fj.ib[0] == 0 && fj.pb[0] == 1;
+        bool three = fj.narr == 3 && fj.nout == 2 && ncorr == 4;
+        const int want_ib[4] = {0, 1, 1, 2}, want_pb[3] = {1, 0, 1};
+        for (int c = 0; c < 4 && three; ++c)
+            three = fj.ia[c] == 0 && fj.pa[c] == 0 && fj.ib[c] == want_ib[c] && (c == 3 || fj.pb[c] == want_pb[c]);
         if (!one && !three) return oip_fail(ctx, OIP_E_RUNTIME, "xpower_stage: unsupported job shape");
         const size_t lds = sizeof(float2) * ((size_t)fj.narr * 2 * rs.k->F + rs.k->F / 2);
         long per_cu = (long)(160 * 1024 / lds);

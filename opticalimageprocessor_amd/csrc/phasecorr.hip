@@ -469,15 +469,11 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
             for (int it = 0; it < NIT2; ++it) {
                 const int q = tid + it * NT;
                 if (q < N / 2) {
-                    // [point][line] interleave: (2q, line 0), (2q, line 1), (2q+1, line 0), (2q+1, line 1).
-                    // Four 8-byte writes straight from the halves of the loaded registers: packing
-                    // (la.xy, lb.xy) into one 16-byte write makes the compiler shuffle registers right
-                    // after the loads -- i.e. wait for them at the point of issue.
-                    float2 *dst = buf + a * 2 * F + 4 * q;
-                    dst[0] = make_float2(la[a][it].x, la[a][it].y);
-                    dst[1] = make_float2(lb[a][it].x, lb[a][it].y);
-                    dst[2] = make_float2(la[a][it].z, la[a][it].w);
-                    dst[3] = make_float2(lb[a][it].z, lb[a][it].w);
+                    // [point][line] interleave: (2q, line 0), (2q, line 1), (2q+1, line 0), (2q+1, line 1):
+                    // two 16-byte writes 32 bytes apart per lane (2-way bank conflict; four 8-byte writes
+                    // would be 4-way).  The repacking moves sit here, after the loads have landed.
+                    buf4[a * F + 2 * q] = make_float4(la[a][it].x, la[a][it].y, lb[a][it].x, lb[a][it].y);
+                    buf4[a * F + 2 * q + 1] = make_float4(la[a][it].z, la[a][it].w, lb[a][it].z, lb[a][it].w);
                 }
             }
         }

@@ -17,6 +17,7 @@ for W in default prestitch rrc; do
     timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -o pmc -- python3 bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_${C}_$W.err
   done
 done
+echo "== host-buffer RRC"; timeout -k 10 300 python3 profiles/experiments/host_rrc.py > $OUT/host_rrc.json 2> $OUT/host_rrc.err || true
 python3 profiles/summarise.py $TAG
 # the raw traces are large; only the summaries travel back
 rm -rf $OUT/trace_* $OUT/pmc_*_default $OUT/pmc_*_prestitch $OUT/pmc_*_rrc

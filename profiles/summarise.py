@@ -25,6 +25,9 @@ def bench_name(kernel):
     return m.group(1) if m else kernel
 
 
+h = os.path.join(out, "host_rrc.json")
+if os.path.exists(h) and os.path.getsize(h):
+    shutil.copy(h, os.path.join(prof, "%s_host_rrc.json" % tag))
 raw, traffic = {}, {}
 for w in ("default", "prestitch", "rrc"):
     b = os.path.join(out, "bench_%s.json" % w)

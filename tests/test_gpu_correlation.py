@@ -140,3 +140,51 @@ def test_interband_argument_errors(ctx):
         ctx.interband_correlate(pan, 100, 0, 100, pan, 400, 0, 25, 64, slices=4, sections=1)
     with pytest.raises(ValueError, match="too many sections"):     # preproc.h:234-237
         ctx.interband_correlate(pan, 100, 0, 100, pan, 400, 0, 25, 64, slices=8, sections=5)
+
+
+def _interband_vs_oracle(ctx, Lp, W, slices, sections, corr, min_resp=0.1):
+    from oracle import phasecorr as pc
+    shifts_true = [(2, -1), (1, 1), (-1, -2), (-2, 1)]
+    pan, bands = _synth.pan_mss(Lp, W, shifts_true, seed=9)
+    want = pc.calc_interband_correlation(pan, bands, slices, sections, corr)
+    planes = _cuda(np.stack(bands, 0))
+    got = ctx.interband_correlate(_cuda(pan), Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, sections, corr)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    ok = want[..., 2] >= min_resp
+    assert ok.mean() > 0.5, want[..., 2]
+    d = np.abs(got[..., :2] - want[..., :2])[ok]
+    assert d.max() < SHIFT_TOL, (d.max(), got[..., :3], want[..., :3])
+    assert np.abs(got[..., 2] - want[..., 2]).max() < 5 * RESP_TOL
+    assert np.array_equal(got[..., 3], want[..., 3])
+    return got
+
+
+def test_interband_reference_unit_shape_matches_oracle(ctx, oracle_mod):
+    """The BASELINE unit shape itself -- 16000 x 3000 windows, x4 up-sampled 4000 x 750 bands -- through the
+    specialised path: vertical-tap kernel + staged horizontal taps in the 128-point first pass, 125-point pass,
+    the persistent three-spectra row-stage kernel, peak pass.  Nine slices: four paired runs (two units sharing
+    the transform of their fourth bands) and one single unit; the oracle (2.5 s per correlation) checks the
+    first pair and the single unit."""
+    from oracle import phasecorr as pc
+    Lp, W, slices = 16000, 27000, 9
+    shifts_true = [(2, -1), (1, 1), (-1, -2), (-2, 1)]
+    pan, bands = _synth.pan_mss(Lp, W, shifts_true, seed=9)
+    planes = _cuda(np.stack(bands, 0))
+    got = ctx.interband_correlate(_cuda(pan), Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, 1, 16000)
+    assert got.shape == (4, slices, 4) and np.isfinite(got).all()
+    bc, sc = W // slices, W // slices // 4
+    for u in (0, 1, 8):
+        a = oracle_mod.window_u16_to_f32(pan, 0, u * bc, Lp, bc)
+        for b in range(4):
+            small = oracle_mod.window_u16_to_f32(bands[b], 0, u * sc, Lp // 4, sc)
+            (wdx, wdy), wr = pc.phase_correlate(a, oracle_mod.resize_cubic(small, bc, Lp))
+            gdx, gdy, gr, gcx = got[b, u]
+            assert abs(gr - wr) < 5 * RESP_TOL, (u, b, gr, wr)
+            if wr >= 0.05:
+                assert abs(gdx - wdx) < SHIFT_TOL and abs(gdy - wdy) < SHIFT_TOL, (u, b, (gdx, gdy), (wdx, wdy))
+            assert gcx == u * bc + bc // 2
+
+
+def test_interband_12288_wide_shape_matches_oracle(ctx, oracle_mod):
+    """slice width 1228 -> 1250-point rows (the reference's 12288-pixel strips): fused row stage for 1250"""
+    _interband_vs_oracle(ctx, 4000, 9824, 8, 1, 4000)

@@ -127,6 +127,7 @@ template <typename T> struct DevBuf {              // RAII device buffer
         Device::get().check(oip_memcpy_d2h(Device::get().ctx(), h, p, count * sizeof(T)));
         Device::get().check(oip_sync(Device::get().ctx()));
     }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     ~DevBuf() { release(); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -472,6 +473,10 @@ public:
         Device::get().check(oip_sync(Device::get().ctx()));
     }
 
+    // Fused task: the PAN strip is already on the device (RRC'd / pre-stitched by the
+    // previous step of the same process) -- no file round trip.  Not owned.
+    void UseDevicePAN(const uint16_t *d_pan) { mPanView = d_pan; }
+
     void LoadMSS()                                                      // preproc.h:56-80 (split deferred to DoRRC4MSS)
     {
         OLOG("Loading MSS raw image ...");
@@ -532,7 +537,9 @@ public:
         const int n = slices * sections;
         std::vector<double> t((size_t)MSS_BANDS * n * 4);
         stop_watch sw;
-        Device::get().check(oip_interband_correlate(Device::get().ctx(), mPAN.p, (long)mLinesPAN, 0, (long)mLinesPAN, mPlanes.p,
+        const uint16_t *pan = mPanView ? mPanView : mPAN.p;
+        if (!pan) throw std::logic_error("PAN raw image data not loaded, call `LoadPAN()' first");
+        Device::get().check(oip_interband_correlate(Device::get().ctx(), pan, (long)mLinesPAN, 0, (long)mLinesPAN, mPlanes.p,
                                                     mPlaneStride, 0, (long)mLinesMSS, mW, slices, sections,
                                                     OIP_CORRELATION_LINES, t.data()));
         OLOG("Inter-band correlation finished in %.3f seconds, result:", sw.tick());
@@ -557,8 +564,11 @@ public:
     }
 
     // preproc.h:351-425 (+ inner :428-468); writes <stem>.ALIGNED.TIFF
+    // keepOnDevice (fused task): the aligned 16UC4 image stays on the device (swapped into *keepOnDevice,
+    // *keptRows lines) and no file is written
     void DoInterBandAlignment(int linePerSection, int lineOffset = 0, int sectionOverlap = OIP_IBPA_DEFAULT_LINEOVERLAP,
-                              bool keepLeadingLines = false, bool autoUnloadRawMSS = true)
+                              bool keepLeadingLines = false, bool autoUnloadRawMSS = true, DevBuf<uint16_t> *keepOnDevice = nullptr,
+                              long *keptRows = nullptr)
     {
         OLOG("Doing inter-band alignment ...");
         const int Wb = mW / MSS_BANDS;
@@ -571,6 +581,15 @@ public:
                                                         rows, Wb, (long)mLinesMSS, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0],
                                                         linePerSection, lineOffset, sectionOverlap, keepLeadingLines ? 1 : 0,
                                                         OIP_IBPA_MIN_PROCESSLINES, &processed));
+        if (keepOnDevice) {
+            Device::get().check(oip_sync(Device::get().ctx()));
+            OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", sw.tick(), processed, rows);
+            keepOnDevice->swap(out);
+            if (keptRows) *keptRows = rows;
+            if (autoUnloadRawMSS) mPlanes.release();
+            OLOG("DoInterBandAlignment(): done.");
+            return;
+        }
         std::unique_ptr<uint16_t[]> h(new uint16_t[(size_t)rows * Wb * MSS_BANDS]);
         out.download(h.get(), (size_t)rows * Wb * MSS_BANDS);
         double es = sw.tick();
@@ -634,10 +653,133 @@ private:
     int mW;
     size_t mSizePAN = 0, mSizeMSS = 0, mLinesPAN = 0, mLinesMSS = 0, mPlaneStride = 0;
     DevBuf<uint16_t> mPAN, mMssBil, mPlanes;
+    const uint16_t *mPanView = nullptr;
     bool mSplitDone = false;
     std::vector<InterBandShift> mBandShift[MSS_BANDS];
     double mDeltaXcoeffs[MSS_BANDS][2] = {};
     double mDeltaYcoeffs[MSS_BANDS][3] = {};
 };
+
+// ---- fused task ---------------------------------------------------------------
+// DOC/sample-task.sh runs five commands -- prestitch, stitch (PAN), the default action for each CCD,
+// stitch (MSS) -- that hand 6 strip-sized files to one another through the file system.  Here the same
+// steps run in one process with every intermediate resident in HBM: four RAW inputs are read once, two
+// TIFFs are written.  Each step is the very code path of the stand-alone command (same C-ABI calls, same
+// parameters), so the two products are identical to the five-command flow's; tests/test_gpu_cli.py
+// compares them.
+struct TaskOptions {
+    int width = OIP_PIXELS_PER_LINE;
+    // prestitch
+    int sections = OIP_STT_DEF_SECTIONS, sectionLines = OIP_STT_DEF_SECLINES, overlapCols = OIP_STT_DEF_OVERLAPPX, edgeCols = 0;
+    double sttThreshold = OIP_STT_DEF_PHCTHRHLD, sttMaxDeltaY = 0.0;
+    // stitching (as given on the command line: halved like main.cpp:189)
+    int foldColsPAN = 0, foldColsMSS = 0;
+    bool useGDAL = false;
+    const int *bandMap = nullptr;
+    // default action
+    int slices = OIP_IBCV_DEF_SLICES, ibcSections = OIP_IBCV_DEF_SECTIONS, linesSection = OIP_IBPA_DEFAULT_BATCHLINES, lineOffset = 0,
+        overlapLines = OIP_IBPA_DEFAULT_LINEOVERLAP;
+    double ibcThreshold = OIP_IBCV_DEF_THRESHOLD;
+    bool keepLeading = false;
+};
+
+inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const std::string &rrc1, const std::string &rrc2,
+                         const std::string &mss1, const std::string &mss2, const std::string rrcMss1[MSS_BANDS],
+                         const std::string rrcMss2[MSS_BANDS], const std::string &outPAN, const std::string &outMSS,
+                         const TaskOptions &o)
+{
+    oip_ctx *ctx = Device::get().ctx();
+    auto ck = [](int rc) { Device::get().check(rc); };
+    stop_watch total;
+    const int W = o.width;
+    // ---- step 1: prestitch.  Sizes and checks as Stitcher's constructor (stitcher.h:49-81)
+    const size_t s1 = IMO::FileSize(pan1), s2 = IMO::FileSize(pan2);
+    if ((size_t)o.sections * o.sectionLines * BYTES_PER_PIXEL > s1) throw std::invalid_argument("PAN1 size too small for SECTION & LINE_PER_SECTION argument");
+    if (s1 != s2) throw std::invalid_argument("PAN1 size doesn't match PAN2 size");
+    const long L = (long)(s1 / ((size_t)W * BYTES_PER_PIXEL));
+    if (L < (long)o.sections * o.sectionLines)
+        throw std::invalid_argument("PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)");
+    const size_t npx = (size_t)W * L;
+    DevBuf<uint16_t> p1(npx), p2(npx), p2s(npx);
+    {
+        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(pan1, 0, 0, s1));
+        p1.upload((uint16_t *)h.get(), npx);
+        ck(oip_sync(ctx));
+        h.reset((char *)IMO::LoadRawImage(pan2, 0, 0, s2));
+        p2.upload((uint16_t *)h.get(), npx);
+        ck(oip_sync(ctx));
+    }
+    // CalcSttParameters on the raw strips (App. B-1), same filter and mean as stitcher.h:181-198
+    std::vector<double> r(3 * (size_t)o.sections);
+    ck(oip_stt_correlate(ctx, p1.p, p2.p, W, L, 0, L, o.sections, o.sectionLines, o.overlapCols, o.edgeCols, r.data()));
+    double dx = 0, dy = 0, resp = 0;
+    int valid = 0;
+    for (int i = 0; i < o.sections; ++i) {
+        const bool ok = r[3 * i + 2] >= o.sttThreshold && (o.sttMaxDeltaY <= 0.0 || std::abs(r[3 * i + 1]) <= o.sttMaxDeltaY);
+        if (ok) { dx += r[3 * i]; dy += r[3 * i + 1]; resp += r[3 * i + 2]; ++valid; }
+    }
+    if (valid == 0) throw std::runtime_error("No valid delta value found for stitching parameter calculating");
+    dx /= valid; dy /= valid; resp /= valid;
+    OLOG("Total %d valid delta value pairs found, everage value:", valid);
+    OLOG("    dx: %.5f, dy: %.5f, r: %.5f", dx, dy, resp);
+    // DoRRC (both strips, in place) + PreStitch of PAN2
+    {
+        DevBuf<double> kb((size_t)W * 2);
+        for (int c = 0; c < 2; ++c) {
+            std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile((c ? rrc2 : rrc1).c_str(), W));
+            kb.upload((double *)prm.get(), (size_t)W * 2);
+            ck(oip_rrc_u16(ctx, c ? p2.p : p1.p, c ? p2.p : p1.p, W, L, kb.p));
+            ck(oip_sync(ctx));
+        }
+    }
+    ck(oip_remap_shift_bicubic_u16(ctx, p2.p, 0, L, p2s.p, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
+    p2.release();
+    // ---- step 2: stitched PAN product
+    {
+        const int fold = o.foldColsPAN / 2;
+        if (fold < 0 || fold >= W) throw std::invalid_argument("fold columns exceed the image width");
+        const size_t nout = (size_t)2 * (W - fold) * L;
+        DevBuf<uint16_t> st(nout);
+        ck(oip_stitch_rows_u16(ctx, p1.p, p2s.p, st.p, W, L, fold));
+        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
+        st.download(h.get(), nout);
+        OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
+        write_tiff_u16(outPAN, h.get(), 2 * (W - fold), L, 1, false);
+    }
+    // ---- step 3: inter-band alignment per CCD, PAN taken from the device
+    DevBuf<uint16_t> aligned[2];
+    long arows[2] = {0, 0};
+    for (int c = 0; c < 2; ++c) {
+        PreProcessor pp(c ? pan2 : pan1, c ? mss2 : mss1, "", c ? rrcMss2 : rrcMss1, W);
+        pp.UseDevicePAN(c ? p2s.p : p1.p);
+        pp.LoadMSS();
+        pp.DoRRC4MSS(true);
+        pp.CalcInterBandCorrelation(o.slices, o.ibcSections, o.ibcThreshold, false);
+        pp.DoInterBandAlignment(o.linesSection, o.lineOffset, o.overlapLines, o.keepLeading, true, &aligned[c], &arows[c]);
+        (c ? p2s : p1).release();
+    }
+    // ---- step 4: stitched MSS product (imageop.h:365-457 / :460-567 on the aligned 16UC4 images)
+    {
+        if (arows[0] != arows[1]) throw std::runtime_error("images have different sizes");
+        const int Wb = W / MSS_BANDS, fold = o.foldColsMSS / 2;
+        if (fold < 0 || fold >= Wb) throw std::invalid_argument("fold columns exceed the image width");
+        const int W4 = Wb * MSS_BANDS, fold4 = fold * MSS_BANDS;
+        const size_t nout = (size_t)2 * (W4 - fold4) * arows[0];
+        DevBuf<uint16_t> st(nout);
+        ck(oip_stitch_rows_u16(ctx, aligned[0].p, aligned[1].p, st.p, W4, arows[0], fold4));
+        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
+        st.download(h.get(), nout);
+        OLOG("Write stitched image to file '%s' ...", outMSS.c_str());
+        const int ow = 2 * (Wb - fold);
+        if (!o.useGDAL && nout < 4000000000ull) {
+            write_tiff_u16(outMSS, h.get(), ow, arows[0], MSS_BANDS, true);          // as cv::imwrite of the stitched Mat
+        } else {
+            int order[4];
+            for (int b = 0; b < 4; ++b) order[b] = o.bandMap ? o.bandMap[b] - 1 : b;  // band b <- Mat channel map[b]-1
+            write_tiff_u16_mapped(outMSS, h.get(), ow, arows[0], order);
+        }
+    }
+    OLOG("Fused task done in %.3f seconds.", total.tick());
+}
 
 }  // namespace OIPGPU

@@ -5,6 +5,7 @@
 //   oip stitch --image1 L.RAW --image2 R.RAW -c/--fold-cols N [-o OUT.RAW]       (main.cpp:159-190)
 //   oip --pan P.RAW --mss M.RAW [--do-rrc4pan --rrc-pan F --no-rrc4mss --rrc-msb1..4 F --slices
 //       --ibc-sections --ibc-threshold --line-offset --lines-section --overlap-lines -k]   (:193-252)
+//   oip task ...                fused flow of DOC/sample-task.sh, see run_task()
 //   oip -v | --version          prints 1.1
 // plus --width N (pixels per PAN line; the reference hard-codes 12288, oipshared.h:28).
 // `auxsep` is outside this build.  TIFF output and (uncompressed) TIFF input go through oip_tiff.hpp;
@@ -108,7 +109,10 @@ void usage()
          "Subcommands:\n"
          "  prestitch  --pan1 FILE --pan2 FILE [--rrc1 FILE --rrc2 FILE -s N -l N --stitch-overlap N\n"
          "             --stt-threshold X --stt-maxdeltay X -e N -r,--rrc/--no-rrc -c,--only-calculate]\n"
-         "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE]");
+         "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE] [-g,--GDAL -m,--band-map a,b,c,d]\n"
+         "  task       prestitch + stitch + default action x2 + stitch in one process (intermediates stay on the GPU):\n"
+         "             --pan1 --pan2 --rrc1 --rrc2 --mss1 --mss2 --rrc-mss{1,2}-b{1..4} FILE --fold-cols-pan N --fold-cols-mss N\n"
+         "             --out-pan FILE.TIFF --out-mss FILE.TIFF [prestitch, default-action and stitch options]");
 }
 
 int run_prestitch(const std::vector<std::string> &args, int width)
@@ -203,6 +207,65 @@ int run_default(const std::vector<std::string> &args, int width)
     return 0;
 }
 
+// oip task: DOC/sample-task.sh's five commands in one process, intermediates resident on the GPU
+int run_task(const std::vector<std::string> &args, int width)
+{
+    Spec sp;
+    sp.valued = {"--pan1", "--pan2", "--rrc1", "--rrc2", "--mss1", "--mss2", "--out-pan", "--out-mss", "--fold-cols-pan", "--fold-cols-mss",
+                 "--sections", "--section-lines", "--stitch-overlap", "--stt-threshold", "--stt-maxdeltay", "--edge-cols", "--band-map",
+                 "--slices", "--ibc-sections", "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width"};
+    for (int c = 1; c <= 2; ++c)
+        for (int b = 1; b <= MSS_BANDS; ++b) sp.valued.insert("--rrc-mss" + std::to_string(c) + "-b" + std::to_string(b));
+    sp.flags = {"--GDAL", "--keep-leading"};
+    sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-g", "--GDAL"}, {"-m", "--band-map"}, {"-k", "--keep-leading"}};
+    Parsed p = parse(sp, args);
+    std::string msb[2][MSS_BANDS];
+    for (auto k : {"--pan1", "--pan2", "--rrc1", "--rrc2", "--mss1", "--mss2", "--out-pan", "--out-mss", "--fold-cols-pan", "--fold-cols-mss"}) require(p, k);
+    for (int c = 0; c < 2; ++c)
+        for (int b = 0; b < MSS_BANDS; ++b) {
+            const std::string k = "--rrc-mss" + std::to_string(c + 1) + "-b" + std::to_string(b + 1);
+            require(p, k);
+            existing_file(p, k);
+            msb[c][b] = p.str(k);
+        }
+    for (auto k : {"--pan1", "--pan2", "--rrc1", "--rrc2", "--mss1", "--mss2"}) existing_file(p, k);
+    TaskOptions o;
+    o.width = p.integer("--width", width);
+    o.sections = p.integer("--sections", o.sections);
+    o.sectionLines = p.integer("--section-lines", o.sectionLines);
+    o.overlapCols = p.integer("--stitch-overlap", o.overlapCols);
+    o.edgeCols = p.integer("--edge-cols", 0);
+    if (o.edgeCols < 0 || o.edgeCols > o.overlapCols / 2) throw cli_error(105, "--edge-cols: invalid edge cols");
+    o.sttThreshold = p.real("--stt-threshold", o.sttThreshold);
+    o.sttMaxDeltaY = p.real("--stt-maxdeltay", 0.0);
+    o.foldColsPAN = p.integer("--fold-cols-pan", 0);
+    o.foldColsMSS = p.integer("--fold-cols-mss", 0);
+    if (o.foldColsPAN < 2 || o.foldColsMSS < 2) throw cli_error(105, "--fold-cols: fold column value too small");
+    o.useGDAL = p.has("--GDAL");
+    if (p.has("--band-map") && !o.useGDAL) throw cli_error(107, "--band-map requires --GDAL");
+    int map[MSS_BANDS] = {0, 0, 0, 0};
+    const std::string bandMap = p.str("--band-map");
+    if (!bandMap.empty()) {
+        if (sscanf(bandMap.c_str(), "%d,%d,%d,%d", map, map + 1, map + 2, map + 3) != 4) throw cli_error(105, "-m: need 4 band indices");
+        for (int i = 0; i < MSS_BANDS; ++i)
+            if (map[i] <= 0 || map[i] > MSS_BANDS) throw cli_error(105, "-m: invalid band index");
+        o.bandMap = map;
+    }
+    o.slices = p.integer("--slices", o.slices);
+    o.ibcSections = p.integer("--ibc-sections", o.ibcSections);
+    o.ibcThreshold = p.real("--ibc-threshold", o.ibcThreshold);
+    if (o.ibcThreshold < 0.0 || o.ibcThreshold >= 1.0) throw cli_error(105, "--ibc-threshold: invalid threshold value");
+    o.linesSection = p.integer("--lines-section", o.linesSection);
+    o.lineOffset = p.integer("--line-offset", 0);
+    o.overlapLines = p.integer("--overlap-lines", o.overlapLines);
+    o.keepLeading = p.flag.count("--keep-leading") != 0;
+    for (auto k : {"--out-pan", "--out-mss"})
+        if (to_lower(std::filesystem::path(p.str(k)).extension().string()) != ".tiff") throw std::invalid_argument("Output file should be a tiff image");
+    RunFusedTask(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), p.str("--mss1"), p.str("--mss2"), msb[0], msb[1],
+                 p.str("--out-pan"), p.str("--out-mss"), o);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, const char *argv[])
@@ -219,6 +282,7 @@ int main(int argc, const char *argv[])
             }
             if (!args.empty() && args[0] == "prestitch") return run_prestitch({args.begin() + 1, args.end()}, width);
             if (!args.empty() && args[0] == "stitch") return run_stitch({args.begin() + 1, args.end()}, width);
+            if (!args.empty() && args[0] == "task") return run_task({args.begin() + 1, args.end()}, width);
             if (!args.empty() && args[0] == "auxsep")
                 throw std::invalid_argument("auxsep (down-link de-framing) is outside this build: run the reference's auxsep, then this tool");
             if (args.empty()) { usage(); return 0; }

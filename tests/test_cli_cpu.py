@@ -123,3 +123,20 @@ def test_tiff_reader(tmp_path):
     (tmp_path / "bad.tiff").write_bytes(b"not a tiff at all")
     r = subprocess.run([str(exe), str(tmp_path / "bad.tiff"), str(tmp_path / "o5.raw")], capture_output=True, text=True)
     assert r.returncode == 3
+
+
+def test_task_subcommand_argument_errors(files):
+    """`oip task` (fused flow of DOC/sample-task.sh): argument checking happens before any device use"""
+    r = run(["task", "--pan1", "a.raw"], files)
+    assert r.returncode == 106 and "is required" in r.stderr
+    base = ["task", "--pan1", "a.raw", "--pan2", "b.raw", "--rrc1", "k.csv", "--rrc2", "k.csv", "--mss1", "a.raw", "--mss2", "b.raw",
+            "--out-pan", "p.TIFF", "--out-mss", "m.TIFF"]
+    for c in (1, 2):
+        for b in range(1, 5):
+            base += ["--rrc-mss%d-b%d" % (c, b), "k.csv"]
+    r = run(base + ["--fold-cols-pan", "1", "--fold-cols-mss", "12"], files)
+    assert r.returncode == 105 and "fold column value too small" in r.stderr
+    r = run(base + ["--fold-cols-pan", "40", "--fold-cols-mss", "12", "-m", "1,2,3,4"], files)
+    assert r.returncode == 107                                       # --band-map needs --GDAL
+    r = run(base + ["--fold-cols-pan", "40", "--fold-cols-mss", "12", "--bogus"], files)
+    assert r.returncode == 109

@@ -120,3 +120,67 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "-g", "-m", "3,2,9,4",
                         "--fold-cols", "12", "-o", "x.TIFF"], cwd=d, env=env, capture_output=True, text=True)
     assert r.returncode == 105
+
+
+def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
+    """`oip task` (everything resident on the GPU, four RAW files in, two TIFFs out) must
+    produce exactly the two products of DOC/sample-task.sh's five commands run through the file system."""
+    import time
+    W, L, OV = 1024, 33024, 64
+    d = str(tmp_path)
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"))
+    pan1, pan2 = _synth.ccd_pair(L, W, OV, (3, -2), seed=11)
+    rng = np.random.default_rng(4)
+
+    def mss_of(pan, shifts):
+        # four bands = 4x4 box means of the PAN strip, each displaced by a small shift, + a little noise
+        small = pan.astype(np.float64).reshape(L // 4, 4, W // 4, 4).mean(axis=(1, 3))
+        bands = [np.roll(small, (sy, sx), (0, 1)) + rng.normal(0, 2.0, small.shape) for sx, sy in shifts]
+        return np.concatenate([np.clip(np.rint(b), 0, 65535).astype(np.uint16) for b in bands], axis=1)      # BIL
+
+    mss1 = mss_of(pan1, [(1, 0), (0, 1), (-1, 0), (0, -1)])
+    mss2 = mss_of(pan2, [(0, 1), (1, 0), (0, -1), (-1, 0)])
+    for name, a in (("A_PAN-1.RAW", pan1), ("A_PAN-2.RAW", pan2), ("A_MSS-1.RAW", mss1), ("A_MSS-2.RAW", mss2)):
+        a.tofile(os.path.join(d, name))
+    _csv(os.path.join(d, "P1.csv"), _synth.lut(W, 1)); _csv(os.path.join(d, "P2.csv"), _synth.lut(W, 2))
+    for c in (1, 2):
+        for b in range(4):
+            _csv(os.path.join(d, "M%dB%d.csv" % (c, b + 1)), _synth.lut(W // 4, 30 + 4 * c + b))
+    stt = ["-s", "3", "-l", "1600", "--stitch-overlap", str(OV), "--stt-threshold", "0.05"]
+    ibc = ["--slices", "8", "--ibc-sections", "1", "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
+
+    def run(args):
+        r = subprocess.run([OIP] + args, cwd=d, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r
+
+    # ---- the reference's flow: five commands, six intermediate files
+    t0 = time.time()
+    run(["prestitch", "--width", str(W), "--pan1", "A_PAN-1.RAW", "--pan2", "A_PAN-2.RAW", "--rrc1", "P1.csv", "--rrc2", "P2.csv"] + stt)
+    run(["stitch", "--width", str(W), "--image1", "A_PAN-1.RRC.RAW", "--image2", "A_PAN-2.RRC.PRESTT.RAW", "--fold-cols", "40", "-o", "ref-PAN.TIFF"])
+    for c, s1 in ((1, "A_PAN-1.RRC.RAW"), (2, "A_PAN-2.RRC.PRESTT.RAW")):
+        run(["--width", str(W), "--pan", s1, "--mss", "A_MSS-%d.RAW" % c] + ibc + sum([["--rrc-msb%d" % (b + 1), "M%dB%d.csv" % (c, b + 1)] for b in range(4)], []))
+    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-o", "ref-MSS.TIFF"])
+    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-g", "-m", "3,2,1,4", "-o", "ref-MSS-g.TIFF"])
+    t_ref = time.time() - t0
+
+    # ---- the fused task
+    task = ["task", "--width", str(W), "--pan1", "A_PAN-1.RAW", "--pan2", "A_PAN-2.RAW", "--rrc1", "P1.csv", "--rrc2", "P2.csv",
+            "--mss1", "A_MSS-1.RAW", "--mss2", "A_MSS-2.RAW", "--fold-cols-pan", "40", "--fold-cols-mss", "12"] + stt + ibc
+    for c in (1, 2):
+        for b in range(4):
+            task += ["--rrc-mss%d-b%d" % (c, b + 1), "M%dB%d.csv" % (c, b + 1)]
+    t0 = time.time()
+    run(task + ["--out-pan", "fused-PAN.TIFF", "--out-mss", "fused-MSS.TIFF"])
+    t_fused = time.time() - t0
+    run(task + ["--out-pan", "fused-PAN2.TIFF", "--out-mss", "fused-MSS-g.TIFF", "-g", "-m", "3,2,1,4"])
+    for a, b in (("ref-PAN.TIFF", "fused-PAN.TIFF"), ("ref-MSS.TIFF", "fused-MSS.TIFF"), ("ref-MSS-g.TIFF", "fused-MSS-g.TIFF")):
+        ia, ta, _ = _tiff.read_tiff_u16(os.path.join(d, a))
+        ib, tb, _ = _tiff.read_tiff_u16(os.path.join(d, b))
+        assert ia.shape == ib.shape and np.array_equal(ia, ib), (a, b)
+        assert ta[262] == tb[262] and ta[277] == tb[277]
+    assert ia.any()                                    # not trivially empty
+    print("five commands %.2f s, fused task %.2f s" % (t_ref, t_fused))
+    # argument errors keep the CLI's codes
+    r = subprocess.run([OIP, "task", "--pan1", "A_PAN-1.RAW"], cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 106

@@ -93,13 +93,19 @@ __global__ __launch_bounds__(kBlock) void resize_cubic_kernel(const SrcT *__rest
 // already does to the correlation (the separate oip_resize_cubic_f32 entry keeps cv::resize's order
 // bit for bit).
 constexpr int kVRows = 4;       // output rows per thread of the vertical pass (they share most source rows)
+constexpr int kVBatch = 8;      // images per launch (the four bands of two units)
+template <typename SrcT> struct VBatch {
+    const SrcT *src[kVBatch];
+    float *dst[kVBatch];
+};
 template <typename SrcT>
-__global__ __launch_bounds__(kBlock) void resize_cubic_v_kernel(const SrcT *__restrict__ src, long spitch, int sw, int sh,
-                                                                float *__restrict__ dst, int dh,
+__global__ __launch_bounds__(kBlock) void resize_cubic_v_kernel(VBatch<SrcT> vb, long spitch, int sw, int sh, int dh,
                                                                 const int *__restrict__ yofs, const float4 *__restrict__ beta)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if (x >= sw) return;
+    const SrcT *__restrict__ src = vb.src[blockIdx.z];
+    float *__restrict__ dst = vb.dst[blockIdx.z];
 #pragma unroll
     for (int j = 0; j < kVRows; ++j) {
         const int dy = blockIdx.y * kVRows + j;
@@ -798,15 +804,20 @@ int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, fl
     return OIP_OK;
 }
 
-// vertical half only (see resize_cubic_v_kernel); *tab carries the horizontal taps for the FFT loader
+// vertical half only (see resize_cubic_v_kernel) of `count` equally shaped images in one launch; *tab
+// carries the horizontal taps for the FFT loader
 template <typename SrcT>
-int launch_resize_v(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, float *dst, int dw, int dh, const OipResizeTab **tab)
+int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int count, long spitch, int sw, int sh, int dw, int dh,
+                    const OipResizeTab **tab)
 {
     int rc = resize_tables(ctx, sw, sh, dw, dh, tab);
     if (rc) return rc;
+    if (count < 1 || count > kVBatch) return oip_fail(ctx, OIP_E_RUNTIME, "launch_resize_v: bad batch");
+    VBatch<SrcT> vb;
+    for (int i = 0; i < kVBatch; ++i) { vb.src[i] = src[i < count ? i : 0]; vb.dst[i] = dst[i < count ? i : 0]; }
     OipProfScope prof(ctx, "resize_cubic_v_kernel");
-    hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows), dim3(kBlock), 0, ctx->stream, src, spitch,
-                       sw, sh, dst, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
+    hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows, count), dim3(kBlock), 0,
+                       ctx->stream, vb, spitch, sw, sh, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
@@ -1171,30 +1182,32 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
     // (u16 -> f32, baseRows x bandSliceCols), the horizontal pass inside the FFT loader.
     const OipResizeTab *tab = nullptr;
-    auto upsample = [&](const Unit &un, float *const fb[4], RealSrc out[4]) -> int {
-        for (int b = 0; b < OIP_MSS_BANDS; ++b) {
-            const uint16_t *bw = d_planes + (size_t)b * plane_stride + (size_t)un.bandRow0 * Wb + (size_t)un.slice * bandSliceCols;
-            int rc2 = launch_resize_v<uint16_t>(ctx, bw, Wb, bandSliceCols, bandRows, fb[b], baseSliceCols, baseRows, &tab);
-            if (rc2) return rc2;
-            out[b] = src_v(fb[b]);
-        }
-        return OIP_OK;
+    // vertical passes of all bands of one or two units in one launch
+    auto upsample = [&](const Unit *const *uns, int nun, float *const *fb, RealSrc *out) -> int {
+        const uint16_t *srcs[kVBatch];
+        for (int u = 0; u < nun; ++u)
+            for (int b = 0; b < OIP_MSS_BANDS; ++b) {
+                srcs[4 * u + b] = d_planes + (size_t)b * plane_stride + (size_t)uns[u]->bandRow0 * Wb + (size_t)uns[u]->slice * bandSliceCols;
+                out[4 * u + b] = src_v(fb[4 * u + b]);
+            }
+        return launch_resize_v<uint16_t>(ctx, srcs, fb, 4 * nun, Wb, bandSliceCols, bandRows, baseSliceCols, baseRows, &tab);
     };
     size_t k = 0;
-    RealSrc sA[4], sB[4];
+    RealSrc sAB[8];
     for (; k + 1 < units.size(); k += 2) {
         const Unit &A = units[k], &B = units[k + 1];
-        if ((rc = upsample(A, w.fb, sA))) return rc;
-        if ((rc = upsample(B, w.fb + 4, sB))) return rc;
+        const Unit *two[2] = {&A, &B};
+        if ((rc = upsample(two, 2, w.fb, sAB))) return rc;
         const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
-        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), sA, src_u16(B.pw, W), sB, baseRows, baseSliceCols,
+        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), sAB, src_u16(B.pw, W), sAB + 4, baseRows, baseSliceCols,
                                       d_res + 12 * A.u, d_res + 12 * B.u, &vt))) return rc;
     }
     if (k < units.size()) {
         const Unit &A = units[k];
-        if ((rc = upsample(A, w.fb, sA))) return rc;
+        const Unit *one[1] = {&A};
+        if ((rc = upsample(one, 1, w.fb, sAB))) return rc;
         const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
-        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), sA, baseRows, baseSliceCols, d_res + 12 * A.u, &vt))) return rc;
+        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), sAB, baseRows, baseSliceCols, d_res + 12 * A.u, &vt))) return rc;
     }
     std::vector<double> r(12 * n);
     if ((rc = fetch_results(ctx, 12 * n, r.data()))) return rc;

@@ -468,7 +468,13 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             const bool staged = cend - cbase < kSeg && F * kSeg * 2 * sizeof(float) <= sizeof(float2) * F * Vp;
             if (staged) {
                 float *seg = reinterpret_cast<float *>(buf);            // [2][F][kSeg]
-                constexpr int PERS = (F * kSeg + kFftBlock - 1) / kFftBlock;
+                // The PAN window (u16 in the real slot) goes through LDS too when its rows are 16-byte
+                // aligned: one 16-byte load per 8 pixels instead of eight 2-byte loads per lane -- the
+                // loader is bound by the number of vector-memory instructions, not by bytes.
+                unsigned short *seg16 = reinterpret_cast<unsigned short *>(seg + 2 * F * kSeg);      // [F][V]
+                const bool wide16 = io.re16 && !io.re_v && V == 16 && (io.cols & 7) == 0 && (io.pitch_re16 & 7) == 0 &&
+                                    ((size_t)io.re16 & 15) == 0 &&
+                                    sizeof(float) * 2 * F * kSeg + sizeof(unsigned short) * F * V <= sizeof(float2) * F * Vp;
                 // directly readable components first: their loads and the staging loads below are
                 // then one round of memory latency, not two
 #pragma unroll
@@ -479,25 +485,58 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
                     if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
                         if (io.re_v) {}
                         else if (io.re) z.x = io.re[(size_t)y * io.cols + x];
-                        else if (io.re16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
+                        else if (io.re16 && !wide16) z.x = __uint_as_float((unsigned)io.re16[(size_t)y * io.pitch_re16 + x]);
                         if (io.im_v) {}
                         else if (io.im) z.y = io.im[(size_t)y * io.cols + x];
                         else if (io.im16) z.y = __uint_as_float((unsigned)io.im16[(size_t)y * io.pitch_im16 + x]);
                     }
                     zz[i] = z;
                 }
+                if (wide16) {
+                    for (int e = threadIdx.x; e < 2 * F; e += kFftBlock) {
+                        const int n = e >> 1, half = e & 1;
+                        const int y = y0 + n * p.S, xc = tt.lane0 + 8 * half;
+                        uint4 px = make_uint4(0u, 0u, 0u, 0u);
+                        if (y < io.rows && xc < io.cols) px = *reinterpret_cast<const uint4 *>(io.re16 + (size_t)y * io.pitch_re16 + xc);
+                        *reinterpret_cast<uint4 *>(seg16 + n * V + 8 * half) = px;
+                    }
+                }
+                // the tap runs: 8-byte loads where the run starts on an even column of an even-pitch image
+                const bool pair_ok = (io.v_cols & 1) == 0 && (cbase & 1) == 0 && (kSeg & 1) == 0;
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
                     const float *__restrict__ Vs = sl ? io.im_v : io.re_v;
                     if (!Vs) continue;
+                    if (pair_ok) {
+                        constexpr int PERS2 = (F * kSeg / 2 + kFftBlock - 1) / kFftBlock;
 #pragma unroll
-                    for (int i = 0; i < PERS; ++i) {
-                        const int e = threadIdx.x + i * kFftBlock;
-                        const int n = e / kSeg, j = e % kSeg;
-                        const int y = y0 + n * p.S;
-                        if ((F * kSeg % kFftBlock == 0 || n < F) && y < io.rows) {
-                            const int c = cbase + j < io.v_cols ? cbase + j : io.v_cols - 1;
-                            seg[(sl * F + n) * kSeg + j] = Vs[(size_t)y * io.v_cols + c];
+                        for (int i = 0; i < PERS2; ++i) {
+                            const int e = threadIdx.x + i * kFftBlock;
+                            const int n = e / (kSeg / 2), j = 2 * (e % (kSeg / 2));
+                            const int y = y0 + n * p.S;
+                            if ((F * kSeg / 2 % kFftBlock == 0 || n < F) && y < io.rows) {
+                                const float *row = Vs + (size_t)y * io.v_cols;
+                                float2 v2;
+                                if (cbase + j + 1 < io.v_cols) {
+                                    v2 = *reinterpret_cast<const float2 *>(row + cbase + j);
+                                } else {
+                                    const int last = io.v_cols - 1;
+                                    v2 = make_float2(row[cbase + j < last ? cbase + j : last], row[last]);
+                                }
+                                *reinterpret_cast<float2 *>(seg + (sl * F + n) * kSeg + j) = v2;
+                            }
+                        }
+                    } else {
+                        constexpr int PERS = (F * kSeg + kFftBlock - 1) / kFftBlock;
+#pragma unroll
+                        for (int i = 0; i < PERS; ++i) {
+                            const int e = threadIdx.x + i * kFftBlock;
+                            const int n = e / kSeg, j = e % kSeg;
+                            const int y = y0 + n * p.S;
+                            if ((F * kSeg % kFftBlock == 0 || n < F) && y < io.rows) {
+                                const int c = cbase + j < io.v_cols ? cbase + j : io.v_cols - 1;
+                                seg[(sl * F + n) * kSeg + j] = Vs[(size_t)y * io.v_cols + c];
+                            }
                         }
                     }
                 }
@@ -516,6 +555,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
                     const int y = y0 + n * p.S;
                     if ((TOTAL % kFftBlock == 0 || n < F) && xin && y < io.rows) {
                         if (io.re_v) zz[i].x = taps(seg + n * kSeg);
+                        else if (wide16) zz[i].x = __uint_as_float((unsigned)seg16[n * V + v]);
                         if (io.im_v) zz[i].y = taps(seg + (F + n) * kSeg);
                     }
                 }
@@ -558,7 +598,12 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             }
         }
     };
-    issue_loads(t);
+    if (IOK == 1 && (p.dbg & 1)) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) zz[i] = make_float2(1.f, 0.f);
+    } else {
+        issue_loads(t);
+    }
     for (int i = threadIdx.x; i < TWN; i += kFftBlock) tw[i] = twF[i];
 
     for (;;) {
@@ -594,7 +639,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             issue_loads(tn);               // in flight during the stages below
         }
 
-        Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw);
+        if (!(IOK == 1 && (p.dbg & 2))) Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw);
 
         if ((IOK == 2 && io.store_kind == 1)) {
             // the scan of the tile ends (barrier inside store_peak) before the scratch is written
@@ -609,7 +654,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             for (int e = threadIdx.x; e < TOTAL; e += kFftBlock) {
                 const int v = MODE == 0 ? (e & (V - 1)) : e / F;
                 const int n = MODE == 0 ? (e >> VS) : e - v * F;
-                if (v >= t.nv) continue;
+                if (v >= t.nv || (IOK == 1 && (p.dbg & 4))) continue;
                 float2 z = buf[n * Vp + v];
                 if (p.inverse) z.y = -z.y;
                 else if (tile_tw) z = cmul(z, twj[n]);
@@ -624,6 +669,175 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
         tile = next;
     }
 }
+
+// ---- first forward column pass with fused x4 up-sampling: persistent over rows, register prefetch ----
+// The generic fused loader above spends most of its time waiting: a tile's source rows are S rows apart
+// (a DRAM page and a TLB entry each), eight workgroups per CU are all the LDS allows, and each of them
+// sits through load -> LDS -> barrier -> taps -> barrier before its transform starts (measured: 0.09 of
+// 0.22 ms).  This kernel is the same pass for the one geometry that matters (16-lane tiles, exact x4
+// up-sampling, 16-byte aligned u16 rows; the host checks and otherwise falls back): a workgroup keeps its
+// lane tile and walks the tile rows o1 = blockIdx.y, + gridDim.y, ..., and the raw source data of the
+// NEXT tile -- one 16-byte load of PAN pixels, two 8-byte loads per up-sampled band, one twiddle -- is
+// requested before the transform of the current one, so it lands while the butterflies and stores run.
+template <int F, int NT, int... Rs>
+__global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
+                                                              const float2 *__restrict__ twF, const float2 *__restrict__ twT)
+{
+    constexpr int VS = 4, V = 16, Vp = V + 1, kSeg = 8;
+    constexpr int TWN = TwTable<F, Rs...>::value();
+    constexpr int NLD = F * V / NT;                     // tile elements per thread
+    constexpr int NRV = F * kSeg / 2 / NT;              // 8-byte tap-run loads per thread and band
+    static_assert(F * V % NT == 0 && F * kSeg / 2 % NT == 0 && 2 * F <= NT && F <= NT && NT % V == 0, "tile / block shape");
+    static_assert(sizeof(float) * 2 * F * kSeg + sizeof(unsigned short) * F * V <= sizeof(float2) * F * Vp, "staging fits the tile buffer");
+    __shared__ float2 buf[F * Vp];
+    __shared__ float2 tw[TWN];
+    __shared__ float2 twj[F];
+    float *seg = reinterpret_cast<float *>(buf);                                         // [2][F][kSeg] tap runs
+    unsigned short *seg16 = reinterpret_cast<unsigned short *>(seg + 2 * F * kSeg);       // [F][V] PAN pixels
+
+    // lane tile: contiguous chunks per XCD (see decode_tile)
+    const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
+    const int rel = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+    if (rel >= ltn) return;
+    const int lane0 = (p.lt0 + rel) << VS;
+    const int nv = p.lanes - lane0 < V ? (int)(p.lanes - lane0) : V;
+    const int o2 = blockIdx.z;
+    const int v = threadIdx.x & (V - 1);
+    const int x = lane0 + v;
+    const bool xin = v < nv && x < io.cols;
+    // horizontal taps of this thread's column (exact x4: first tap column = ((x - 2) >> 2) - 1)
+    const int lastc = io.v_cols - 1;
+    int cb = ((lane0 - 2) >> 2) - 1;
+    const int cbase = cb < 0 ? 0 : (cb > lastc ? lastc : cb);
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xin) {
+        const int sx = (x - 2) >> 2;
+        a = reinterpret_cast<const float4 *>(io.alpha)[x];
+        int c0 = sx - 1, c1 = sx, c2 = sx + 1, c3 = sx + 2;
+        c0 = c0 < 0 ? 0 : (c0 > lastc ? lastc : c0);
+        c1 = c1 < 0 ? 0 : (c1 > lastc ? lastc : c1);
+        c2 = c2 < 0 ? 0 : (c2 > lastc ? lastc : c2);
+        c3 = c3 < 0 ? 0 : (c3 > lastc ? lastc : c3);
+        r0 = c0 - cbase; r1 = c1 - cbase; r2 = c2 - cbase; r3 = c3 - cbase;
+    }
+    const bool has16 = io.re16 != nullptr;
+    const float *__restrict__ V0 = io.re_v, *__restrict__ V1 = io.im_v;
+    for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
+
+    // raw data of one tile: everything is loaded unconditionally from clamped addresses (a select on a
+    // loaded value would wait for the load where it is issued); validity is applied when it is used
+    uint4 rpx = make_uint4(0u, 0u, 0u, 0u);
+    float2 rv[2][NRV];
+    float2 rtw = make_float2(1.f, 0.f);
+    auto fetch = [&](int o1, int tid) {
+        const int y0 = o2 * p.T + o1;
+        if (has16) {
+            const int n = tid >> 1, half = tid & 1;
+            int y = y0 + (n < F ? n : F - 1) * p.S;
+            y = y < io.rows ? y : io.rows - 1;
+            int xc = lane0 + 8 * half;
+            xc = xc < io.cols ? xc : io.cols - 8;
+            rpx = *reinterpret_cast<const uint4 *>(io.re16 + (size_t)y * io.pitch_re16 + xc);
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const float *__restrict__ Vs = sl ? V1 : V0;
+            if (!Vs) continue;
+#pragma unroll
+            for (int i = 0; i < NRV; ++i) {
+                const int e = tid + i * NT;
+                const int n = e / (kSeg / 2), j = 2 * (e % (kSeg / 2));
+                int y = y0 + n * p.S;
+                y = y < io.rows ? y : io.rows - 1;
+                int c = cbase + j;
+                c = c + 1 <= lastc ? c : lastc - 1;                 // the pair stays inside the row
+                rv[sl][i] = *reinterpret_cast<const float2 *>(Vs + (size_t)y * io.v_cols + c);
+            }
+        }
+        if (tid < F) rtw = twT[(long)o1 * tid];
+    };
+    float2 zz[NLD];
+    auto expand = [&](int o1, int tid) {
+        const int y0 = o2 * p.T + o1;
+        if (has16) {
+            const int n = tid >> 1, half = tid & 1;
+            if (n < F) *reinterpret_cast<uint4 *>(seg16 + n * V + 8 * half) = rpx;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            if (!(sl ? V1 : V0)) continue;
+#pragma unroll
+            for (int i = 0; i < NRV; ++i) {
+                const int e = tid + i * NT;
+                const int n = e / (kSeg / 2), j = 2 * (e % (kSeg / 2));
+                float2 v2 = rv[sl][i];
+                // a pair pulled back from the row end holds column lastc in its second half
+                if (cbase + j + 1 > lastc) v2 = make_float2(v2.y, v2.y);
+                *reinterpret_cast<float2 *>(seg + (sl * F + n) * kSeg + j) = v2;
+            }
+        }
+        if (tid < F) twj[tid] = rtw;
+        __syncthreads();
+        auto taps = [&](const float *__restrict__ row) {
+            float r = __fmul_rn(row[r0], a.x);
+            r = __fadd_rn(r, __fmul_rn(row[r1], a.y));
+            r = __fadd_rn(r, __fmul_rn(row[r2], a.z));
+            r = __fadd_rn(r, __fmul_rn(row[r3], a.w));
+            return r;
+        };
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int n = (tid >> VS) + i * (NT >> VS);
+            const int y = y0 + n * p.S;
+            float2 z = make_float2(0.f, 0.f);
+            if (xin && y < io.rows) {
+                if (has16) z.x = (float)seg16[n * V + v];
+                else if (V0) z.x = taps(seg + n * kSeg);
+                if (V1) z.y = taps(seg + (F + n) * kSeg);
+            }
+            zz[i] = z;
+        }
+        __syncthreads();                    // the staging area is the tile buffer
+    };
+
+    int o1 = blockIdx.y;
+    if (o1 >= p.O1) return;
+    fetch(o1, threadIdx.x);
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));       // per-iteration opaque copy: no loop-invariant stage addressing in registers
+        expand(o1, tid);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int n = (tid >> VS) + i * (NT >> VS);
+            buf[n * Vp + (tid & (V - 1))] = zz[i];
+        }
+        __syncthreads();
+        const int o1n = o1 + gridDim.y;
+        const bool more = o1n < p.O1;
+        if (more) fetch(o1n, tid);               // in flight during the transform and the stores below
+        __builtin_amdgcn_sched_barrier(0);
+        Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw, tid);
+        const long base = (long)o2 * p.o2_stride + (long)o1 * p.o1_stride + lane0;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int n = (tid >> VS) + i * (NT >> VS);
+            if (v < nv) data[base + (long)n * p.nstride + v] = cmul(buf[n * Vp + (tid & (V - 1))], twj[n]);
+        }
+        if (!more) break;
+        __syncthreads();                    // buf and twj are free for the next tile
+        o1 = o1n;
+    }
+}
+
+struct FirstUpKernel {
+    int F, threads;
+    void (*fn)(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);
+};
+const FirstUpKernel kFirstUp[] = {
+    {128, 256, fft_first_pass_up_kernel<128, 256, 8, 4, 4>},
+};
 
 // table of specialisations: (F, log2 V, mode) -> kernel
 struct FastKernel {
@@ -896,6 +1110,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d%s" : "fft_pass_kernel_F%d%s"), p.F,
              io.load_kind == 1 ? "_pack" : (io.store_kind == 1 ? "_peak" : ""));
     OipProfScope prof(ctx, pname);
+    { const char *e = getenv("OIP_PACK_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid3((unsigned)blocks);
     p.grid3 = 0;
     if (p.mode == 0 && (p.O1 > 65535 || p.O2 > 65535)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass: more than 65535 rows or blocks");
@@ -904,6 +1119,25 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
         const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
         p.xcd_chunk = (ltn + 7) / 8;
         grid3 = dim3((unsigned)(8 * p.xcd_chunk), (unsigned)p.O1, (unsigned)p.O2);
+    }
+    // the persistent first pass with fused up-sampling, when the geometry allows (see the kernel)
+    if (blocks_override <= 0 && !inverse && io.load_kind == 1 && p.mode == 0 && p.axis == 1 && p.vshift == 4 && p.tw_mode == 2 &&
+        (io.re_v || io.im_v) && io.x4 && !io.re && !io.im && !io.im16 && !(io.re16 && io.re_v) && (io.v_cols & 1) == 0 &&
+        io.v_cols >= 8 && io.cols >= 8 && io.rows >= 1 &&
+        (!io.re16 || ((io.cols & 7) == 0 && (io.pitch_re16 & 7) == 0 && ((size_t)io.re16 & 15) == 0)) &&
+        ((size_t)io.re_v & 7) == 0 && ((size_t)io.im_v & 7) == 0) {
+        static const char *envu = getenv("OIP_FIRST_UP");                 // experiment knob: 0 disables, N = tile rows per workgroup
+        const int tiles = envu ? atoi(envu) : 3;
+        for (const FirstUpKernel &k : kFirstUp)
+            if (k.F == p.F && tiles > 0) {
+                const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
+                p.xcd_chunk = (ltn + 7) / 8;
+                const int gy = (p.O1 + tiles - 1) / tiles;
+                hipLaunchKernelGGL(k.fn, dim3((unsigned)(8 * p.xcd_chunk), (unsigned)gy, (unsigned)p.O2), dim3(k.threads), 0, ctx->stream,
+                                   data, p, io, twF, twT);
+                OIP_HIP(ctx, hipGetLastError());
+                return OIP_OK;
+            }
     }
     if (p.fast >= 0) {
         p.ntiles = blocks;

@@ -67,6 +67,7 @@ struct OipFftPass {
     int lt0, ltn;       // lane-tile window of this launch (column panel); ltn == 0: all
     int fast;           // index of a compile-time specialised kernel, -1: generic
     int grid3;          // mode 0 launched as a (lane tile, o1, o2) grid: the tile needs no divisions to decode
+    int dbg;            // experiment mask for the fused-loader kernels (OIP_PACK_DBG): 1 no loads, 2 no stages, 4 no stores
     int xcd_chunk;      // grid3: lane tiles per XCD (grid x = 8 * xcd_chunk >= lane tiles); see decode_tile
 };
 

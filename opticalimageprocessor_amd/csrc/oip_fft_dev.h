@@ -143,7 +143,7 @@ template <int F, int First, int... Rest> struct TwTable {          // entries of
 };
 
 template <int F, int VS, int VP, int NT, int Ns, int R>
-__device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 *__restrict__ tw)
+__device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 *__restrict__ tw, int tid)
 {
     constexpr int kFftBlock = NT;
     constexpr int V = 1 << VS;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 
     float2 x[PER][R];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int item = threadIdx.x + i * kFftBlock;
+        const int item = tid + i * kFftBlock;
         if (ITEMS % kFftBlock == 0 || item < ITEMS) {
             const int v = item & (V - 1), b = item >> VS;
 #pragma unroll
@@ -165,7 +165,7 @@ __device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        const int item = threadIdx.x + i * kFftBlock;
+        const int item = tid + i * kFftBlock;
         if (ITEMS % kFftBlock == 0 || item < ITEMS) {
             const int v = item & (V - 1), b = item >> VS;
             const int k = b % Ns;
@@ -190,13 +190,15 @@ __device__ __forceinline__ void stage_ct(float2 *__restrict__ buf, const float2 
 
 template <int F, int VS, int VP, int NT, int Ns, int... Rs> struct Stages;
 template <int F, int VS, int VP, int NT, int Ns> struct Stages<F, VS, VP, NT, Ns> {
-    static __device__ __forceinline__ void run(float2 *, const float2 *) {}
+    static __device__ __forceinline__ void run(float2 *, const float2 *, int = 0) {}
 };
 template <int F, int VS, int VP, int NT, int Ns, int R, int... Rest> struct Stages<F, VS, VP, NT, Ns, R, Rest...> {
-    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw)
+    // tid: threadIdx.x, or an opaque copy of it inside persistent loops (keeps the stage addressing from
+    // being hoisted out of the loop and held in registers)
+    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw, int tid = threadIdx.x)
     {
-        stage_ct<F, VS, VP, NT, Ns, R>(buf, tw);
-        Stages<F, VS, VP, NT, Ns * R, Rest...>::run(buf, tw);
+        stage_ct<F, VS, VP, NT, Ns, R>(buf, tw, tid);
+        Stages<F, VS, VP, NT, Ns * R, Rest...>::run(buf, tw, tid);
     }
 };
 

@@ -21,6 +21,9 @@ def bench_name(kernel):
     if m:
         F, iok = int(m.group(1)), int(m.group(5))
         return "fft_pass_ct_kernel_F%d%s" % (F, {0: "", 1: "_pack", 2: "_peak"}[iok])
+    m = re.search(r"fft_first_pass_up_kernel<(\d+)", kernel)
+    if m:
+        return "fft_pass_ct_kernel_F%d_pack" % int(m.group(1))       # the library profiles it under the pass's name
     m = re.search(r"([A-Za-z_0-9]+_kernel)\b", kernel)
     return m.group(1) if m else kernel
 

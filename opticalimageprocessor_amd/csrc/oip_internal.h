@@ -30,6 +30,7 @@ struct OipResizeTab {
     int sw, sh, dw, dh;
     bool x4;            // exact x4 up-sampling: the 4x4-per-lane kernel applies
     int x4h;            // xofs[dx] == (dx - 2) >> 2 for every dx: the FFT loader needs no xofs look-up
+    int x4v;            // yofs[dy] == (dy - 2) >> 2 for every dy: the sliding-window vertical kernel applies
     int *d_xofs;
     float *d_alpha;     // dw x 4
     int *d_yofs;

@@ -769,6 +769,8 @@ int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeT
     for (int dy = 0; dy < dh && t.x4; ++dy) { int o = (yofs[dy] - 1) - (dy / 4 - 2); t.x4 = o == 0 || o == 1; }
     t.x4h = 1;
     for (int dx = 0; dx < dw && t.x4h; ++dx) t.x4h = xofs[dx] == ((dx - 2) >> 2);
+    t.x4v = 1;
+    for (int dy = 0; dy < dh && t.x4v; ++dy) t.x4v = yofs[dy] == ((dy - 2) >> 2);
     OIP_HIP(ctx, hipMalloc((void **)&t.d_xofs, sizeof(int) * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_alpha, sizeof(float) * 4 * dw));
     OIP_HIP(ctx, hipMalloc((void **)&t.d_yofs, sizeof(int) * dh));
@@ -804,6 +806,53 @@ int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, fl
     return OIP_OK;
 }
 
+// The same for the exact x4 geometry (host-verified: yofs[dy] == (dy - 2) >> 2, even widths and pitch): a
+// thread owns two adjacent columns and kV4Blocks source rows; the four outputs of source row p use rows
+// p-2 .. p+2, so a 5-row window slides down one row per 4 outputs -- 1.25 loads of a pixel pair per 4 x 2
+// outputs instead of 32 -- and the outputs leave as 8-byte stores.  Same taps, same f32 order.
+constexpr int kV4Blocks = 8;        // source rows (= 4 output rows each) per thread
+constexpr int kV4Threads = 128;
+template <typename SrcT>
+__global__ __launch_bounds__(kV4Threads) void resize_cubic_v_x4_kernel(VBatch<SrcT> vb, long spitch, int sw, int sh, int dh,
+                                                                      const float4 *__restrict__ beta)
+{
+    const int c = blockIdx.x * kV4Threads + threadIdx.x;            // column pair
+    if (2 * c >= sw) return;
+    const SrcT *__restrict__ src = vb.src[blockIdx.z] + 2 * c;
+    float *__restrict__ dst = vb.dst[blockIdx.z] + 2 * c;
+    const int p0 = blockIdx.y * kV4Blocks;
+    auto load = [&](int r) {                                        // clamped source row as two floats
+        r = r < 0 ? 0 : (r > sh - 1 ? sh - 1 : r);
+        const SrcT *q = src + (size_t)r * spitch;
+        return make_float2((float)q[0], (float)q[1]);
+    };
+    float2 w0 = load(p0 - 2), w1 = load(p0 - 1), w2 = load(p0), w3 = load(p0 + 1), w4;
+#pragma unroll
+    for (int k = 0; k < kV4Blocks; ++k) {
+        const int p = p0 + k;
+        if (4 * p >= dh) break;
+        w4 = load(p + 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = 4 * p + j;
+            const float4 b = beta[dy];
+            // rows (dy - 2 >> 2) - 1 ... + 2: p-2..p+1 for j = 0, 1 and p-1..p+2 for j = 2, 3
+            const float2 t0 = j < 2 ? w0 : w1, t1 = j < 2 ? w1 : w2, t2 = j < 2 ? w2 : w3, t3 = j < 2 ? w3 : w4;
+            float2 o;
+            o.x = __fmul_rn(t0.x, b.x);
+            o.x = __fadd_rn(o.x, __fmul_rn(t1.x, b.y));
+            o.x = __fadd_rn(o.x, __fmul_rn(t2.x, b.z));
+            o.x = __fadd_rn(o.x, __fmul_rn(t3.x, b.w));
+            o.y = __fmul_rn(t0.y, b.x);
+            o.y = __fadd_rn(o.y, __fmul_rn(t1.y, b.y));
+            o.y = __fadd_rn(o.y, __fmul_rn(t2.y, b.z));
+            o.y = __fadd_rn(o.y, __fmul_rn(t3.y, b.w));
+            if (dy < dh) *reinterpret_cast<float2 *>(dst + (size_t)dy * sw) = o;
+        }
+        w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+    }
+}
+
 // vertical half only (see resize_cubic_v_kernel) of `count` equally shaped images in one launch; *tab
 // carries the horizontal taps for the FFT loader
 template <typename SrcT>
@@ -816,6 +865,15 @@ int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int
     VBatch<SrcT> vb;
     for (int i = 0; i < kVBatch; ++i) { vb.src[i] = src[i < count ? i : 0]; vb.dst[i] = dst[i < count ? i : 0]; }
     OipProfScope prof(ctx, "resize_cubic_v_kernel");
+    bool aligned = (sw & 1) == 0 && (spitch & 1) == 0 && dh == 4 * sh && (*tab)->x4v;
+    for (int i = 0; i < count; ++i) aligned = aligned && ((size_t)src[i] % (2 * sizeof(SrcT))) == 0 && ((size_t)dst[i] & 7) == 0;
+    { const char *e = getenv("OIP_V_GENERIC"); if (e && atoi(e)) aligned = false; }      // test knob: force the generic kernel
+    if (aligned) {
+        hipLaunchKernelGGL(resize_cubic_v_x4_kernel<SrcT>, dim3((sw / 2 + kV4Threads - 1) / kV4Threads, (sh + kV4Blocks - 1) / kV4Blocks, count),
+                           dim3(kV4Threads), 0, ctx->stream, vb, spitch, sw, sh, dh, reinterpret_cast<const float4 *>((*tab)->d_beta));
+        OIP_HIP(ctx, hipGetLastError());
+        return OIP_OK;
+    }
     hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows, count), dim3(kBlock), 0,
                        ctx->stream, vb, spitch, sw, sh, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
     OIP_HIP(ctx, hipGetLastError());

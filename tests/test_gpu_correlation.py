@@ -188,3 +188,20 @@ def test_interband_reference_unit_shape_matches_oracle(ctx, oracle_mod):
 def test_interband_12288_wide_shape_matches_oracle(ctx, oracle_mod):
     """slice width 1228 -> 1250-point rows (the reference's 12288-pixel strips): fused row stage for 1250"""
     _interband_vs_oracle(ctx, 4000, 9824, 8, 1, 4000)
+
+
+def test_vertical_upsampling_kernels_agree(ctx):
+    """the sliding-window x4 vertical kernel and the generic one feed the FFT identical images: the whole
+    correlation table must come out bit for bit the same"""
+    import os
+    Lp, W, slices = 3200, 2560, 8
+    pan, bands = _synth.pan_mss(Lp, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=3)
+    planes = _cuda(np.stack(bands, 0))
+    args = (_cuda(pan), Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, 1, 3200)
+    try:
+        os.environ["OIP_V_GENERIC"] = "1"
+        a = ctx.interband_correlate(*args)
+    finally:
+        os.environ.pop("OIP_V_GENERIC", None)
+    b = ctx.interband_correlate(*args)
+    assert np.array_equal(a, b)

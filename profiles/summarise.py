@@ -24,6 +24,8 @@ def bench_name(kernel):
     m = re.search(r"fft_first_pass_up_kernel<(\d+)", kernel)
     if m:
         return "fft_pass_ct_kernel_F%d_pack" % int(m.group(1))       # the library profiles it under the pass's name
+    if "resize_cubic_v_x4_kernel" in kernel:
+        return "resize_cubic_v_kernel"                                # profiled under the generic kernel's name
     m = re.search(r"([A-Za-z_0-9]+_kernel)\b", kernel)
     return m.group(1) if m else kernel
 

@@ -385,15 +385,11 @@ __device__ __forceinline__ float2 load_elem_raw(const float2 *__restrict__ data,
     return z;
 }
 
-// PERSIST: workgroups walk tiles blockIdx.x, +gridDim.x, ... and issue the global loads of the
-// NEXT tile into registers right after the current tile has been committed to LDS, so they are
-// in flight while the butterflies run.  It costs ~50 VGPRs; measured on MI355X it pays for the
-// 128-point column pass (5.1 TB/s) and loses occupancy elsewhere, so it is a per-kernel choice.
 // IOK 0: plain pass (complex array in, complex array out); 1: fused loader (io.load_kind 1), plain
 // store; 2: plain load, fused store (io.store_kind 1 or 2).  Separate instantiations because the
 // kernel arguments of the fusions cost scalar registers -- past 100 a wave of occupancy goes, and
 // these passes are latency-bound enough to lose 15-20 % with it.
-template <int F, int VS, int MODE, int NT, bool PERSIST, int IOK, int... Rs>
+template <int F, int VS, int MODE, int NT, int IOK, int... Rs>
 __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ data, OipFftPass p, OipFftIo io,
                                                          const float2 *__restrict__ twF,
                                                          const float2 *__restrict__ twT)
@@ -411,7 +407,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 
     const long ntiles = (IOK == 2 && io.store_kind == 2) ? gridDim.x : p.ntiles;
     long tile = blockIdx.x;
-    if (!(MODE == 0 && !PERSIST) && tile >= ntiles) return;
+    if (MODE != 0 && tile >= ntiles) return;
     Tile t;
     int wn0 = 0, wv0 = 0;
     if ((IOK == 2 && io.store_kind == 2)) {
@@ -419,9 +415,9 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
-    } else if (MODE == 0 && !PERSIST) {
+    } else if (MODE == 0) {
         OipFftPass pg = p;
-        pg.grid3 = 1;                  // launch_pass always gives non-persistent mode-0 passes the 3-D grid
+        pg.grid3 = 1;                  // launch_pass always gives mode-0 passes the 3-D grid
         t = decode_tile(pg, 0);
         if (t.nv <= 0) return;         // padding workgroup of the XCD-chunked grid
     } else {
@@ -606,7 +602,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
     }
     for (int i = threadIdx.x; i < TWN; i += kFftBlock) tw[i] = twF[i];
 
-    for (;;) {
+    {
         if (tile_tw) {
             for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = twT[(long)t.o1 * i];
             if (p.inverse) __syncthreads();
@@ -630,14 +626,6 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
             }
         }
         __syncthreads();
-
-        const long next = tile + gridDim.x;
-        const bool has_next = PERSIST && io.store_kind != 2 && next < ntiles;
-        Tile tn = t;
-        if (has_next) {
-            tn = decode_tile(p, next);
-            issue_loads(tn);               // in flight during the stages below
-        }
 
         if (!(IOK == 1 && (p.dbg & 2))) Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw);
 
@@ -663,10 +651,6 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
                 data[off] = z;
             }
         }
-        if (!has_next) break;
-        __syncthreads();                   // everyone is done with buf / twj of this tile
-        t = tn;
-        tile = next;
     }
 }
 
@@ -842,25 +826,24 @@ const FirstUpKernel kFirstUp[] = {
 // table of specialisations: (F, log2 V, mode) -> kernel
 struct FastKernel {
     int F, vshift, mode, threads;
-    bool persist;
     void (*fn[3])(float2 *, OipFftPass, OipFftIo, const float2 *, const float2 *);         // by IOK: plain, fused load, fused store
 };
 const FastKernel kFast[] = {
     // column passes of 16000 = 125 * 128 (and other 5^3 / 2^7 factors): 16 lanes = 128-byte
     // segments, 17 KiB of LDS per workgroup -> 8 workgroups per CU (measured faster than 32 lanes)
-    {125, 4, 0, 256, false, {fft_pass_ct_kernel<125, 4, 0, 256, false, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, false, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, false, 2, 5, 5, 5>}},
-    {128, 4, 0, 256, false, {fft_pass_ct_kernel<128, 4, 0, 256, false, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, false, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, false, 2, 8, 4, 4>}},
-    {125, 5, 0, 256, false, {fft_pass_ct_kernel<125, 5, 0, 256, false, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, false, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, false, 2, 5, 5, 5>}},
-    {128, 5, 0, 256, false, {fft_pass_ct_kernel<128, 5, 0, 256, false, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, false, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, false, 2, 8, 4, 4>}},
-    {100, 4, 0, 256, false, {fft_pass_ct_kernel<100, 4, 0, 256, false, 0, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, false, 1, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, false, 2, 4, 5, 5>}},
-    {160, 4, 0, 256, false, {fft_pass_ct_kernel<160, 4, 0, 256, false, 0, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, false, 1, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, false, 2, 4, 8, 5>}},
-    {64, 5, 0, 256, false, {fft_pass_ct_kernel<64, 5, 0, 256, false, 0, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, false, 1, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, false, 2, 4, 4, 4>}},
+    {125, 4, 0, 256, {fft_pass_ct_kernel<125, 4, 0, 256, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 4, 0, 256, 2, 5, 5, 5>}},
+    {128, 4, 0, 256, {fft_pass_ct_kernel<128, 4, 0, 256, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 4, 0, 256, 2, 8, 4, 4>}},
+    {125, 5, 0, 256, {fft_pass_ct_kernel<125, 5, 0, 256, 0, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, 1, 5, 5, 5>, fft_pass_ct_kernel<125, 5, 0, 256, 2, 5, 5, 5>}},
+    {128, 5, 0, 256, {fft_pass_ct_kernel<128, 5, 0, 256, 0, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, 1, 8, 4, 4>, fft_pass_ct_kernel<128, 5, 0, 256, 2, 8, 4, 4>}},
+    {100, 4, 0, 256, {fft_pass_ct_kernel<100, 4, 0, 256, 0, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, 1, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, 2, 4, 5, 5>}},
+    {160, 4, 0, 256, {fft_pass_ct_kernel<160, 4, 0, 256, 0, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, 1, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, 2, 4, 8, 5>}},
+    {64, 5, 0, 256, {fft_pass_ct_kernel<64, 5, 0, 256, 0, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, 1, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, 2, 4, 4, 4>}},
     // row passes: 30000/10, 12288/10 -> 1250, the 200-column stitch overlap
-    {3000, 1, 1, 512, false, {fft_pass_ct_kernel<3000, 1, 1, 512, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, false, 2, 3, 8, 5, 5, 5>}},
-    {3000, 0, 1, 512, false, {fft_pass_ct_kernel<3000, 0, 1, 512, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, false, 2, 3, 8, 5, 5, 5>}},
-    {3000, 0, 1, 256, false, {fft_pass_ct_kernel<3000, 0, 1, 256, false, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, false, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, false, 2, 3, 8, 5, 5, 5>}},
-    {1250, 1, 1, 256, false, {fft_pass_ct_kernel<1250, 1, 1, 256, false, 0, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, false, 1, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, false, 2, 2, 5, 5, 5, 5>}},
-    {200, 4, 1, 256, false, {fft_pass_ct_kernel<200, 4, 1, 256, false, 0, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, false, 1, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, false, 2, 8, 5, 5>}},
+    {3000, 1, 1, 512, {fft_pass_ct_kernel<3000, 1, 1, 512, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, 2, 3, 8, 5, 5, 5>}},
+    {3000, 0, 1, 512, {fft_pass_ct_kernel<3000, 0, 1, 512, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, 2, 3, 8, 5, 5, 5>}},
+    {3000, 0, 1, 256, {fft_pass_ct_kernel<3000, 0, 1, 256, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 256, 2, 3, 8, 5, 5, 5>}},
+    {1250, 1, 1, 256, {fft_pass_ct_kernel<1250, 1, 1, 256, 0, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, 1, 2, 5, 5, 5, 5>, fft_pass_ct_kernel<1250, 1, 1, 256, 2, 2, 5, 5, 5, 5>}},
+    {200, 4, 1, 256, {fft_pass_ct_kernel<200, 4, 1, 256, 0, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, 1, 8, 5, 5>, fft_pass_ct_kernel<200, 4, 1, 256, 2, 8, 5, 5>}},
 };
 constexpr int kNumFast = sizeof(kFast) / sizeof(kFast[0]);
 
@@ -1114,7 +1097,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     dim3 grid3((unsigned)blocks);
     p.grid3 = 0;
     if (p.mode == 0 && (p.O1 > 65535 || p.O2 > 65535)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass: more than 65535 rows or blocks");
-    if (p.mode == 0 && blocks_override <= 0 && !(p.fast >= 0 && kFast[p.fast].persist)) {
+    if (p.mode == 0 && blocks_override <= 0) {
         p.grid3 = 1;
         const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
         p.xcd_chunk = (ltn + 7) / 8;
@@ -1142,11 +1125,6 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     if (p.fast >= 0) {
         p.ntiles = blocks;
         long grid = blocks;
-        if (blocks_override <= 0 && kFast[p.fast].persist) {
-            static const char *envg = getenv("OIP_FFT_WGS_PER_CU");          // experiment knob
-            const long cap = (long)ctx->cu_count * (envg ? atoi(envg) : 8);
-            if (grid > cap) grid = cap;
-        }
         hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);

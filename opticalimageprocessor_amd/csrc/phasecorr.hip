@@ -303,17 +303,12 @@ struct FusedJob {
     int dbg;                            // experiment mask (OIP_ROWS_DBG): skip phases to time the rest; results are wrong
 };
 
-// Row stage of the whole correlation in one kernel, for shapes whose row axis is a single factor
-// (natural order along x).  The workgroup of frequency line ky owns the lines ky and -ky of every
-// spectrum of the job:
-//   FWD: the spectra arrive with only their column passes done; each pair of lines is staged in
-//        LDS, row-transformed (both lines in one Stockham network) and picked up into registers
-//        -- the forward row pass never touches HBM;
-//   the cross-power lines Y(ky,.) and Y(-ky,.) of each output are formed in LDS straight from the
-//   registers, inverse row-transformed and stored -- Y never exists in the spectral domain.
-// Against separate kernels this saves a read + write of every spectrum (forward rows), a write +
-// read of every Y (cross-power), and the second read of spectra shared by two outputs.
-template <int F, int NT, int WPE, bool FWD, int... Rs>
+// Cross-power + inverse row pass (OIP_FUSED_ROWS=1: the forward row pass stays a separate launch; kept as
+// the measured intermediate step towards corr_rows_kernel below).  The workgroup of frequency line ky owns
+// the lines ky and -ky of every spectrum of the job:
+// the cross-power lines Y(ky,.) and Y(-ky,.) of each output are formed in LDS straight from the
+// registers, inverse row-transformed and stored -- Y never exists in the spectral domain.
+template <int F, int NT, int WPE, int... Rs>
 __global__ __launch_bounds__(NT, WPE) void xpower_rows_kernel(FusedJob fj, int M, int P, OipAxisDigits yd,
                                                          const float2 *__restrict__ twF)
 {
@@ -331,49 +326,18 @@ __global__ __launch_bounds__(NT, WPE) void xpower_rows_kernel(FusedJob fj, int M
     // one register array per spectrum and line: static indices only (no scratch)
     float2 zk0[NIT], zk1[NIT], zk2[NIT], zm0[NIT], zm1[NIT], zm2[NIT];
     const float2 zero = make_float2(0.f, 0.f);
-    if (FWD) {
+    const float2 *z0 = fj.z[0], *z1 = fj.z[1], *z2 = fj.z[2];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            if (s >= narr) break;
-            const float2 *zs = fj.z[s];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int x = threadIdx.x + it * NT;
-                if (x < N) { buf[2 * x] = zs[r1 + x]; buf[2 * x + 1] = zs[r2 + x]; }
-            }
-            __syncthreads();
-            oipfft::Stages<F, 1, 2, NT, 1, Rs...>::run(buf, tw);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int kx = threadIdx.x + it * NT;
-                const bool ok = kx < N;
-                const int nkx = kx ? N - kx : 0;
-                const float2 a = ok ? buf[2 * kx] : zero, b = ok ? buf[2 * nkx + 1] : zero;
-                if (s == 0) { zk0[it] = a; zm0[it] = b; }
-                else if (s == 1) { zk1[it] = a; zm1[it] = b; }
-                else { zk2[it] = a; zm2[it] = b; }
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            if (narr < 2) { zk1[it] = zero; zm1[it] = zero; }
-            if (narr < 3) { zk2[it] = zero; zm2[it] = zero; }
-        }
-    } else {
-        const float2 *z0 = fj.z[0], *z1 = fj.z[1], *z2 = fj.z[2];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int kx = threadIdx.x + it * NT;
-            const int nkx = kx ? N - kx : 0;
-            const bool ok = kx < N;
-            zk0[it] = ok ? z0[r1 + kx] : zero;
-            zm0[it] = ok ? z0[r2 + nkx] : zero;
-            zk1[it] = ok && narr > 1 ? z1[r1 + kx] : zero;
-            zm1[it] = ok && narr > 1 ? z1[r2 + nkx] : zero;
-            zk2[it] = ok && narr > 2 ? z2[r1 + kx] : zero;
-            zm2[it] = ok && narr > 2 ? z2[r2 + nkx] : zero;
-        }
+    for (int it = 0; it < NIT; ++it) {
+        const int kx = threadIdx.x + it * NT;
+        const int nkx = kx ? N - kx : 0;
+        const bool ok = kx < N;
+        zk0[it] = ok ? z0[r1 + kx] : zero;
+        zm0[it] = ok ? z0[r2 + nkx] : zero;
+        zk1[it] = ok && narr > 1 ? z1[r1 + kx] : zero;
+        zm1[it] = ok && narr > 1 ? z1[r2 + nkx] : zero;
+        zk2[it] = ok && narr > 2 ? z2[r1 + kx] : zero;
+        zm2[it] = ok && narr > 2 ? z2[r2 + nkx] : zero;
     }
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -598,11 +562,11 @@ struct FusedRow {
 // stores at a 128-byte stride, an 8-way bank conflict for ds_write_b64)
 const FusedRow kFusedRow[] = {
     {3000, 512, 768, corr_rows_kernel<3000, 768, 1, 1, 3, 5, 5, 5, 8>, corr_rows_kernel<3000, 768, 3, 2, 3, 5, 5, 5, 8>,
-     xpower_rows_kernel<3000, 512, 2, false, 3, 8, 5, 5, 5>},
+     xpower_rows_kernel<3000, 512, 2, 3, 8, 5, 5, 5>},
     {1250, 256, 512, corr_rows_kernel<1250, 512, 1, 1, 5, 5, 5, 5, 2>, corr_rows_kernel<1250, 512, 3, 2, 5, 5, 5, 5, 2>,
-     xpower_rows_kernel<1250, 256, 2, false, 2, 5, 5, 5, 5>},
+     xpower_rows_kernel<1250, 256, 2, 2, 5, 5, 5, 5>},
     {200, 256, 256, corr_rows_kernel<200, 256, 1, 1, 5, 5, 8>, corr_rows_kernel<200, 256, 3, 2, 5, 5, 8>,
-     xpower_rows_kernel<200, 256, 2, false, 8, 5, 5>},
+     xpower_rows_kernel<200, 256, 2, 8, 5, 5>},
 };
 
 // ---- peak: first maximum of the fftShift-ed surface + 5x5 weighted centroid ----------------------

@@ -284,7 +284,11 @@ def main():
         out_local = 0
         workload = "RRC kernel only, %dx%d u16 per GPU (BASELINE config 2)" % (W, pb)
     else:
-        plan = StripPlan(W, Lp, world, args.slices, args.sections)
+        # weak scaling: the strip is `world` times longer, so it carries `world` times the correlation
+        # sections (same section density) -- every rank owns about args.sections of them, like the
+        # single-GPU run; keeping 5 sections for the whole strip would shrink the per-GPU work with N
+        sections_total = args.sections * world
+        plan = StripPlan(W, Lp, world, args.slices, sections_total)
         bufs = ShardBuffers(plan, rank, dev)
         raw_mss = synth.mss_strip(rank * plan.mb, plan.mb, W, kb_mss, device=dev)
         o0, o1 = plan.align_out_rows(rank)
@@ -302,6 +306,8 @@ def main():
         workload = ("default action (--do-rrc4pan): PAN %dx%d + MSS 4x(%dx%d) per GPU; RRC + %dx%dx4 inter-band phase "
                     "correlations (%dx%d FFT) + polyfit + bicubic align to 16UC4" %
                     (W, pb, W // 4, plan.mb, args.sections, args.slices, M, N))
+        if world > 1:
+            workload += "; strip of %d x %d lines with %d sections in total" % (world, pb, sections_total)
         # the synthetic scene is not guaranteed to clear the reference's default response
         # threshold in every slice: fall back to a lower --ibc-threshold once, and say so
         try:

@@ -178,7 +178,57 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
     // by one per output line, window already primed -- the new source lines are known before any of
     // them is used, so their loads go out together.  Measured, the extra registers cost more
     // (occupancy) than the shorter dependency chains gain, so KB = 1 is the default.
-    constexpr int kBatch = KB;
+    if (KB == 0) {
+        // One-line lookahead: after the window for output line r is complete, the source line that line
+        // r + 1 will need in the regular case (same section, first tap line + 1) is requested BEFORE the 16-tap
+        // sum of line r, so its latency hides under ~50 f32 operations instead of stalling the next iteration.
+        // A wrong guess (section seam, rounding flip of the map) is detected by (base, line) tags and reloaded.
+        float nl[4] = {0.f, 0.f, 0.f, 0.f};
+        int nl_iy = INT_MIN, nl_base = INT_MIN;
+        for (long r = r0; r < r1; ++r) {
+            const AlignRow a = rows[r];
+            unsigned res = 0;
+            if (a.valid) {
+                if (a.base != cur_base) { cur_base = a.base; cur_iy = INT_MIN; }
+                int iy, fy;
+                map_y(a, &iy, &fy);
+                if (iy == cur_iy + 1 && cur_iy != INT_MIN) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) win[t][j] = win[t + 1][j];
+                    }
+                    if (nl_base == a.base && nl_iy == iy) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) win[3][j] = nl[j];
+                    } else {
+                        const int rr = iy + 3;
+                        const long lr = (long)a.base + rr;
+                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[3]);
+                    }
+                } else if (iy != cur_iy) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int rr = iy + t;
+                        const long lr = (long)a.base + rr;
+                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[t]);
+                    }
+                }
+                cur_iy = iy;
+                {
+                    const int rr = iy + 4;
+                    const long lr = (long)a.base + rr;
+                    align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, nl);
+                    nl_iy = iy + 1;
+                    nl_base = a.base;
+                }
+                res = resample(a, iy, fy);
+            }
+            dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
+        }
+        return;
+    }
+    constexpr int kBatch = KB > 0 ? KB : 1;
     long r = r0;
     for (; r + kBatch <= r1; r += kBatch) {
         AlignRow a[kBatch];
@@ -353,8 +403,8 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
         static const char *envb = getenv("OIP_ALIGN_BATCH");                 // experiment knob
-        const int kb = envb ? atoi(envb) : 1;       // measured on MI355X: 4.4 / 5.4 / 6.8 ms for 1 / 2 / 4 (VGPRs cost occupancy)
-        auto fn = kb == 1 ? align_mss_kernel<1> : (kb == 2 ? align_mss_kernel<2> : align_mss_kernel<4>);
+        const int kb = envb ? atoi(envb) : 0;       // measured on MI355X: 3.9 ms lookahead (0); 4.4 / 5.4 / 6.8 ms for batches of 1 / 2 / 4
+        auto fn = kb == 0 ? align_mss_kernel<0> : (kb == 1 ? align_mss_kernel<1> : (kb == 2 ? align_mss_kernel<2> : align_mss_kernel<4>));
         hipLaunchKernelGGL(fn, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
                            src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpb);
     }

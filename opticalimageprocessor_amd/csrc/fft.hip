@@ -228,18 +228,43 @@ __device__ void store_peak(const float2 *buf, int Vp, const OipFftPass &p, const
         long k = skey[part];
         for (int w = 1; w < nwaves; ++w)
             if (peak_better(sval[w * 2 + part], skey[w * 2 + part], v, k)) { v = sval[w * 2 + part]; k = skey[w * 2 + part]; }
-        OipPeakPartial &o = io.partials[(size_t)part * ntiles + tile];
-        o.val = v;
-        o.key = k;
+        const unsigned long long packed = oip_peak_pack(v, k);
+        if (packed) atomicMax(&io.slots[part * kPeakSlots + (int)(tile & (kPeakSlots - 1))], packed);
     }
 }
 
+// store_kind 2: the peak of part `part` from the slots (block-wide: every thread gets the key); the first
+// window block of a part publishes it for the centroid kernel.  scratch: >= 8 * 16 bytes of LDS.
+__device__ long window_peak_key(const OipFftPass &p, const OipFftIo &io, int blk, unsigned long long *scratch)
+{
+    const int part = blk / 25;
+    unsigned long long best = 0ull;
+    for (int i = threadIdx.x; i < kPeakSlots; i += blockDim.x) {
+        const unsigned long long s = io.slots[part * kPeakSlots + i];
+        best = s > best ? s : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = best;
+    __syncthreads();
+    best = scratch[0];
+    for (int w = 1; w < nwaves; ++w) best = scratch[w] > best ? scratch[w] : best;
+    __syncthreads();                          // scratch is the tile buffer
+    // an all-NaN surface has no entry: minMaxLoc leaves (0, 0)
+    const long key = oip_peak_key(best, 0);
+    if (blk % 25 == 0 && threadIdx.x == 0) io.peak_key[part] = key;
+    return key;
+}
+
 // store_kind 2: which tile holds window element w of the 5x5 window around the peak
-__device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo &io, int blk, Tile *t, int *n0, int *v0)
+__device__ __forceinline__ bool window_tile(const OipFftPass &p, const OipFftIo &io, int blk, long key, Tile *t, int *n0, int *v0)
 {
     // block = 25 * part + w: the windows of all parts of one array go in a single launch
     const int w = blk % 25;
-    const long key = io.peak_key[blk / 25];
     const int py = (int)(key / p.N), px = (int)(key - (long)py * p.N);
     const int ys = py - 2 + w / 5, xs = px - 2 + w % 5;
     if (ys < 0 || ys >= p.M || xs < 0 || xs >= p.N) return false;     // weightedCentroid clamps the window
@@ -303,7 +328,8 @@ __global__ __launch_bounds__(kFftBlock) void fft_pass_kernel(float2 *__restrict_
     Tile t;
     int wn0 = 0, wv0 = 0;
     if (io.store_kind == 2) {
-        if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
+        const long key = window_peak_key(p, io, blockIdx.x, reinterpret_cast<unsigned long long *>(smem));
+        if (!window_tile(p, io, blockIdx.x, key, &t, &wn0, &wv0)) {
             if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
@@ -411,7 +437,8 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
     Tile t;
     int wn0 = 0, wv0 = 0;
     if ((IOK == 2 && io.store_kind == 2)) {
-        if (!window_tile(p, io, blockIdx.x, &t, &wn0, &wv0)) {
+        const long key = window_peak_key(p, io, blockIdx.x, reinterpret_cast<unsigned long long *>(buf));
+        if (!window_tile(p, io, blockIdx.x, key, &t, &wn0, &wv0)) {
             if (threadIdx.x == 0) io.window[(blockIdx.x / 25) * 32 + blockIdx.x % 25] = NAN;
             return;
         }
@@ -1068,12 +1095,6 @@ static long pass_blocks(const OipFftPass &p)
     return (p.lanes + (1 << p.vshift) - 1) >> p.vshift;
 }
 
-long oip_fft2d_last_pass_blocks(const OipFft2dPlan *pl)
-{
-    OipFftPass p = pl->passes[0];
-    p.ltn = 0;
-    return pass_blocks(p);
-}
 
 static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, const OipFftIo &io, long blocks_override)
 {
@@ -1163,7 +1184,7 @@ int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inver
                 p.ltn = lt1 - lt0;
                 OipFftIo use = plain;
                 if (!inv && i == 0 && io) { use = *io; use.store_kind = 0; }
-                if (inv && i == 0 && io) { use.store_kind = io->store_kind; use.partials = io->partials; }
+                if (inv && i == 0 && io) { use.store_kind = io->store_kind; use.slots = io->slots; }
                 int rc = launch_pass(ctx, data, p, inv ? 1 : 0, use, 0);
                 if (rc) return rc;
             }
@@ -1182,7 +1203,7 @@ int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inver
     } else {
         for (int i = np - 1; i >= pl->n_y; --i) {
             OipFftIo use = plain;
-            if (i == 0 && io) { use.store_kind = io->store_kind; use.partials = io->partials; }
+            if (i == 0 && io) { use.store_kind = io->store_kind; use.slots = io->slots; }
             int rc = launch_pass(ctx, data, pl->passes[i], 1, use, 0);
             if (rc) return rc;
         }
@@ -1200,6 +1221,7 @@ int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, const O
     memset(&use, 0, sizeof use);
     use.store_kind = 2;
     use.peak_key = io->peak_key;
+    use.slots = io->slots;
     use.window = io->window;
     use.part = io->part;
     return launch_pass(ctx, data, pl->passes[0], 1, use, 25L * (io->part > 0 ? io->part : 1));

@@ -2,17 +2,33 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstring>
 
 #include <functional>
 #include <vector>
 
 struct oip_ctx;
 
-struct OipPeakPartial {
-    float val;
-    int pad;
-    long key;           // index in the fftShift-ed image, row-major
-};
+// Arg-max of a correlation surface without a reduction pass: every workgroup of the last inverse pass
+// folds its tile maximum into one of kPeakSlots 64-bit slots per surface with atomicMax.  A slot packs
+// (order-preserving bits of the f32 value) << 32 | (0xFFFFFFFF - key), key = row-major index in the
+// fftShift-ed image (< 2^32), so the largest value wins and, among equal values, the smallest key -- the
+// first maximum in minMaxLoc's scan order.  0 = empty (NaN never enters).  The window kernel reduces the
+// slots itself; the centroid kernel zeroes them for the next surface.
+constexpr int kPeakSlots = 256;
+__host__ __device__ inline unsigned long long oip_peak_pack(float v, long key)
+{
+    if (v != v) return 0ull;                                   // NaN
+    if (v == 0.f) v = 0.f;                                     // -0 == +0 for minMaxLoc
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)key);
+}
+__host__ __device__ inline long oip_peak_key(unsigned long long packed, long none)
+{
+    return packed == 0ull ? none : (long)(0xFFFFFFFFu - (unsigned)(packed & 0xFFFFFFFFull));
+}
 
 // What a pass reads instead of / writes besides the complex array (fusions)
 struct OipFftIo {
@@ -34,8 +50,8 @@ struct OipFftIo {
     int rows, cols;     // extent of the real images
     int store_kind;     // 0: the complex array; 1: peak partials only (nothing stored);
                         // 2: 5x5 window around a known peak (25 workgroups, nothing else stored)
-    OipPeakPartial *partials;   // store_kind 1: [2][grid] (real part, imaginary part)
-    const long *peak_key;       // store_kind 2: shifted key of the peak (device)
+    unsigned long long *slots;  // store_kind 1 and 2: [2][kPeakSlots] arg-max slots (real part, imaginary part)
+    long *peak_key;             // store_kind 2: out, shifted key of the peak per part (for the centroid kernel)
     float *window;              // store_kind 2: [25] values, row-major dy,dx (NaN = outside image)
     int part;                   // store_kind 2: number of parts (1: real surface only, 2: real and imaginary), 25 tiles each
 };
@@ -85,7 +101,6 @@ int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, int inv
 int oip_fft_table(oip_ctx *ctx, int T, const float2 **out);     // exp(-2 pi i t / T), t in [0, T)
 // re-run the last inverse pass for the 25 tiles holding the 5x5 window around *peak_key
 int oip_fft2d_window(oip_ctx *ctx, const OipFft2dPlan *plan, float2 *data, const OipFftIo *io);
-long oip_fft2d_last_pass_blocks(const OipFft2dPlan *plan);
 
 // position <-> frequency of one axis after the forward transform.  With factors
 // (F1, F2, ..) position p = k1*(F2*F3..) + k2*(F3..) + .. holds frequency

@@ -570,39 +570,16 @@ const FusedRow kFusedRow[] = {
 };
 
 // ---- peak: first maximum of the fftShift-ed surface + 5x5 weighted centroid ----------------------
-__device__ __forceinline__ bool pk_better(float v, long k, float bv, long bk) { return v > bv || (v == bv && k < bk); }
-
-// reduce the per-tile maxima the last inverse pass left behind
-constexpr int kPeakBlock = 1024;
-__global__ __launch_bounds__(kPeakBlock) void peak_final_kernel(const OipPeakPartial *__restrict__ partials, int npart,
-                                                            long mn, long *__restrict__ key_out)
-{
-    __shared__ float sval[kPeakBlock];
-    __shared__ long skey[kPeakBlock];
-    partials += (size_t)blockIdx.x * npart;          // one block per part
-    key_out += blockIdx.x;
-    float bv = -INFINITY;
-    long bk = mn;
-    for (int i = threadIdx.x; i < npart; i += kPeakBlock)
-        if (pk_better(partials[i].val, partials[i].key, bv, bk)) { bv = partials[i].val; bk = partials[i].key; }
-    sval[threadIdx.x] = bv;
-    skey[threadIdx.x] = bk;
-    __syncthreads();
-    for (int s = kPeakBlock / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s && pk_better(sval[threadIdx.x + s], skey[threadIdx.x + s], sval[threadIdx.x], skey[threadIdx.x])) {
-            sval[threadIdx.x] = sval[threadIdx.x + s];
-            skey[threadIdx.x] = skey[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *key_out = skey[0] >= mn ? 0 : skey[0];      // all-NaN surface: minMaxLoc leaves (0,0)
-}
 
 // weightedCentroid(C, peak, Size(5,5), &response) (phasecorr.cpp) on the recomputed window;
 // NaN marks window cells outside the image (the reference clamps the window to the image).
 __global__ void centroid_kernel(const float *__restrict__ window, const long *__restrict__ key, int M, int N,
-                                double *__restrict__ result)
+                                double *__restrict__ result, unsigned long long *__restrict__ slots)
 {
+    // last consumer of this surface's arg-max slots: leave them empty for the next surface
+    // (both surfaces: the pass fills the imaginary one's slots even when only the real one is wanted)
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * kPeakSlots; i += blockDim.x) slots[i] = 0ull;
     if (threadIdx.x != 0) return;
     window += 32 * blockIdx.x;                       // one block per part
     key += blockIdx.x;
@@ -659,8 +636,7 @@ struct PcWork {
     float *fa;          // base window, f32
     float *fb[8];       // second images, f32 (up-sampled bands; two units' worth)
     float *fsmall;      // MSS window before resize
-    OipPeakPartial *partials;   // [2][npart]
-    int npart;
+    unsigned long long *slots;  // [2][kPeakSlots] arg-max slots, empty between surfaces
     long *keys;         // peak key scratch
     float *window;      // 25 floats
 };
@@ -671,8 +647,7 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     const size_t zbytes = align_up(sizeof(float2) * (size_t)M * pl->P, 256);
     const size_t fbytes = align_up(sizeof(float) * (size_t)rows * cols, 256);
     const size_t sbytes = align_up(sizeof(float) * (size_t)(small_elems > 0 ? small_elems : 1), 256);
-    w->npart = (int)oip_fft2d_last_pass_blocks(pl);
-    const size_t pbytes = align_up(sizeof(OipPeakPartial) * 2 * (size_t)w->npart, 256);
+    const size_t pbytes = align_up(sizeof(unsigned long long) * 2 * kPeakSlots, 256);
     size_t total = zbytes * (nz + ny) + fbytes * (1 + nfb) + sbytes + pbytes + 512;
     void *ws;
     int rc = oip_workspace(ctx, total, &ws);
@@ -683,9 +658,12 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     w->fa = (float *)p; p += fbytes;
     for (int i = 0; i < 8; ++i) { w->fb[i] = i < nfb ? (float *)p : nullptr; if (i < nfb) p += fbytes; }
     w->fsmall = (float *)p; p += sbytes;
-    w->partials = (OipPeakPartial *)p; p += pbytes;
+    w->slots = (unsigned long long *)p; p += pbytes;
     w->keys = (long *)p; p += 256;
     w->window = (float *)p;
+    // the slots must start empty (later surfaces are cleaned by the centroid kernel)
+    ctx->prof_chain = nullptr;
+    OIP_HIP(ctx, hipMemsetAsync(w->slots, 0, sizeof(unsigned long long) * 2 * kPeakSlots, ctx->stream));
     return OIP_OK;
 }
 
@@ -983,24 +961,21 @@ int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, flo
     OipFftIo io;
     memset(&io, 0, sizeof io);
     io.store_kind = 1;
-    io.partials = w.partials;
+    io.slots = w.slots;
     int rc = oip_fft2d_exec(ctx, pl, y, 1, &io, rows_done ? 1 : 0);
     if (rc) return rc;
-    // all parts (the real and imaginary surface of y) in one launch each
-    {
-        OipProfScope prof(ctx, "peak_final_kernel");
-        hipLaunchKernelGGL(peak_final_kernel, dim3(nparts), dim3(kPeakBlock), 0, ctx->stream, w.partials, w.npart,
-                           (long)pl->M * pl->N, w.keys);
-    }
+    // all parts (the real and imaginary surface of y) in one launch each; the window launch reduces
+    // the arg-max slots itself
     OipFftIo wio;
     memset(&wio, 0, sizeof wio);
     wio.peak_key = w.keys;
+    wio.slots = w.slots;
     wio.window = w.window;
     wio.part = nparts;
     if ((rc = oip_fft2d_window(ctx, pl, y, &wio))) return rc;
     {
         OipProfScope prof(ctx, "centroid_kernel");
-        hipLaunchKernelGGL(centroid_kernel, dim3(nparts), dim3(64), 0, ctx->stream, w.window, w.keys, pl->M, pl->N, d_results);
+        hipLaunchKernelGGL(centroid_kernel, dim3(nparts), dim3(64), 0, ctx->stream, w.window, w.keys, pl->M, pl->N, d_results, w.slots);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;

@@ -17,7 +17,7 @@ os.makedirs(prof, exist_ok=True)
 
 def bench_name(kernel):
     """library profiler name (bench.py's key) of a demangled kernel symbol"""
-    m = re.search(r"fft_pass_ct_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(?:false|true|0|1), *(\d+)", kernel)
+    m = re.search(r"fft_pass_ct_kernel<(\d+), *(\d+), *(\d+), *(\d+), *(\d+)", kernel)      # <F, VS, MODE, NT, IOK, radices...>
     if m:
         F, iok = int(m.group(1)), int(m.group(5))
         return "fft_pass_ct_kernel_F%d%s" % (F, {0: "", 1: "_pack", 2: "_peak"}[iok])

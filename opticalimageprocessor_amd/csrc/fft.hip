@@ -989,6 +989,7 @@ void oip_fft_destroy(oip_ctx *ctx)
 {
     if (!ctx->fft) return;
     for (auto &kv : ctx->fft->tables) hipFree(kv.second);
+    for (auto &kv : ctx->fft->plans) hipFree(const_cast<int *>(kv.second.d_ypos));
     delete ctx->fft;
     ctx->fft = nullptr;
 }
@@ -1083,6 +1084,19 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
         int rc = get_table(ctx, p.F, &t);
         if (rc) return rc;
         if (p.tw_mode) { rc = get_table(ctx, p.T, &t); if (rc) return rc; }
+    }
+    // row positions of the frequency lines (the row stage of the correlation walks ky and M - ky)
+    {
+        OipAxisDigits d;
+        d.n = (int)pl.yf.size();
+        d.L = M;
+        for (int i = 0; i < 4; ++i) d.f[i] = i < d.n ? pl.yf[i] : 1;
+        std::vector<int> ypos(M);
+        for (int k = 0; k < M; ++k) ypos[k] = oip_freq_to_pos(d, k);
+        int *dp = nullptr;
+        OIP_HIP(ctx, hipMalloc((void **)&dp, sizeof(int) * M));
+        OIP_HIP(ctx, hipMemcpy(dp, ypos.data(), sizeof(int) * M, hipMemcpyHostToDevice));
+        pl.d_ypos = dp;
     }
     it = ctx->fft->plans.emplace(key, pl).first;
     *out = &it->second;

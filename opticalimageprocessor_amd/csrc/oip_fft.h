@@ -93,6 +93,7 @@ struct OipFft2dPlan {
     std::vector<int> xf, yf;          // pass factors per axis, in forward order
     std::vector<OipFftPass> passes;   // forward order: y passes then x passes
     int n_y;
+    const int *d_ypos;                // device: row position of frequency line ky in the scrambled spectrum, ky in [0, M)
 };
 
 int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out);

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NT, WPE) void xpower_rows_kernel(FusedJob fj, int M
 // per CU (3 x 48 KB of LDS at F = 3000) hides HBM latency by the register prefetch instead of
 // occupancy.
 template <int F, int NT, int NARR, int NOUT, int... Rs>
-__global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P, OipAxisDigits yd,
+__global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P, const int *__restrict__ ypos,
                                                        const float2 *__restrict__ twF)
 {
     constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
     float4 la[NARR][NIT2], lb[NARR][NIT2];
     float4 *buf4 = reinterpret_cast<float4 *>(buf);
     // rows of the line pair whose loads are in la/lb (n1, n2) and of the pair in LDS (s1, s2)
-    long n1 = (long)oip_freq_to_pos(yd, ky) * P, n2 = (long)oip_freq_to_pos(yd, ky ? M - ky : 0) * P;
+    // (row positions come from a per-plan table: decoding them with the digit loop cost ~300 scalar
+    // instructions and four dependent scalar loads per iteration, on every wave at the same time)
+    long n1 = (long)ypos[ky] * P, n2 = (long)ypos[ky ? M - ky : 0] * P;
     auto fetch = [&](int tid) {
 #pragma unroll
         for (int a = 0; a < NARR; ++a) {
@@ -465,8 +467,8 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
         const int kn = ky + gridDim.x;
         const bool more = kn <= half;
         if (more && !(dbg & 8)) {
-            n1 = (long)oip_freq_to_pos(yd, kn) * P;
-            n2 = (long)oip_freq_to_pos(yd, M - kn) * P;
+            n1 = (long)ypos[kn] * P;
+            n2 = (long)ypos[M - kn] * P;
             fetch(tid);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -554,8 +556,8 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
 
 struct FusedRow {
     int F, threads, fwd_threads;
-    void (*fwd1)(FusedJob, int, int, OipAxisDigits, const float2 *);      // one spectrum -> one output
-    void (*fwd3)(FusedJob, int, int, OipAxisDigits, const float2 *);      // three spectra -> two outputs
+    void (*fwd1)(FusedJob, int, int, const int *, const float2 *);        // one spectrum -> one output
+    void (*fwd3)(FusedJob, int, int, const int *, const float2 *);        // three spectra -> two outputs
     void (*inv)(FusedJob, int, int, OipAxisDigits, const float2 *);
 };
 // power-of-two radices last: their stores are then contiguous in LDS (a leading radix-8 stage
@@ -943,7 +945,7 @@ int xpower_stage(oip_ctx *ctx, const OipFft2dPlan *pl, const RowStage &rs, const
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
         OipProfScope prof(ctx, "corr_rows_kernel");
         hipLaunchKernelGGL(one ? rs.k->fwd1 : rs.k->fwd3, dim3((unsigned)grid), dim3(rs.k->fwd_threads), 0, ctx->stream, fj, pl->M,
-                           pl->P, digits_of(pl->yf, pl->M), twF);
+                           pl->P, pl->d_ypos, twF);
     } else {
         OipProfScope prof(ctx, "xpower_rows_kernel");
         hipLaunchKernelGGL(rs.k->inv, dim3(pl->M / 2 + 1), dim3(rs.k->threads), 0, ctx->stream, fj, pl->M, pl->P,

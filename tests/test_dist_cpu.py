@@ -90,3 +90,22 @@ def test_plan_geometry():
     assert all(covered[i][1] == covered[i + 1][0] for i in range(7))
     with pytest.raises(ValueError):
         StripPlan(30000, 100001, 2)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_weak_scaling_plan_keeps_per_rank_work_fixed(world):
+    """bench.py's N-GPU workload: an N x 100000-line strip with 5 N correlation sections.  Every rank must own
+    exactly 5 sections (the per-GPU work of the single-GPU run), and at these sizes no section straddles a block
+    boundary, so the only exchanges are the align halos and the all-gather of the table."""
+    from opticalimageprocessor_amd.dist import StripPlan
+    plan = StripPlan(30000, 100000 * world, world, 10, 5 * world)
+    owners = [plan.owner(s) for s in range(plan.sections)]
+    assert [owners.count(r) for r in range(world)] == [5] * world
+    assert plan.correlation_transfers() == []
+    assert all(plan.pan_tail(r) == 0 for r in range(world))
+    # the aligned image is covered once, in order
+    rows = [plan.align_out_rows(r) for r in range(world)]
+    assert rows[0][0] == 0 and rows[-1][1] == plan.out_rows
+    assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    # the results of all sections fit the library's result buffer (64 KiB of doubles, 12 per unit)
+    assert plan.slices * plan.sections * 12 * 8 <= 65536

@@ -77,7 +77,6 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         # last inverse pass: reads the array, keeps only per-tile maxima
         "fft_pass_ct_kernel_F128_peak": 8.0 * MN,
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out
-        "resize_cubic_x4_kernel": 4.0 * win + 2.0 * win / 16.0,
         "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
         "remap_shift_kernel": 4.0 * W * pb,                   # 2 B read + 2 B written per pixel
         "remap_shift8_kernel": 4.0 * W * pb,

@@ -645,7 +645,7 @@ struct PcWork {
 
 int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_elems, int nz, int ny, int nfb, PcWork *w)
 {
-    const int M = pl->M, N = pl->N;
+    const int M = pl->M;
     const size_t zbytes = align_up(sizeof(float2) * (size_t)M * pl->P, 256);
     const size_t fbytes = align_up(sizeof(float) * (size_t)rows * cols, 256);
     const size_t sbytes = align_up(sizeof(float) * (size_t)(small_elems > 0 ? small_elems : 1), 256);

@@ -182,6 +182,9 @@ int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_
  * last reset, measured with HIP events on the context's stream (off by default). */
 int oip_profile_enable(oip_ctx *ctx, int on);
 int oip_profile_reset(oip_ctx *ctx);
+/* Time only the kernels profiled under this name (NULL or "": every kernel).  The events themselves cost
+   stream time (about 2 % of a correlation batch when every kernel is timed). */
+int oip_profile_filter(oip_ctx *ctx, const char *kernel_name);
 int oip_profile_count(oip_ctx *ctx);
 int oip_profile_get(oip_ctx *ctx, int i, char *name, int namelen, double *total_ms, long *launches);
 

@@ -76,6 +76,7 @@ _SIGS = {
     "oip_stitch_rows_u16": ([_vp, _vp, _vp, _vp, _i, _l, _i], _i),
     "oip_profile_enable": ([_vp, _i], _i),
     "oip_profile_reset": ([_vp], _i),
+    "oip_profile_filter": ([_vp, _cp], _i),
     "oip_profile_count": ([_vp], _i),
     "oip_profile_get": ([_vp, _i, _cp, _i, _dp, _lp], _i),
 }
@@ -290,6 +291,10 @@ class Context:
     # -- instrumentation
     def profile_enable(self, on=True):
         self._ck(self.lib.oip_profile_enable(self.h, int(on)))
+
+    def profile_filter(self, name=None):
+        """time only the kernels profiled under `name` (None: all)"""
+        self._ck(self.lib.oip_profile_filter(self.h, name.encode() if name else None))
 
     def profile_reset(self):
         self._ck(self.lib.oip_profile_reset(self.h))

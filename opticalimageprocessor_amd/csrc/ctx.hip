@@ -180,6 +180,10 @@ int oip_workspace(oip_ctx *ctx, size_t bytes, void **out)
 int oip_prof_begin(oip_ctx *ctx, const char *name)
 {
     if (!ctx || !ctx->prof_on) return -1;
+    if (!ctx->prof_filter.empty() && ctx->prof_filter != name) {
+        ctx->prof_chain = nullptr;          // an untimed kernel follows: the next timed one needs its own start event
+        return -1;
+    }
     int entry = -1;
     for (size_t i = 0; i < ctx->prof.size(); ++i)
         if (ctx->prof[i].name == name) { entry = (int)i; break; }
@@ -237,6 +241,13 @@ extern "C" int oip_profile_enable(oip_ctx *ctx, int on)
     OIP_CHECK_CTX(ctx);
     prof_resolve(ctx);
     ctx->prof_on = on != 0;
+    return OIP_OK;
+}
+
+extern "C" int oip_profile_filter(oip_ctx *ctx, const char *kernel_name)
+{
+    OIP_CHECK_CTX(ctx);
+    ctx->prof_filter = kernel_name ? kernel_name : "";
     return OIP_OK;
 }
 

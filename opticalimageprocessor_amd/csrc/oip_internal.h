@@ -77,6 +77,7 @@ struct oip_ctx {
 
     // profiling
     bool prof_on = false;
+    std::string prof_filter;            // non-empty: only this kernel name is timed
     std::vector<oip_prof_entry> prof;
     std::vector<oip_prof_pending> prof_pending;
     hipEvent_t prof_chain = nullptr;    // end event of the previous scope while nothing else has been enqueued since

@@ -180,6 +180,15 @@ int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_
 /* ---- instrumentation --------------------------------------------------------------- */
 /* name + accumulated device time of the kernels launched through this context since the
  * last reset, measured with HIP events on the context's stream (off by default). */
+/* ---- 8f rank 4: sub-image merge of the down-link de-framer ------------------------------------------
+ * AuxSeparator::WriteImageData / MergeSubImage / the byte-order pass of InflateSubImage
+ * (aux_separator.h:341-393) for uncompressed frames: d_tiles holds vparts*hparts sub-images of
+ * sub_lines x sub_cols BIG-endian u16, tile r*hparts + c after tile r*hparts + c - 1; d_out receives
+ * vparts stripes of sub_lines lines of hparts*sub_cols little-endian pixels
+ * (reference frame: vparts = 4 PAN + 1 MSS, hparts = 8, 256 x 1536 sub-images).  Not in place. */
+int oip_merge_subimages_be16(oip_ctx *ctx, const uint16_t *d_tiles, uint16_t *d_out, int vparts, int hparts,
+                             int sub_lines, int sub_cols);
+
 int oip_profile_enable(oip_ctx *ctx, int on);
 int oip_profile_reset(oip_ctx *ctx);
 /* Time only the kernels profiled under this name (NULL or "": every kernel).  The events themselves cost

@@ -74,6 +74,7 @@ _SIGS = {
     "oip_align_mss_bicubic_u16x4": ([_vp, _vp, _sz, _l, _l, _vp, _l, _l, _i, _l, _dp, _dp, _i, _i, _i, _i, _i, _lp], _i),
     "oip_align_mss_src_range": ([_l, _l, _l, _dp, _i, _i, _i, _i, _i, _i, _lp, _lp], _i),
     "oip_stitch_rows_u16": ([_vp, _vp, _vp, _vp, _i, _l, _i], _i),
+    "oip_merge_subimages_be16": ([_vp, _vp, _vp, _i, _i, _i, _i], _i),
     "oip_profile_enable": ([_vp, _i], _i),
     "oip_profile_reset": ([_vp], _i),
     "oip_profile_filter": ([_vp, _cp], _i),
@@ -289,6 +290,10 @@ class Context:
         self._ck(self.lib.oip_stitch_rows_u16(self.h, _ptr(left), _ptr(right), _ptr(out), W, L, fold))
 
     # -- instrumentation
+    def merge_subimages_be16(self, tiles, out, vparts, hparts, sub_lines, sub_cols):
+        """aux_separator.h:341-393 for uncompressed frames: big-endian sub-images -> little-endian stripes"""
+        self._ck(self.lib.oip_merge_subimages_be16(self.h, _ptr(tiles), _ptr(out), vparts, hparts, sub_lines, sub_cols))
+
     def profile_enable(self, on=True):
         self._ck(self.lib.oip_profile_enable(self.h, int(on)))
 

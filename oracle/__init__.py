@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
                                     _f64p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_align_mss.restype = C.c_long
         L.orc_stitch_raw.argtypes = [_u16p, _u16p, _u16p, C.c_int, C.c_long, C.c_int]
+        L.orc_merge_subimages_be16.argtypes = [_u16p, _u16p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_resize_cubic_f32.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int]
         L.orc_window_u16_to_f32.argtypes = [_u16p, C.c_size_t, C.c_long, C.c_int, C.c_int,
                                             C.c_int, _f32p]
@@ -188,6 +189,16 @@ def stitch_raw(left: np.ndarray, right: np.ndarray, fold: int) -> np.ndarray:
     L, W = left.shape
     out = np.empty((L, 2 * (W - fold)), np.uint16)
     lib().orc_stitch_raw(_p16(left), _p16(right), _p16(out), W, L, fold)
+    return out
+
+
+def merge_subimages_be16(tiles: np.ndarray) -> np.ndarray:
+    """aux_separator.h:341-393 (uncompressed frames): tiles[vparts][hparts][sub_lines][sub_cols] of big-endian
+    words (held in a uint16 array as read from the file) -> vparts*sub_lines lines of hparts*sub_cols pixels"""
+    tiles = _c16(tiles)
+    vparts, hparts, sub_lines, sub_cols = tiles.shape
+    out = np.empty((vparts * sub_lines, hparts * sub_cols), np.uint16)
+    lib().orc_merge_subimages_be16(_p16(tiles), _p16(out), vparts, hparts, sub_lines, sub_cols)
     return out
 
 

@@ -403,3 +403,25 @@ void orc_window_u16_to_f32(const uint16_t *img, size_t pitch, long row0, int col
         for (int x = 0; x < cols; ++x) out[(size_t)y * cols + x] = (float)S[x];
     }
 }
+
+
+/* aux_separator.h:341-393, ratio == IMGSIG_ZRTO_NONE: InflateSubImage memcpy's the sub-image and swaps the
+ * bytes of every 16-bit word (:386-392); MergeSubImage (:366-372) memcpy's each of its rows to
+ * image + r * BYTES_PER_PANLINE + vSlice * IMGSIG_IMBASE_COLS * BYTES_PER_PIXEL; WriteImageData (:347-363)
+ * writes one full stripe per row of sub-images, PAN stripes first. */
+void orc_merge_subimages_be16(const uint16_t *tiles, uint16_t *out, int vparts, int hparts, int sub_lines, int sub_cols)
+{
+    const size_t sub = (size_t)sub_lines * sub_cols;
+    const size_t linepx = (size_t)hparts * sub_cols;
+    for (int r = 0; r < vparts; ++r)
+        for (int c = 0; c < hparts; ++c) {
+            const uint16_t *t = tiles + ((size_t)r * hparts + c) * sub;
+            uint16_t *stripe = out + (size_t)r * sub_lines * linepx;
+            for (int line = 0; line < sub_lines; ++line)
+                for (int col = 0; col < sub_cols; ++col) {
+                    uint16_t w = t[(size_t)line * sub_cols + col];
+                    w = (uint16_t)((w & 0x00FF) << 8 | (w & 0xFF00) >> 8);
+                    stripe[(size_t)line * linepx + (size_t)c * sub_cols + col] = w;
+                }
+        }
+}

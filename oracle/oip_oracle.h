@@ -87,4 +87,9 @@ void orc_window_u16_to_f32(const uint16_t *img, size_t pitch, long row0, int col
 #ifdef __cplusplus
 }
 #endif
+/* AuxSeparator::WriteImageData + MergeSubImage + InflateSubImage's byte-order pass, uncompressed frames
+ * (aux_separator.h:341-393): the reference copies sub-image c of stripe r row by row to column offset
+ * c * sub_cols of a hparts*sub_cols-wide stripe after swapping the two bytes of every word. */
+void orc_merge_subimages_be16(const uint16_t *tiles, uint16_t *out, int vparts, int hparts, int sub_lines, int sub_cols);
+
 #endif

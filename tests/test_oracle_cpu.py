@@ -165,3 +165,18 @@ def test_rrc_param_file_loader_oracle(oracle_mod, tmp_path):
     assert np.allclose(kb, [[1, .5], [.9, -2], [1.1, 3.25], [1, 0]])
     with pytest.raises(RuntimeError, match="expected 5 lines"):
         oracle_mod.load_rrc_param_file(str(p), 5)
+
+
+def test_merge_subimages_restatement(oracle_mod):
+    """aux_separator.h:341-393 for uncompressed frames, against the obvious numpy formulation: byte-swap every
+    word, put the hparts sub-images of a row side by side, stack the rows of sub-images"""
+    rng = np.random.default_rng(8)
+    for shape in [(5, 8, 16, 24), (2, 3, 5, 7), (1, 1, 1, 1)]:
+        tiles = rng.integers(0, 65536, shape).astype(np.uint16)
+        got = oracle_mod.merge_subimages_be16(tiles)
+        want = tiles.byteswap().transpose(0, 2, 1, 3).reshape(shape[0] * shape[2], shape[1] * shape[3])
+        assert np.array_equal(got, want)
+    # the reference frame geometry: (4 PAN + 1 MSS) x 8 sub-images of 256 x 1536 -> 1280 lines of 12288 pixels
+    tiles = rng.integers(0, 65536, (5, 8, 256, 1536)).astype(np.uint16)
+    got = oracle_mod.merge_subimages_be16(tiles)
+    assert got.shape == (1280, 12288) and got[300, 1536 * 3 + 5] == int(tiles[1, 3, 44, 5]).to_bytes(2, "big")[1] * 256 + int(tiles[1, 3, 44, 5]).to_bytes(2, "big")[0]

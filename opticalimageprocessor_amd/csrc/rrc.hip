@@ -23,6 +23,9 @@
 // overflow case needs a select (negative overflow and NaN already give low half 0).
 #include "oip_internal.h"
 
+#include <thread>
+#include <vector>
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -326,6 +329,28 @@ extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16
 // Host-buffer form of InplaceRRC: the caller's heap buffer is corrected in place through
 // two pinned staging blocks and two device blocks on two streams, so the H2D copy of block
 // i+1, the kernel of block i and the D2H copy of block i-1 overlap.
+// The staging copies between the caller's pageable raster and the pinned buffers are what bounds the
+// host-buffer form (one thread moves about 10 GB/s; the link moves 50): split them over a few threads.
+static void staged_copy(void *dst, const void *src, size_t bytes)
+{
+    static const int nthreads = [] {
+        const char *e = getenv("OIP_HOST_COPY_THREADS");
+        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        return n < 1 ? 1 : (n > 8 ? 8 : n);
+    }();
+    if (nthreads == 1 || bytes < ((size_t)8 << 20)) { memcpy(dst, src, bytes); return; }
+    const size_t part = (bytes / nthreads + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int i = 1; i < nthreads; ++i) {
+        const size_t off = (size_t)i * part;
+        if (off >= bytes) break;
+        const size_t n = bytes - off < part ? bytes - off : part;
+        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, n); });
+    }
+    memcpy(dst, src, part < bytes ? part : bytes);
+    for (auto &t : th) t.join();
+}
+
 extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb_host)
 {
     OIP_CHECK_CTX(ctx);
@@ -363,12 +388,12 @@ extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, con
             long r0 = pc * rows_per_chunk;
             long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
             if (hipStreamSynchronize(ctx->stage_stream[slot]) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "stage sync failed"); break; }
-            memcpy(buff + r0 * (long)w, ctx->h_stage[slot], (size_t)n * row_bytes);
+            staged_copy(buff + r0 * (long)w, ctx->h_stage[slot], (size_t)n * row_bytes);
         }
         if (c < nchunks) {
             long r0 = c * rows_per_chunk;
             long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
-            memcpy(ctx->h_stage[slot], buff + r0 * (long)w, (size_t)n * row_bytes);
+            staged_copy(ctx->h_stage[slot], buff + r0 * (long)w, (size_t)n * row_bytes);
             hipStream_t st = ctx->stage_stream[slot];
             if (hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], (size_t)n * row_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "H2D failed"); break; }
             ctx->stream = st;

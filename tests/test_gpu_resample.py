@@ -431,3 +431,37 @@ def test_merge_subimages_be16(ctx, oracle_mod, shape):
     assert np.array_equal(got, oracle_mod.merge_subimages_be16(tiles))
     with pytest.raises(ValueError):
         ctx.merge_subimages_be16(d_in, d_in, *shape)
+
+
+def test_profile_filter_times_only_the_named_kernel(ctx):
+    """oip_profile_filter: bench.py times only the dominant kernel inside its timed region"""
+    import torch
+    W, H = 4096, 64
+    src = torch.zeros(H, W, dtype=torch.int16, device="cuda")
+    dst = torch.empty_like(src)
+    left = torch.zeros(H, W, dtype=torch.int16, device="cuda")
+    out = torch.empty(H, 2 * (W - 8), dtype=torch.int16, device="cuda")
+    kb = ctx.upload_kb(np.stack([np.ones(W), np.zeros(W)], 1))
+    try:
+        ctx.profile_reset()
+        ctx.profile_filter("stitch_rows_kernel")
+        ctx.profile_enable(True)
+        ctx.rrc_u16(src, dst, W, H, kb)
+        ctx.stitch_rows_u16(left, dst, out, W, H, 8)
+        ctx.rrc_u16(src, dst, W, H, kb)
+        ctx.sync()
+        ctx.profile_enable(False)
+        prof = ctx.profile()
+        assert list(prof) == ["stitch_rows_kernel"] and prof["stitch_rows_kernel"][1] == 1 and prof["stitch_rows_kernel"][0] > 0
+        ctx.profile_filter(None)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ctx.rrc_u16(src, dst, W, H, kb)
+        ctx.stitch_rows_u16(left, dst, out, W, H, 8)
+        ctx.sync()
+        ctx.profile_enable(False)
+        assert len(ctx.profile()) == 2
+    finally:
+        ctx.profile_filter(None)
+        ctx.profile_enable(False)
+        ctx.profile_reset()

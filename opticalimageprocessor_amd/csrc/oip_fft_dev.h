@@ -251,6 +251,68 @@ template <int F, int NT, int Ns, int R> struct StageOps {
     }
 };
 
+// The same stage with one item = one butterfly of BOTH lines of a two-line buffer ([point][line] interleave:
+// a point's two lines are one 16-byte word).  The twiddle look-up, the power chain and the address arithmetic
+// are shared by the two butterflies and the LDS accesses are 16 bytes wide -- about a quarter fewer
+// instructions per butterfly; it pays wherever there are enough butterflies to keep the block busy
+// (kPairStage below).
+template <int F, int NT, int Ns, int R> struct StageOpsPair {
+    static constexpr int NB = F / R;
+    static constexpr int ITEMS = NB;
+    static constexpr int PER = (ITEMS + NT - 1) / NT;
+    static constexpr int TWSTEP = F / (Ns * R);
+    static constexpr int XR = 2 * R;                    // registers per item: line 0 points, then line 1 points
+    static __device__ __forceinline__ void load(const float2 *__restrict__ buf, float2 (&x)[PER][XR], int tid)
+    {
+        const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(buf);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int b = tid + i * NT;
+            if (ITEMS % NT == 0 || b < ITEMS) {
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const float4 v = p4[b + m * NB];
+                    x[i][m] = make_float2(v.x, v.y);
+                    x[i][R + m] = make_float2(v.z, v.w);
+                }
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(float2 *__restrict__ buf, const float2 *__restrict__ tw, float2 (&x)[PER][XR], int tid)
+    {
+        float4 *__restrict__ p4 = reinterpret_cast<float4 *>(buf);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int b = tid + i * NT;
+            if (ITEMS % NT == 0 || b < ITEMS) {
+                const int k = b % Ns;
+                if (Ns > 1) {
+                    const float2 w1 = tw[k * TWSTEP];
+                    float2 w = w1;
+#pragma unroll
+                    for (int m = 1; m < R; ++m) {
+                        x[i][m] = cmul(x[i][m], w);
+                        x[i][R + m] = cmul(x[i][R + m], w);
+                        if (m + 1 < R) w = cmul(w, w1);
+                    }
+                }
+                butterfly<R>(x[i]);
+                butterfly<R>(x[i] + R);
+                const int j0 = (b - k) * R + k;
+#pragma unroll
+                for (int m = 0; m < R; ++m) p4[j0 + m * Ns] = make_float4(x[i][m].x, x[i][m].y, x[i][R + m].x, x[i][R + m].y);
+            }
+        }
+    }
+};
+
+// pair items when they still fill the block, or when single items would need three rounds
+template <int F, int NT, int R> struct kPairStage {
+    static constexpr bool value = R >= 3 && ((F / R >= NT * 3 / 4) || ((2 * (F / R) + NT - 1) / NT >= 3));
+};
+template <int F, int NT, int Ns, int R, bool PAIR> struct StageSelect { using type = StageOps<F, NT, Ns, R>; static constexpr int XR = R; };
+template <int F, int NT, int Ns, int R> struct StageSelect<F, NT, Ns, R, true> { using type = StageOpsPair<F, NT, Ns, R>; static constexpr int XR = 2 * R; };
+
 template <int F, int NT, int NA, int Ns, int... Rs> struct StagesPipe;
 template <int F, int NT, int NA, int Ns> struct StagesPipe<F, NT, NA, Ns> {
     static __device__ __forceinline__ void run(float2 *, const float2 *, int) { if (NA > 1) __syncthreads(); }
@@ -258,8 +320,9 @@ template <int F, int NT, int NA, int Ns> struct StagesPipe<F, NT, NA, Ns> {
 template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesPipe<F, NT, NA, Ns, R, Rest...> {
     static __device__ __forceinline__ void run(float2 *buf, const float2 *tw, int tid)
     {
-        using Ops = StageOps<F, NT, Ns, R>;
-        float2 x[2][Ops::PER][R];
+        using Sel = StageSelect<F, NT, Ns, R, kPairStage<F, NT, R>::value>;
+        using Ops = typename Sel::type;
+        float2 x[2][Ops::PER][Sel::XR];
         Ops::load(buf, x[0], tid);
 #pragma unroll
         for (int a = 0; a < NA; ++a) {

@@ -13,9 +13,15 @@ over one synthetic 4-band strip already resident in HBM:
     4-band bicubic alignment -> 16UC4               DoInterBandAlignment      preproc.h:351
 pixels per step = PAN pixels + MSS pixels of all bands = 1.25 * W * L.
 
-N GPUs (`--gpus N`, one rank per GPU under torch.distributed.run): weak scaling -- every rank
-owns a 100000-line block of an N x 100000-line strip (scan-line blocks), correlation
-windows and align halos move point-to-point over RCCL, results are all-gathered.
+N GPUs (`--gpus N`, one rank per GPU under torch.distributed.run): every rank owns a `--lines`-line block
+(default 100000, the metric's strip; `--lines 65536 --gpus 8` is BASELINE config 4 exactly) of an N x lines
+strip (scan-line blocks).  The strip carries the reference's 5 correlation sections for the WHOLE
+strip (preproc.h:245-247: the number of windows does not grow with the strip), their 50 (section, slice)
+units are dealt to the ranks and lines a unit's rank lacks move point-to-point over RCCL; results are
+all-gathered; align halos move point-to-point.  Pixels per GPU are fixed ("scaling": "weak"); the
+correlation stage is a fixed-size job that the ranks share.  `--workload weak5n` keeps the PER-GPU
+correlation work fixed instead (5 N sections; round-1's variant).  `--workload prestitch --gpus N` is the
+cross-CCD path (BASELINE config 5; `--fp16-accumulate` for its resampling variant).
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,10 +51,13 @@ def parse():
     ap.add_argument("--slices", type=int, default=10)
     ap.add_argument("--sections", type=int, default=5)
     ap.add_argument("--ibc-threshold", type=float, default=0.4)
-    ap.add_argument("--workload", choices=["default", "rrc", "prestitch"], default="default",
-                    help="default: the full 4-band path; rrc: BASELINE config 2 (RRC kernel only, 30000x65536); "
-                         "prestitch: cross-CCD path (BASELINE config 5 on one GPU): CalcSttParameters + RRC x2 + "
+    ap.add_argument("--workload", choices=["default", "weak5n", "rrc", "prestitch"], default="default",
+                    help="default: the full 4-band path (5 sections for the whole strip); weak5n: the same with 5 N "
+                         "sections (per-GPU correlation work fixed); rrc: BASELINE config 2 (RRC kernel only, "
+                         "30000x65536); prestitch: cross-CCD path (BASELINE config 5): CalcSttParameters + RRC x2 + "
                          "PreStitch remap + RAW stitch of two CCD segments")
+    ap.add_argument("--fp16-accumulate", action="store_true",
+                    help="prestitch: the fp16-accumulate resampling variant (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -80,6 +89,7 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         "align_mss_kernel": 16.0 * Wb * out_rows_local,       # 4 x 2 B read + 8 B written per pixel
         "remap_shift_kernel": 4.0 * W * pb,                   # 2 B read + 2 B written per pixel
         "remap_shift8_kernel": 4.0 * W * pb,
+        "remap_shift8_f16_kernel": 4.0 * W * pb,
         "stitch_rows_kernel": 4.0 * 2 * (W - 100) * pb,       # 2 B read + 2 B written per output pixel
     }
     return d
@@ -182,7 +192,8 @@ def main():
     import torch.distributed as dist
     import opticalimageprocessor_amd as oip
     from opticalimageprocessor_amd import synth
-    from opticalimageprocessor_amd.dist import HipBackend, ShardBuffers, StripPlan, default_action_step
+    from opticalimageprocessor_amd.dist import (CcdBuffers, CcdPlan, HipBackend, ShardBuffers, StripPlan,
+                                                default_action_step, prestitch_stitch_step)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -235,43 +246,33 @@ def main():
     info = {}
 
     if args.workload == "prestitch":
-        if world != 1:
-            sys.exit("bench.py --workload prestitch is a single-GPU measurement")
         OV = 200
         kb2 = synth.lut(W, 5)
         d_kb2 = ctx.upload_kb(kb2)
         del raw_pan
-        pan1, pan2 = synth.ccd_pair(0, pb, W, OV, kb_pan, kb2, device=dev)
-        rrc1, rrc2, prestt = torch.empty_like(pan1), torch.empty_like(pan1), torch.empty_like(pan1)
-        stitched = torch.empty(pb, 2 * (W - OV // 2), dtype=torch.uint16, device=dev)
-        nsec = min(10, pb // 16000)
+        nsec = min(10, Lp // 16000)
+        cplan = CcdPlan(W, Lp, world, nsec, 16000, OV, 0)
+        pan1, pan2 = synth.ccd_pair(rank * pb, pb, W, OV, kb_pan, kb2, device=dev)
+        cbufs = CcdBuffers(cplan, rank, pan1, pan2)
+        prestt = torch.empty_like(pan1)
+        stitched = torch.empty(pb, 2 * (W - cplan.fold), dtype=torch.uint16, device=dev)
+        backend = HipBackend(ctx, cplan)
 
         def step():
-            # main.cpp:270-286: correlation on the raw files, then RRC of both, then the remap
-            t = ctx.stt_correlate(pan1, pan2, W, pb, 0, pb, nsec, 16000, OV, 0)
-            ok = t[:, 2] >= threshold
-            if not ok.any():
-                raise RuntimeError("No valid delta value found for stitching parameter calculating")
-            dx, dy = float(t[ok, 0].mean()), float(t[ok, 1].mean())
+            # main.cpp:270-286 then :177-190: correlation on the raw strips, RRC of both, remap of CCD 2, stitch
+            dx, dy, _ = prestitch_stitch_step(backend, cplan, cbufs, d_kb_pan, d_kb2, prestt, stitched, rank,
+                                              threshold=threshold, f16acc=args.fp16_accumulate)
             info["dx"], info["dy"] = dx, dy
-            ctx.rrc_u16(pan1, rrc1, W, pb, d_kb_pan)
-            ctx.rrc_u16(pan2, rrc2, W, pb, d_kb2)
-            ctx.remap_shift_bicubic_u16(rrc2, prestt, W, pb, dx, dy)
-            ctx.stitch_rows_u16(rrc1, prestt, stitched, W, pb, OV // 2)      # --fold-cols 200 -> 100 (main.cpp:189)
         pix_per_rank = 2 * W * pb
         plan = None
         base_rows, base_cols = 16000, OV
         M, N = 16000, OV
         out_local = 0
-        workload = ("prestitch + stitch: 2 CCD segments %dx%d, %d x (16000x%d) phase correlations, RRC x2, constant-shift "
-                    "bicubic remap (30000-row sections), RAW stitch fold %d" % (W, pb, nsec, OV, OV // 2))
-        try:
-            step()
-        except RuntimeError as e:
-            if "No valid delta" not in str(e):
-                raise
-            threshold = 0.05
-            step()
+        workload = ("prestitch + stitch: 2 CCD segments %dx%d%s, %d x (16000x%d) phase correlations, RRC x2, constant-shift "
+                    "bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d" %
+                    (W, Lp, " in %d scan-line blocks" % world if world > 1 else "", nsec, OV,
+                     "fp16" if args.fp16_accumulate else "fp32", cplan.fold))
+        step()
     elif args.workload == "rrc":
         dst = torch.empty_like(raw_pan)
 
@@ -283,10 +284,9 @@ def main():
         out_local = 0
         workload = "RRC kernel only, %dx%d u16 per GPU (BASELINE config 2)" % (W, pb)
     else:
-        # weak scaling: the strip is `world` times longer, so it carries `world` times the correlation
-        # sections (same section density) -- every rank owns about args.sections of them, like the
-        # single-GPU run; keeping 5 sections for the whole strip would shrink the per-GPU work with N
-        sections_total = args.sections * world
+        # default: the reference's sections for the WHOLE strip, whatever its length (BASELINE config 4);
+        # weak5n: `world` times the sections, so that every rank keeps the single-GPU run's correlation work
+        sections_total = args.sections * (world if args.workload == "weak5n" else 1)
         plan = StripPlan(W, Lp, world, args.slices, sections_total)
         bufs = ShardBuffers(plan, rank, dev)
         raw_mss = synth.mss_strip(rank * plan.mb, plan.mb, W, kb_mss, device=dev)
@@ -306,16 +306,11 @@ def main():
                     "correlations (%dx%d FFT) + polyfit + bicubic align to 16UC4" %
                     (W, pb, W // 4, plan.mb, args.sections, args.slices, M, N))
         if world > 1:
-            workload += "; strip of %d x %d lines with %d sections in total" % (world, pb, sections_total)
-        # the synthetic scene is not guaranteed to clear the reference's default response
-        # threshold in every slice: fall back to a lower --ibc-threshold once, and say so
-        try:
-            step()
-        except RuntimeError as e:
-            if "Not enough valid correlation values" not in str(e):
-                raise
-            threshold = 0.05
-            step()
+            workload += ("; strip of %d x %d lines with %d sections in total, %d..%d of its %d units per rank" %
+                         (world, pb, sections_total, min(len(plan.units_of(r)) for r in range(world)),
+                          max(len(plan.units_of(r)) for r in range(world)), plan.n_units))
+        # a synthetic scene that does not clear --ibc-threshold is an error here, not a reason to change the workload
+        step()
     ctx.sync()
 
     # Per-kernel table: ONE untimed step with every kernel bracketed by HIP events (the last warm-up step, or an
@@ -353,7 +348,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pix_per_rank * world * args.steps / elapsed / 1e6
-        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local, 5.0 if args.workload == "default" else 2.0)
+        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local, 2.0 if args.workload == "prestitch" else 5.0)
         kernels = {}
         for name, (ms, n) in prof_all.items():
             avg = ms / max(n, 1)
@@ -377,7 +372,7 @@ def main():
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+                traffic = json.load(open(tpath)).get("default" if args.workload == "weak5n" else args.workload, {}).get(dom)
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": avg_s * 1e3}
@@ -402,7 +397,7 @@ def main():
             line["shift"] = {"dx": info.get("dx"), "dy": info.get("dy"), "truth_px": list(synth.CCD_SHIFT)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "prestitch":
             pass        # CPU baseline for this workload: see DESIGN.md (oracle remap is measured in the tests)
-        elif world == 1 and not args.no_cpu_baseline and args.workload == "default":
+        elif world == 1 and not args.no_cpu_baseline and args.workload in ("default", "weak5n"):
             line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
         elif world == 1 and not args.no_cpu_baseline:
             import oracle

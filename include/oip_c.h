@@ -126,6 +126,15 @@ int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uint16_t *d_pa
                       long L, long row0, long nrows, int sections, int lines_per_section,
                       int overlap_cols, int edge_cols, double *out);
 
+/* The same loop body for n explicit window pairs (multi-GPU: a section whose lines live on several ranks
+ * is gathered into compact windows on the rank that computes it): window i of CCD 1 / CCD 2 is rows x cols
+ * u16 at d_a[i] / d_b[i] with row pitch pitch_a[i] / pitch_b[i] (elements) -- the Mat1w.colRange views of
+ * stitcher.h:175-176.  out[3*i + {0,1,2}] = dx, dy, response.  The pointer arrays are host arrays of
+ * device pointers. */
+int oip_stt_correlate_windows(oip_ctx *ctx, const uint16_t *const *d_a, const size_t *pitch_a,
+                              const uint16_t *const *d_b, const size_t *pitch_b, int n, int rows, int cols,
+                              double *out);
+
 /* Loop body of PreProcessor::CalcInterBandCorrelation (preproc.h:251-329):
  * out[((b*sections + sec)*slices + i)*4 + {0..3}] = dx, dy, rs, cx.  PAN lines
  * [prow0, prow0+pn) and MSS band lines [mrow0, mrow0+mn) are resident; sections not fully
@@ -134,11 +143,33 @@ int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long Lp, long p
                             const uint16_t *d_planes, size_t plane_stride, long mrow0, long mn,
                             int W, int slices, int sections, int corr_lines, double *out);
 
+/* The (section, slice) body of the same loop (preproc.h:262-329) for n explicit units: unit u is a PAN
+ * window of rows x cols u16 at d_pan[u] (pitch pan_pitch[u]) and the four band windows of (rows/4) x
+ * (cols/4) u16 at d_bands[4*u + b] (pitch band_pitch[u]).  out[12*u + 3*b + {0,1,2}] = dx, dy, rs of band
+ * b.  Lets a multi-GPU host hand any unit to any rank (a unit needs 96 MB + 4 x 6 MB of windows at the
+ * 30000-wide geometry); units are processed two at a time. */
+int oip_interband_correlate_units(oip_ctx *ctx, const uint16_t *const *d_pan, const size_t *pan_pitch,
+                                  const uint16_t *const *d_bands, const size_t *band_pitch, int n, int rows,
+                                  int cols, double *out);
+
+/* The validity filter and means of Stitcher::CalcSttParameters (stitcher.h:181-198), host: table[3*s +
+ * {0,1,2}] = dx, dy, response of section s, in section order.  OIP_E_RUNTIME when no section is valid
+ * ("No valid delta value found for stitching parameter calculating"). */
+int oip_stt_mean(const double *table, int sections, double threshold, double max_delta_y, double *dx,
+                 double *dy, double *response, int *valid);
+
 /* FilterInterBandShiftValues + DoCorrelationPolynomialFitting (preproc.h:492-550), host.
- * shifts: [4][n][4] (dx,dy,rs,cx).  cx_out[4][2], cy_out[4][3] ascending coefficients. */
+ * shifts: [4][n][4] (dx,dy,rs,cx).  cx_out[4][2], cy_out[4][3] ascending coefficients.
+ * oip_filter_and_fit fits like the reference (OIP_FIT_REFERENCE). */
+#define OIP_FIT_REFERENCE 0  /* NumCpp Poly1d::fit as called at preproc.h:535-536: inv(A^T A) A^T y, raw abscissa */
+#define OIP_FIT_LSTSQ     1  /* the same least-squares problem by Householder QR on a scaled abscissa       */
 int oip_filter_and_fit(const double *shifts, int n, double threshold, int min_count,
                        double *cx_out, double *cy_out, char *err, int errlen);
-/* nc::polynomial::Poly1d<double>::fit(x, y, deg): least squares, ascending coefficients */
+int oip_filter_and_fit_mode(const double *shifts, int n, double threshold, int min_count, int fit_mode,
+                            double *cx_out, double *cy_out, char *err, int errlen);
+/* nc::polynomial::Poly1d<double>::fit(x, y, deg), ascending coefficients: the reference's operation
+ * order (oip_polyfit_reference) and the well-conditioned solver (oip_polyfit) */
+int oip_polyfit_reference(const double *x, const double *y, int n, int deg, double *coeffs);
 int oip_polyfit(const double *x, const double *y, int n, int deg, double *coeffs);
 
 /* ---- resampling -------------------------------------------------------------------- */
@@ -152,6 +183,15 @@ int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, long src_ro
                                 long src_rows, uint16_t *d_dst, long out_row0, long out_rows,
                                 int W, long L, double dx, double dy, int section_rows,
                                 int row_guard);
+/* The same call with the 16-tap sums of the regular interior pixels accumulated in packed fp16 (BASELINE
+ * config 5: "fp16 accumulate (tolerance stated)").  NOT the parity mode: |result - fp32 result| <= 4 DN on
+ * 12-bit data (measured max 4), <= 4 + max(sample)/256 DN in general; data above 15 bits overflows fp16.
+ * Geometry, 1/32-px phases, section borders and the irregular columns are identical (and computed in
+ * f32); widths that are not a multiple of 8 fall back to the fp32 kernel altogether. */
+int oip_remap_shift_bicubic_u16_f16acc(oip_ctx *ctx, const uint16_t *d_src, long src_row0,
+                                       long src_rows, uint16_t *d_dst, long out_row0, long out_rows,
+                                       int W, long L, double dx, double dy, int section_rows,
+                                       int row_guard);
 /* source lines [first, last) that output lines [out_row0, out_row0+out_rows) read: the halo
  * a row-block shard has to hold (host arithmetic only) */
 int oip_remap_shift_src_range(long out_row0, long out_rows, long L, double dy,

@@ -21,6 +21,7 @@ from .capi import (  # noqa: F401
     load_rrc_param_file,
     polyfit,
     remap_shift_src_range,
+    stt_mean,
     align_mss_src_range,
 )
 

@@ -66,10 +66,16 @@ _SIGS = {
     "oip_window_u16_to_f32": ([_vp, _vp, _sz, _l, _i, _i, _i, _vp], _i),
     "oip_resize_cubic_f32": ([_vp, _vp, _i, _i, _vp, _i, _i], _i),
     "oip_stt_correlate": ([_vp, _vp, _vp, _i, _l, _l, _l, _i, _i, _i, _i, _dp], _i),
+    "oip_stt_correlate_windows": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dp], _i),
+    "oip_interband_correlate_units": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _dp], _i),
     "oip_interband_correlate": ([_vp, _vp, _l, _l, _l, _vp, _sz, _l, _l, _i, _i, _i, _i, _dp], _i),
     "oip_filter_and_fit": ([_dp, _i, _d, _i, _dp, _dp, _cp, _i], _i),
+    "oip_filter_and_fit_mode": ([_dp, _i, _d, _i, _i, _dp, _dp, _cp, _i], _i),
     "oip_polyfit": ([_dp, _dp, _i, _i, _dp], _i),
+    "oip_polyfit_reference": ([_dp, _dp, _i, _i, _dp], _i),
+    "oip_stt_mean": ([_dp, _i, _d, _d, _dp, _dp, _dp, C.POINTER(_i)], _i),
     "oip_remap_shift_bicubic_u16": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
+    "oip_remap_shift_bicubic_u16_f16acc": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_src_range": ([_l, _l, _l, _d, _i, _lp, _lp], _i),
     "oip_align_mss_bicubic_u16x4": ([_vp, _vp, _sz, _l, _l, _vp, _l, _l, _i, _l, _dp, _dp, _i, _i, _i, _i, _i, _lp], _i),
     "oip_align_mss_src_range": ([_l, _l, _l, _dp, _i, _i, _i, _i, _i, _i, _lp, _lp], _i),
@@ -134,27 +140,46 @@ def load_rrc_param_file(path: str, expected: int) -> np.ndarray:
     return out
 
 
-def polyfit(x, y, deg: int) -> np.ndarray:
+FIT_MODES = {"reference": 0, "lstsq": 1}
+
+
+def polyfit(x, y, deg: int, fit: str = "reference") -> np.ndarray:
+    """fit="reference": NumCpp's operation order as the reference calls it (the product default);
+    fit="lstsq": Householder QR on a scaled abscissa"""
     lib = load_library()
     x, y = _dbl(x), _dbl(y)
     out = np.zeros(deg + 1)
-    rc = lib.oip_polyfit(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), x.size, deg, out.ctypes.data_as(_dp))
+    fn = lib.oip_polyfit if FIT_MODES[fit] else lib.oip_polyfit_reference
+    rc = fn(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), x.size, deg, out.ctypes.data_as(_dp))
     if rc:
         raise _STATUS_EXC.get(rc, OipError)("oip_polyfit failed (%s)" % STATUS_NAMES.get(rc))
     return out
 
 
-def filter_and_fit(shifts, threshold=0.4, min_count=5):
+def filter_and_fit(shifts, threshold=0.4, min_count=5, fit: str = "reference"):
     lib = load_library()
     s = _dbl(shifts)
     assert s.ndim == 3 and s.shape[0] == 4 and s.shape[2] == 4
     cx, cy = np.zeros((4, 2)), np.zeros((4, 3))
     err = C.create_string_buffer(1024)
-    rc = lib.oip_filter_and_fit(s.ctypes.data_as(_dp), s.shape[1], threshold, min_count,
-                                cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), err, 1024)
+    rc = lib.oip_filter_and_fit_mode(s.ctypes.data_as(_dp), s.shape[1], threshold, min_count, FIT_MODES[fit],
+                                     cx.ctypes.data_as(_dp), cy.ctypes.data_as(_dp), err, 1024)
     if rc:
         raise _STATUS_EXC.get(rc, OipError)(err.value.decode())
     return cx, cy
+
+
+def stt_mean(table, threshold=0.4, max_delta_y=0.0):
+    """stitcher.h:181-198 on an (S, 3) table -> (dx, dy, response, valid)"""
+    lib = load_library()
+    t = _dbl(table)
+    dx, dy, r, v = _d(), _d(), _d(), _i()
+    rc = lib.oip_stt_mean(t.ctypes.data_as(_dp), t.shape[0], threshold, max_delta_y, C.byref(dx), C.byref(dy), C.byref(r), C.byref(v))
+    if rc == 2:
+        raise RuntimeError("No valid delta value found for stitching parameter calculating")
+    if rc:
+        raise ValueError("oip_stt_mean: bad argument")
+    return dx.value, dy.value, r.value, v.value
 
 
 def remap_shift_src_range(out_row0, out_rows, L, dy, section_rows=30000):
@@ -263,13 +288,38 @@ class Context:
                                                   out.ctypes.data_as(_dp)))
         return out
 
+    def stt_correlate_windows(self, a_ptrs, a_pitch, b_ptrs, b_pitch, rows, cols):
+        """n explicit CCD window pairs (device pointers + element pitches) -> (n, 3) dx, dy, response"""
+        n = len(a_ptrs)
+        out = np.zeros((n, 3))
+        if n == 0:
+            return out
+        pa = (C.c_void_p * n)(*[_ptr(p) for p in a_ptrs]); pb = (C.c_void_p * n)(*[_ptr(p) for p in b_ptrs])
+        qa = (C.c_size_t * n)(*a_pitch); qb = (C.c_size_t * n)(*b_pitch)
+        self._ck(self.lib.oip_stt_correlate_windows(self.h, pa, qa, pb, qb, n, rows, cols, out.ctypes.data_as(_dp)))
+        return out
+
+    def interband_correlate_units(self, pan_ptrs, pan_pitch, band_ptrs, band_pitch, rows, cols):
+        """n explicit (section, slice) units; band_ptrs is n x 4 device pointers -> (n, 4, 3) dx, dy, rs"""
+        n = len(pan_ptrs)
+        out = np.zeros((n, 4, 3))
+        if n == 0:
+            return out
+        pp = (C.c_void_p * n)(*[_ptr(p) for p in pan_ptrs])
+        bp = (C.c_void_p * (4 * n))(*[_ptr(p) for u in band_ptrs for p in u])
+        qp = (C.c_size_t * n)(*pan_pitch); qb = (C.c_size_t * n)(*band_pitch)
+        self._ck(self.lib.oip_interband_correlate_units(self.h, pp, qp, bp, qb, n, rows, cols, out.ctypes.data_as(_dp)))
+        return out
+
     # -- resampling
     def remap_shift_bicubic_u16(self, src, dst, W, L, dx, dy, section_rows=30000, row_guard=32767,
-                                src_row0=0, src_rows=None, out_row0=0, out_rows=None):
+                                src_row0=0, src_rows=None, out_row0=0, out_rows=None, f16acc=False):
+        """f16acc=True: the fp16-accumulate variant (not the parity mode; tolerance in include/oip_c.h)"""
         src_rows = L if src_rows is None else src_rows
         out_rows = L if out_rows is None else out_rows
-        self._ck(self.lib.oip_remap_shift_bicubic_u16(self.h, _ptr(src), src_row0, src_rows, _ptr(dst), out_row0,
-                                                      out_rows, W, L, dx, dy, section_rows, row_guard))
+        fn = self.lib.oip_remap_shift_bicubic_u16_f16acc if f16acc else self.lib.oip_remap_shift_bicubic_u16
+        self._ck(fn(self.h, _ptr(src), src_row0, src_rows, _ptr(dst), out_row0, out_rows, W, L, dx, dy,
+                    section_rows, row_guard))
 
     def align_mss_bicubic_u16x4(self, planes, plane_stride, dst, Wb, Lm, cx, cy, lines_per_section=20000,
                                 line_offset=0, overlap=520, keep_leading=False, min_lines=1500,

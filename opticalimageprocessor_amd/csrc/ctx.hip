@@ -50,7 +50,26 @@ extern "C" int oip_create(int device, oip_ctx **out)
         oip_destroy(ctx);
         return OIP_E_DEVICE;
     }
+    ctx->small_bytes = 65536;
     *out = ctx;
+    return OIP_OK;
+}
+
+int oip_small(oip_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->small_bytes) return OIP_OK;
+    OIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t want = (bytes + 65535) / 65536 * 65536;
+    void *d = nullptr, *h = nullptr;
+    if (hipMalloc(&d, want) != hipSuccess || hipHostMalloc(&h, want, hipHostMallocDefault) != hipSuccess) {
+        if (d) hipFree(d);
+        return oip_fail(ctx, OIP_E_NOMEM, "result scratch of %zu bytes failed", want);
+    }
+    hipFree(ctx->d_small);
+    hipHostFree(ctx->h_small);
+    ctx->d_small = d;
+    ctx->h_small = h;
+    ctx->small_bytes = want;
     return OIP_OK;
 }
 

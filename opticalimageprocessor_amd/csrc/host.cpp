@@ -50,13 +50,11 @@ extern "C" int oip_load_rrc_param_file(const char *path, int expected_lines, dou
     return OIP_OK;
 }
 
-// nc::polynomial::Poly1d<double>::fit (call sites preproc.h:535-536): least-squares
-// polynomial, coefficients in ascending order.  NumCpp solves it on the raw Vandermonde
-// matrix, which at cx up to 12288..30000 and degree 2 is conditioned ~1e16..1e18, so its low
-// digits are an artefact of its own inverse.  Here: Householder QR on the abscissa centred
-// and scaled to [-1,1], then the coefficients are expanded back to powers of x -- the exact
-// least-squares solution to fp64 accuracy.  Every rank calls this with identical inputs and
-// gets identical bits (single thread, fixed order).
+// Least-squares polynomial, coefficients in ascending order, solved WELL: Householder QR on the
+// abscissa centred and scaled to [-1,1], then the coefficients are expanded back to powers of x --
+// the exact least-squares solution to fp64 accuracy (OIP_FIT_LSTSQ).  This is NOT what the reference
+// computes (see oip_polyfit_reference below); it is offered as `--fit lstsq`.  Every rank calls this
+// with identical inputs and gets identical bits (single thread, fixed order).
 extern "C" int oip_polyfit(const double *x, const double *y, int n, int deg, double *coeffs)
 {
     if (!x || !y || !coeffs || deg < 0 || deg > 8 || n <= deg) return OIP_E_INVALID;
@@ -118,13 +116,75 @@ extern "C" int oip_polyfit(const double *x, const double *y, int n, int deg, dou
     return OIP_OK;
 }
 
+// nc::polynomial::Poly1d<double>::fit(x, y, deg) as the reference calls it (preproc.h:535-536), restated
+// from NumCpp (un-vendored, version unpinned: PARITY UNPINNED):
+//   A[i][j] = x_i^j by repeated multiplication (utils::power), raw abscissa;
+//   non-square A:  aInv = inv(A^T A) . A^T ;  coefficients = aInv . y
+//   NdArray::dot = one std::inner_product per element (k ascending, starting from 0);
+//   linalg::inv  = in-place Gauss-Jordan sweep over the diagonal without pivoting (rows are only
+//                  swapped for exactly-zero diagonal entries, which cannot occur for A^T A here).
+// At cx up to 12288..30000 and degree 2 cond(A^T A) is 1e16..1e18, so the low digits of the result
+// are set by this very operation order -- which is why it is reproduced operation by operation
+// instead of being replaced by a better-conditioned solver: the product's default (OIP_FIT_REFERENCE)
+// must give the maps the reference gives.  No FMA (the library is built -ffp-contract=off, like the
+// reference's x86-64 build).
+extern "C" int oip_polyfit_reference(const double *x, const double *y, int n, int deg, double *coeffs)
+{
+    if (!x || !y || !coeffs || deg < 0 || deg > 8 || n <= deg) return OIP_E_INVALID;
+    const int m = deg + 1;
+    std::vector<double> A((size_t)n * m);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double v = 1.0;
+            if (j > 0) { v = x[i]; for (int e = 1; e < j; ++e) v *= x[i]; }
+            A[(size_t)i * m + j] = v;
+        }
+    // aT.dot(a)
+    std::vector<double> G((size_t)m * m), R((size_t)m * m);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < n; ++k) acc = acc + A[(size_t)k * m + i] * A[(size_t)k * m + j];
+            G[(size_t)i * m + j] = acc;
+        }
+    // linalg::inv: sweep k = 0..m-1, each sweep builds `result` from the current matrix and replaces it
+    for (int k = 0; k < m; ++k) {
+        if (G[(size_t)k * m + k] == 0.0) return OIP_E_RUNTIME;      // degenerate abscissae
+        R[(size_t)k * m + k] = -1.0 / G[(size_t)k * m + k];
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) {
+                if (i != k && j != k) R[(size_t)i * m + j] = G[(size_t)i * m + j] + G[(size_t)k * m + j] * G[(size_t)i * m + k] * R[(size_t)k * m + k];
+                else if (i != k && j == k) R[(size_t)i * m + k] = G[(size_t)i * m + k] * R[(size_t)k * m + k];
+                else if (i == k && j != k) R[(size_t)k * m + j] = G[(size_t)k * m + j] * R[(size_t)k * m + k];
+            }
+        G = R;
+    }
+    for (double &v : R) v *= -1.0;
+    // aTaInv.dot(aT), then .dot(y)
+    std::vector<double> P((size_t)m * n);
+    for (int i = 0; i < m; ++i)
+        for (int c = 0; c < n; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < m; ++k) acc = acc + R[(size_t)i * m + k] * A[(size_t)c * m + k];
+            P[(size_t)i * n + c] = acc;
+        }
+    for (int i = 0; i < m; ++i) {
+        double acc = 0.0;
+        for (int c = 0; c < n; ++c) acc = acc + P[(size_t)i * n + c] * y[c];
+        if (!(acc == acc) || std::isinf(acc)) return OIP_E_RUNTIME;
+        coeffs[i] = acc;
+    }
+    return OIP_OK;
+}
+
 // FilterInterBandShiftValues (preproc.h:492-512) + DoCorrelationPolynomialFitting
 // (preproc.h:514-550): per band keep the shifts whose response reaches the threshold,
 // require at least min_count of them, fit dx(cx) with degree 1 and dy(cx) with degree 2.
-extern "C" int oip_filter_and_fit(const double *shifts, int n, double threshold, int min_count, double *cx_out,
-                                  double *cy_out, char *err, int errlen)
+extern "C" int oip_filter_and_fit_mode(const double *shifts, int n, double threshold, int min_count, int fit_mode,
+                                       double *cx_out, double *cy_out, char *err, int errlen)
 {
-    if (!shifts || n <= 0 || !cx_out || !cy_out) return OIP_E_INVALID;
+    if (!shifts || n <= 0 || !cx_out || !cy_out || (fit_mode != OIP_FIT_REFERENCE && fit_mode != OIP_FIT_LSTSQ)) return OIP_E_INVALID;
+    auto fit = fit_mode == OIP_FIT_LSTSQ ? oip_polyfit : oip_polyfit_reference;
     std::vector<double> cxv(n), xv(n), yv(n);
     for (int b = 0; b < OIP_MSS_BANDS; ++b) {
         int vvi = 0;
@@ -143,12 +203,41 @@ extern "C" int oip_filter_and_fit(const double *shifts, int n, double threshold,
                          b + 1, vvi, min_count);
             return OIP_E_RUNTIME;
         }
-        int rc = oip_polyfit(cxv.data(), xv.data(), vvi, 1, cx_out + b * 2);
-        if (rc == OIP_OK) rc = oip_polyfit(cxv.data(), yv.data(), vvi, 2, cy_out + b * 3);
+        int rc = fit(cxv.data(), xv.data(), vvi, 1, cx_out + b * 2);
+        if (rc == OIP_OK) rc = fit(cxv.data(), yv.data(), vvi, 2, cy_out + b * 3);
         if (rc != OIP_OK) {
             if (err && errlen > 0) snprintf(err, errlen, "polynomial fit failed for band#%d (degenerate abscissae)", b + 1);
             return OIP_E_RUNTIME;
         }
     }
+    return OIP_OK;
+}
+
+extern "C" int oip_filter_and_fit(const double *shifts, int n, double threshold, int min_count, double *cx_out,
+                                  double *cy_out, char *err, int errlen)
+{
+    return oip_filter_and_fit_mode(shifts, n, threshold, min_count, OIP_FIT_REFERENCE, cx_out, cy_out, err, errlen);
+}
+
+// The accumulation of Stitcher::CalcSttParameters (stitcher.h:181-198): sections in order, a section is
+// valid when resp >= threshold and (max_delta_y <= 0 or |dy| <= max_delta_y); arithmetic means in fp64.
+// NaN rows (sections no rank computed) fail the comparison like any low response.  Every rank of a
+// multi-GPU run calls this on the all-gathered table and gets identical bits.
+extern "C" int oip_stt_mean(const double *table, int sections, double threshold, double max_delta_y, double *dx,
+                            double *dy, double *response, int *valid_out)
+{
+    if (!table || sections <= 0) return OIP_E_INVALID;
+    double sx = 0.0, sy = 0.0, sr = 0.0;
+    int valid = 0;
+    for (int i = 0; i < sections; ++i) {
+        const double x = table[3 * i], y = table[3 * i + 1], r = table[3 * i + 2];
+        const bool ok = r >= threshold && (max_delta_y <= 0.0 || std::fabs(y) <= max_delta_y);
+        if (ok) { sx += x; sy += y; sr += r; ++valid; }
+    }
+    if (valid_out) *valid_out = valid;
+    if (valid == 0) return OIP_E_RUNTIME;       // "No valid delta value found for stitching parameter calculating"
+    if (dx) *dx = sx / valid;
+    if (dy) *dy = sy / valid;
+    if (response) *response = sr / valid;
     return OIP_OK;
 }

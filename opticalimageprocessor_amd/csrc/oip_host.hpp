@@ -5,8 +5,8 @@
 //
 // Differences kept deliberately small:
 //   * the line width is a constructor/run-time argument (reference: PIXELS_PER_LINE 12288);
-//   * TIFF output goes through a dependency-free uncompressed TIFF/BigTIFF writer (oip_tiff.hpp)
-//     instead of GDAL / cv::imwrite; TIFF *input* (stitching two ALIGNED.TIFF files) is not built;
+//   * TIFF input and output go through a dependency-free TIFF/BigTIFF codec (oip_tiff.hpp) instead of
+//     GDAL / cv::imread / cv::imwrite;
 //   * timing lines are logged like the reference's (seconds, MBps) through a plain logger.
 #pragma once
 

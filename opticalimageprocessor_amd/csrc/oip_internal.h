@@ -59,8 +59,9 @@ struct oip_ctx {
     float *d_tab1d = nullptr;
 
     // scratch for small host<->device results
-    void *d_small = nullptr;       // 64 KiB device scratch
-    void *h_small = nullptr;       // 64 KiB pinned host scratch
+    void *d_small = nullptr;       // device scratch for result tables (64 KiB, grown on demand: oip_small)
+    void *h_small = nullptr;       // pinned host mirror of it
+    size_t small_bytes = 0;
 
     // growable device workspace (FFT planes, windows)
     void *d_work = nullptr;
@@ -87,6 +88,7 @@ int oip_fail(oip_ctx *ctx, int code, const char *fmt, ...);
 int oip_prof_begin(oip_ctx *ctx, const char *name);   // returns pending index or -1
 void oip_prof_end(oip_ctx *ctx, int pending);
 int oip_workspace(oip_ctx *ctx, size_t bytes, void **out);   // grow-only workspace
+int oip_small(oip_ctx *ctx, size_t bytes);                   // make d_small / h_small hold at least `bytes`
 void oip_fft_destroy(oip_ctx *ctx);
 
 #define OIP_HIP(ctx, call)                                                              \

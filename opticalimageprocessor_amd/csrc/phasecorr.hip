@@ -97,15 +97,17 @@ constexpr int kVBatch = 8;      // images per launch (the four bands of two unit
 template <typename SrcT> struct VBatch {
     const SrcT *src[kVBatch];
     float *dst[kVBatch];
+    long spitch[kVBatch];       // source pitch per image (raster windows and compact unit windows mix in one batch)
 };
 template <typename SrcT>
-__global__ __launch_bounds__(kBlock) void resize_cubic_v_kernel(VBatch<SrcT> vb, long spitch, int sw, int sh, int dh,
+__global__ __launch_bounds__(kBlock) void resize_cubic_v_kernel(VBatch<SrcT> vb, int sw, int sh, int dh,
                                                                 const int *__restrict__ yofs, const float4 *__restrict__ beta)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if (x >= sw) return;
     const SrcT *__restrict__ src = vb.src[blockIdx.z];
     float *__restrict__ dst = vb.dst[blockIdx.z];
+    const long spitch = vb.spitch[blockIdx.z];
 #pragma unroll
     for (int j = 0; j < kVRows; ++j) {
         const int dy = blockIdx.y * kVRows + j;
@@ -757,13 +759,14 @@ int launch_resize(oip_ctx *ctx, const SrcT *src, long spitch, int sw, int sh, fl
 constexpr int kV4Blocks = 8;        // source rows (= 4 output rows each) per thread
 constexpr int kV4Threads = 128;
 template <typename SrcT>
-__global__ __launch_bounds__(kV4Threads) void resize_cubic_v_x4_kernel(VBatch<SrcT> vb, long spitch, int sw, int sh, int dh,
+__global__ __launch_bounds__(kV4Threads) void resize_cubic_v_x4_kernel(VBatch<SrcT> vb, int sw, int sh, int dh,
                                                                       const float4 *__restrict__ beta)
 {
     const int c = blockIdx.x * kV4Threads + threadIdx.x;            // column pair
     if (2 * c >= sw) return;
     const SrcT *__restrict__ src = vb.src[blockIdx.z] + 2 * c;
     float *__restrict__ dst = vb.dst[blockIdx.z] + 2 * c;
+    const long spitch = vb.spitch[blockIdx.z];
     const int p0 = blockIdx.y * kV4Blocks;
     auto load = [&](int r) {                                        // clamped source row as two floats
         r = r < 0 ? 0 : (r > sh - 1 ? sh - 1 : r);
@@ -800,26 +803,27 @@ __global__ __launch_bounds__(kV4Threads) void resize_cubic_v_x4_kernel(VBatch<Sr
 // vertical half only (see resize_cubic_v_kernel) of `count` equally shaped images in one launch; *tab
 // carries the horizontal taps for the FFT loader
 template <typename SrcT>
-int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int count, long spitch, int sw, int sh, int dw, int dh,
+int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int count, const long *spitch, int sw, int sh, int dw, int dh,
                     const OipResizeTab **tab)
 {
     int rc = resize_tables(ctx, sw, sh, dw, dh, tab);
     if (rc) return rc;
     if (count < 1 || count > kVBatch) return oip_fail(ctx, OIP_E_RUNTIME, "launch_resize_v: bad batch");
     VBatch<SrcT> vb;
-    for (int i = 0; i < kVBatch; ++i) { vb.src[i] = src[i < count ? i : 0]; vb.dst[i] = dst[i < count ? i : 0]; }
+    for (int i = 0; i < kVBatch; ++i) { vb.src[i] = src[i < count ? i : 0]; vb.dst[i] = dst[i < count ? i : 0]; vb.spitch[i] = spitch[i < count ? i : 0]; }
     OipProfScope prof(ctx, "resize_cubic_v_kernel");
-    bool aligned = (sw & 1) == 0 && (spitch & 1) == 0 && dh == 4 * sh && (*tab)->x4v;
-    for (int i = 0; i < count; ++i) aligned = aligned && ((size_t)src[i] % (2 * sizeof(SrcT))) == 0 && ((size_t)dst[i] & 7) == 0;
+    bool aligned = (sw & 1) == 0 && dh == 4 * sh && (*tab)->x4v;
+    for (int i = 0; i < count; ++i)
+        aligned = aligned && (spitch[i] & 1) == 0 && ((size_t)src[i] % (2 * sizeof(SrcT))) == 0 && ((size_t)dst[i] & 7) == 0;
     { const char *e = getenv("OIP_V_GENERIC"); if (e && atoi(e)) aligned = false; }      // test knob: force the generic kernel
     if (aligned) {
         hipLaunchKernelGGL(resize_cubic_v_x4_kernel<SrcT>, dim3((sw / 2 + kV4Threads - 1) / kV4Threads, (sh + kV4Blocks - 1) / kV4Blocks, count),
-                           dim3(kV4Threads), 0, ctx->stream, vb, spitch, sw, sh, dh, reinterpret_cast<const float4 *>((*tab)->d_beta));
+                           dim3(kV4Threads), 0, ctx->stream, vb, sw, sh, dh, reinterpret_cast<const float4 *>((*tab)->d_beta));
         OIP_HIP(ctx, hipGetLastError());
         return OIP_OK;
     }
     hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows, count), dim3(kBlock), 0,
-                       ctx->stream, vb, spitch, sw, sh, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
+                       ctx->stream, vb, sw, sh, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
 }
@@ -1090,45 +1094,157 @@ extern "C" int oip_phase_correlate_f32(oip_ctx *ctx, const float *d_a, const flo
     return OIP_OK;
 }
 
+// CCD-pair correlations of n window pairs (the loop body of stitcher.h:166-191 after the colRange): window i is
+// rows x cols u16 at a[i] / b[i] with its own pitch; results go to d_res[3 * i]
+static int stt_pairs(oip_ctx *ctx, const uint16_t *const *a, const size_t *pitch_a, const uint16_t *const *b,
+                     const size_t *pitch_b, int n, int rows, int cols, double *host_out)
+{
+    const int M = optimal_dft_size(rows), N = optimal_dft_size(cols);
+    if (M > 65535) return oip_fail(ctx, OIP_E_UNSUPPORTED, "correlation window taller than 65535 lines");
+    const OipFft2dPlan *pl;
+    int rc = oip_fft2d_plan(ctx, M, N, &pl);
+    if (rc) return rc;
+    PcWork w;
+    if ((rc = carve(ctx, pl, 1, 1, 0, 1, 1, 0, &w))) return rc;
+    if ((rc = oip_small(ctx, sizeof(double) * 3 * (size_t)(n > 0 ? n : 1)))) return rc;
+    double *d_res = (double *)ctx->d_small;
+    for (int i = 0; i < n; ++i)
+        if ((rc = correlate_pair(ctx, pl, w, src_u16(a[i], (long)pitch_a[i]), src_u16(b[i], (long)pitch_b[i]), rows, cols, d_res + 3 * i)))
+            return rc;
+    if (n > 0 && (rc = fetch_results(ctx, 3 * n, host_out))) return rc;
+    return OIP_OK;
+}
+
+extern "C" int oip_stt_correlate_windows(oip_ctx *ctx, const uint16_t *const *d_a, const size_t *pitch_a,
+                                         const uint16_t *const *d_b, const size_t *pitch_b, int n, int rows, int cols,
+                                         double *out)
+{
+    OIP_CHECK_CTX(ctx);
+    if (n < 0 || (n > 0 && (!d_a || !d_b || !pitch_a || !pitch_b || !out)) || rows <= 0 || cols <= 0)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_stt_correlate_windows: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!d_a[i] || !d_b[i] || pitch_a[i] < (size_t)cols || pitch_b[i] < (size_t)cols)
+            return oip_fail(ctx, OIP_E_INVALID, "oip_stt_correlate_windows: window %d has a null pointer or a pitch below %d", i, cols);
+    return stt_pairs(ctx, d_a, pitch_a, d_b, pitch_b, n, rows, cols, out);
+}
+
 extern "C" int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uint16_t *d_pan2, int W, long L, long row0,
                                  long nrows, int sections, int lines_per_section, int overlap_cols, int edge_cols,
                                  double *out)
 {
     OIP_CHECK_CTX(ctx);
     if (!d_pan1 || !d_pan2 || !out || W <= 0 || L <= 0 || sections <= 0 || lines_per_section <= 0 || overlap_cols <= 0 ||
-        overlap_cols > W || edge_cols < 0 || edge_cols >= overlap_cols || sections > 1000)
+        overlap_cols > W || edge_cols < 0 || edge_cols >= overlap_cols || sections > 100000)
         return oip_fail(ctx, OIP_E_INVALID, "oip_stt_correlate: bad argument");
     // stitcher.h:75-77
     if (L < (long)sections * lines_per_section)
         return oip_fail(ctx, OIP_E_INVALID, "PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)");
     const int rows = lines_per_section, cols = overlap_cols - edge_cols;
+    // stitcher.h:151-152, :167
+    const long gap = (L - (long)sections * lines_per_section) / (sections + 1);
+    const long step = gap + lines_per_section;
+    std::vector<int> which;
+    std::vector<const uint16_t *> a, b;
+    for (int s = 0; s < sections; ++s) {
+        const long off = gap + (long)s * step;
+        if (off < row0 || off + rows > row0 + nrows) continue;     // another rank's section
+        which.push_back(s);
+        // stitcher.h:175-176: PAN1 cols [W-ov, W-edge), PAN2 cols [edge, ov); the u16->f32
+        // conversion happens in the first FFT pass' loader
+        a.push_back(d_pan1 + (size_t)(off - row0) * W + (W - overlap_cols));
+        b.push_back(d_pan2 + (size_t)(off - row0) * W + edge_cols);
+    }
+    std::vector<size_t> pitch(which.size(), (size_t)W);
+    std::vector<double> r(3 * which.size() + 3);
+    int rc = stt_pairs(ctx, a.data(), pitch.data(), b.data(), pitch.data(), (int)which.size(), rows, cols, r.data());
+    if (rc) return rc;
+    for (int s = 0; s < sections; ++s)
+        for (int k = 0; k < 3; ++k) out[3 * s + k] = NAN;
+    for (size_t i = 0; i < which.size(); ++i)
+        for (int k = 0; k < 3; ++k) out[3 * which[i] + k] = r[3 * i + k];
+    return OIP_OK;
+}
+
+// One inter-band unit: a PAN window (rows x cols u16) and the matching windows of the four bands
+// (band_rows x band_cols u16), each with its own pitch -- a window of the resident raster or a compact
+// copy received from another rank.
+struct IbUnit {
+    const uint16_t *pan;
+    long pan_pitch;
+    const uint16_t *band[OIP_MSS_BANDS];
+    long band_pitch;
+};
+
+// The loop body of preproc.h:262-329 for n units: per unit and band (dx, dy, response) -> host_out[12 * u + 3 * b].
+// Units go two at a time (five forward and four inverse transforms per pair).
+static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, int cols, int band_rows, int band_cols,
+                           double *host_out)
+{
     const int M = optimal_dft_size(rows), N = optimal_dft_size(cols);
-    if (M > 65535) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_stt_correlate: section taller than 65535 lines");
+    if (M > 65535) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_interband_correlate: more than 65535 correlation lines");
     const OipFft2dPlan *pl;
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
     PcWork w;
-    if ((rc = carve(ctx, pl, 1, 1, 0, 1, 1, 0, &w))) return rc;
-    // stitcher.h:151-152, :167
-    const long gap = (L - (long)sections * lines_per_section) / (sections + 1);
-    const long step = gap + lines_per_section;
+    if ((rc = carve(ctx, pl, rows, band_cols, 0, 5, 2, 8, &w))) return rc;      // f32 scratch: the V images
+    if ((rc = oip_small(ctx, sizeof(double) * 12 * (size_t)(n > 0 ? n : 1)))) return rc;
     double *d_res = (double *)ctx->d_small;
-    std::vector<int> have(sections, 0);
-    for (int s = 0; s < sections; ++s) {
-        const long off = gap + (long)s * step;
-        if (off < row0 || off + rows > row0 + nrows) continue;     // another rank's section
-        have[s] = 1;
-        // stitcher.h:175-176: PAN1 cols [W-ov, W-edge), PAN2 cols [edge, ov); the u16->f32
-        // conversion happens in the first FFT pass' loader
-        const uint16_t *a = d_pan1 + (size_t)(off - row0) * W + (W - overlap_cols);
-        const uint16_t *b = d_pan2 + (size_t)(off - row0) * W + edge_cols;
-        if ((rc = correlate_pair(ctx, pl, w, src_u16(a, W), src_u16(b, W), rows, cols, d_res + 3 * s))) return rc;
+    // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
+    // (u16 -> f32, rows x band_cols), the horizontal pass inside the FFT loader.
+    const OipResizeTab *tab = nullptr;
+    // vertical passes of all bands of one or two units in one launch
+    auto upsample = [&](const IbUnit *const *uns, int nun, float *const *fb, RealSrc *out) -> int {
+        const uint16_t *srcs[kVBatch];
+        long pitches[kVBatch];
+        for (int u = 0; u < nun; ++u)
+            for (int b = 0; b < OIP_MSS_BANDS; ++b) {
+                srcs[4 * u + b] = uns[u]->band[b];
+                pitches[4 * u + b] = uns[u]->band_pitch;
+                out[4 * u + b] = src_v(fb[4 * u + b]);
+            }
+        return launch_resize_v<uint16_t>(ctx, srcs, fb, 4 * nun, pitches, band_cols, band_rows, cols, rows, &tab);
+    };
+    int k = 0;
+    RealSrc sAB[8];
+    for (; k + 1 < n; k += 2) {
+        const IbUnit &A = units[k], &B = units[k + 1];
+        const IbUnit *two[2] = {&A, &B};
+        if ((rc = upsample(two, 2, w.fb, sAB))) return rc;
+        const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
+        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, src_u16(B.pan, B.pan_pitch), sAB + 4, rows, cols,
+                                      d_res + 12 * k, d_res + 12 * (k + 1), &vt))) return rc;
     }
-    std::vector<double> r(3 * sections);
-    if ((rc = fetch_results(ctx, 3 * sections, r.data()))) return rc;
-    for (int s = 0; s < sections; ++s)
-        for (int k = 0; k < 3; ++k) out[3 * s + k] = have[s] ? r[3 * s + k] : NAN;
+    if (k < n) {
+        const IbUnit &A = units[k];
+        const IbUnit *one[1] = {&A};
+        if ((rc = upsample(one, 1, w.fb, sAB))) return rc;
+        const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
+        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, rows, cols, d_res + 12 * k, &vt))) return rc;
+    }
+    if (n > 0 && (rc = fetch_results(ctx, 12 * n, host_out))) return rc;
     return OIP_OK;
+}
+
+extern "C" int oip_interband_correlate_units(oip_ctx *ctx, const uint16_t *const *d_pan, const size_t *pan_pitch,
+                                             const uint16_t *const *d_bands, const size_t *band_pitch, int n, int rows,
+                                             int cols, double *out)
+{
+    OIP_CHECK_CTX(ctx);
+    if (n < 0 || (n > 0 && (!d_pan || !pan_pitch || !d_bands || !band_pitch || !out)) || rows <= 0 || cols <= 0)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_interband_correlate_units: bad argument");
+    // preproc.h:274-276: the band window is the PAN window integer-divided by 4
+    const int band_rows = rows / OIP_MSS_BANDS, band_cols = cols / OIP_MSS_BANDS;
+    if (band_rows <= 0 || band_cols <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_interband_correlate_units: window too small");
+    std::vector<IbUnit> units((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        units[i].pan = d_pan[i];
+        units[i].pan_pitch = (long)pan_pitch[i];
+        units[i].band_pitch = (long)band_pitch[i];
+        bool ok = d_pan[i] && pan_pitch[i] >= (size_t)cols && band_pitch[i] >= (size_t)band_cols;
+        for (int b = 0; b < OIP_MSS_BANDS; ++b) { units[i].band[b] = d_bands[4 * i + b]; ok = ok && d_bands[4 * i + b]; }
+        if (!ok) return oip_fail(ctx, OIP_E_INVALID, "oip_interband_correlate_units: unit %d has a null pointer or a short pitch", i);
+    }
+    return interband_units(ctx, units.data(), n, rows, cols, band_rows, band_cols, out);
 }
 
 extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long Lp, long prow0, long pn,
@@ -1144,8 +1260,6 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     if (sections <= 0) return oip_fail(ctx, OIP_E_INVALID, "CalcInterBandCorrelation: section count should be a positive integer");
     if (sections > 1 && (long)sections * corr_lines > Lp)
         return oip_fail(ctx, OIP_E_INVALID, "CalcInterBandCorrelation: too many sections (%d lines per section), not enough total PAN data lines", corr_lines);
-    if ((long)slices * sections * 12 * sizeof(double) > 65536)
-        return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_interband_correlate: too many slices x sections");
     // preproc.h:245-247, :274-276
     const int baseRows = (int)(Lp < corr_lines ? Lp : corr_lines);
     const long baseRowGap = (Lp - (long)baseRows * sections) / (sections + 1);
@@ -1155,67 +1269,37 @@ extern "C" int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long
     const int bandSliceCols = baseSliceCols / OIP_MSS_BANDS;
     const int Wb = W / OIP_MSS_BANDS;
     if (bandRows <= 0 || bandSliceCols <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_interband_correlate: slice too small");
-    const int M = optimal_dft_size(baseRows), N = optimal_dft_size(baseSliceCols);
-    if (M > 65535) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_interband_correlate: more than 65535 correlation lines");
-    const OipFft2dPlan *pl;
-    int rc = oip_fft2d_plan(ctx, M, N, &pl);
-    if (rc) return rc;
-    PcWork w;
-    if ((rc = carve(ctx, pl, baseRows, bandSliceCols, 0, 5, 2, 8, &w))) return rc;      // f32 scratch: the V images
-    double *d_res = (double *)ctx->d_small;
     const int n = slices * sections;
-    std::vector<int> have(n, 0);
-    struct Unit { int u; const uint16_t *pw; long bandRow0; int slice; };
-    std::vector<Unit> units;
+    std::vector<int> which;
+    std::vector<IbUnit> units;
     for (int sec = 0; sec < sections; ++sec) {
         const long secRowStart = baseRowGap + (long)sec * (baseRows + baseRowGap);        // preproc.h:257
         const long secBandRowStart = bandRowGap + (long)sec * (bandRows + bandRowGap);    // preproc.h:284
         if (secRowStart < prow0 || secRowStart + baseRows > prow0 + pn) continue;
         if (secBandRowStart < mrow0 || secBandRowStart + bandRows > mrow0 + mn) continue;
         for (int i = 0; i < slices; ++i) {
-            have[sec * slices + i] = 1;
-            units.push_back(Unit{sec * slices + i, d_pan + (size_t)(secRowStart - prow0) * W + (size_t)i * baseSliceCols,
-                                 secBandRowStart - mrow0, i});
+            which.push_back(sec * slices + i);
+            IbUnit u;
+            u.pan = d_pan + (size_t)(secRowStart - prow0) * W + (size_t)i * baseSliceCols;
+            u.pan_pitch = W;
+            for (int b = 0; b < OIP_MSS_BANDS; ++b)
+                u.band[b] = d_planes + (size_t)b * plane_stride + (size_t)(secBandRowStart - mrow0) * Wb + (size_t)i * bandSliceCols;
+            u.band_pitch = Wb;
+            units.push_back(u);
         }
     }
-    // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
-    // (u16 -> f32, baseRows x bandSliceCols), the horizontal pass inside the FFT loader.
-    const OipResizeTab *tab = nullptr;
-    // vertical passes of all bands of one or two units in one launch
-    auto upsample = [&](const Unit *const *uns, int nun, float *const *fb, RealSrc *out) -> int {
-        const uint16_t *srcs[kVBatch];
-        for (int u = 0; u < nun; ++u)
-            for (int b = 0; b < OIP_MSS_BANDS; ++b) {
-                srcs[4 * u + b] = d_planes + (size_t)b * plane_stride + (size_t)uns[u]->bandRow0 * Wb + (size_t)uns[u]->slice * bandSliceCols;
-                out[4 * u + b] = src_v(fb[4 * u + b]);
-            }
-        return launch_resize_v<uint16_t>(ctx, srcs, fb, 4 * nun, Wb, bandSliceCols, bandRows, baseSliceCols, baseRows, &tab);
-    };
-    size_t k = 0;
-    RealSrc sAB[8];
-    for (; k + 1 < units.size(); k += 2) {
-        const Unit &A = units[k], &B = units[k + 1];
-        const Unit *two[2] = {&A, &B};
-        if ((rc = upsample(two, 2, w.fb, sAB))) return rc;
-        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
-        if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pw, W), sAB, src_u16(B.pw, W), sAB + 4, baseRows, baseSliceCols,
-                                      d_res + 12 * A.u, d_res + 12 * B.u, &vt))) return rc;
-    }
-    if (k < units.size()) {
-        const Unit &A = units[k];
-        const Unit *one[1] = {&A};
-        if ((rc = upsample(one, 1, w.fb, sAB))) return rc;
-        const HTaps vt{bandSliceCols, tab->d_xofs, tab->d_alpha, tab->x4h};
-        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pw, W), sAB, baseRows, baseSliceCols, d_res + 12 * A.u, &vt))) return rc;
-    }
-    std::vector<double> r(12 * n);
-    if ((rc = fetch_results(ctx, 12 * n, r.data()))) return rc;
+    std::vector<double> r(12 * units.size() + 12);
+    int rc = interband_units(ctx, units.data(), (int)units.size(), baseRows, baseSliceCols, bandRows, bandSliceCols, r.data());
+    if (rc) return rc;
     for (int b = 0; b < OIP_MSS_BANDS; ++b)
         for (int u = 0; u < n; ++u) {
             double *o = out + ((size_t)b * n + u) * 4;
             const int i = u % slices;
-            for (int k = 0; k < 3; ++k) o[k] = have[u] ? r[12 * u + 3 * b + k] : NAN;
+            o[0] = o[1] = o[2] = NAN;
             o[3] = (double)(i * baseSliceCols + baseSliceCols / 2);                        // preproc.h:326
         }
+    for (size_t j = 0; j < which.size(); ++j)
+        for (int b = 0; b < OIP_MSS_BANDS; ++b)
+            for (int k = 0; k < 3; ++k) out[((size_t)b * n + which[j]) * 4 + k] = r[12 * j + 3 * b + k];
     return OIP_OK;
 }

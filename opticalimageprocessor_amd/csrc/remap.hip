@@ -269,6 +269,130 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
     }
 }
 
+// ---- fp16-accumulate variant (BASELINE config 5: "fp16 accumulate, tolerance stated") ----------------------
+// Same geometry, phases, tap positions and border rules as remap_shift8_kernel; only the 16-tap sum of
+// the regular interior pixels changes: samples and the sixteen 2-D weights are rounded to fp16 and the sum
+// is a chain of packed fp16 FMAs (v_pk_fma_f16: two output pixels per instruction, 16 instructions per
+// pixel pair instead of 62 unfused f32 operations).  NOT the parity mode: fp16 carries 11 significant bits,
+// so 12-bit data above 2047 DN is already quantised to even values on the way in and the running sum rounds
+// to 2 DN steps above 2048 (4 DN above 4096, ...).  Measured against the f32 kernel on the 12-bit synthetic
+// strips: max |delta| 4 DN (tests/test_gpu_resample.py::test_remap_f16acc_tolerance); the
+// bound asserted for arbitrary data is |delta| <= 4 + max(sample) / 256.  Samples above 65504 overflow fp16: the
+// mode is specified for data up to 15 bits.  Irregular column groups and section-border lines still go
+// through the f32 fix-up kernels.
+typedef _Float16 oip_h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ oip_h2 h2_from_u16pair(uint32_t w)
+{
+    oip_h2 r;
+    r.x = (_Float16)(unsigned short)(w & 0xffffu);
+    r.y = (_Float16)(unsigned short)(w >> 16);
+    return r;
+}
+// (a.y, b.x): the pair one sample further along the line
+__device__ __forceinline__ oip_h2 h2_shift(oip_h2 a, oip_h2 b)
+{
+    const uint32_t ua = __builtin_bit_cast(uint32_t, a), ub = __builtin_bit_cast(uint32_t, b);
+    return __builtin_bit_cast(oip_h2, __builtin_amdgcn_alignbit(ub, ua, 16));
+}
+
+// one source line as packed fp16 pairs: E[i] = (g[2i], g[2i+1]), O[i] = (g[2i+1], g[2i+2]), g[q] = sample c0 + q
+__device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
+                                                  oip_h2 E[6], oip_h2 O[5])
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
+    const long e0 = (long)row * W + c0;
+    const long d0 = e0 >> 1;
+    const long dmax = (nelem - 1) >> 1;
+    oip_h2 H[6], S[5];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        long di = d0 + i;
+        H[i] = h2_from_u16pair(p32[di > dmax ? dmax : di]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) S[i] = h2_shift(H[i], H[i + 1]);
+    const bool odd = c0 & 1;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        E[i] = odd ? S[i] : H[i];
+        O[i] = odd ? H[i + 1] : S[i];
+    }
+    E[5] = H[5];        // only its first half is ever used (sample 10), and only for even c0; odd c0 never reads E[5]
+}
+
+__global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+                                                                     const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                                     long src_elems, double dx, const float *__restrict__ tab1d,
+                                                                     int rows_per_block)
+{
+    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (x0 >= W) return;
+    int c0, fx0;
+    if (!shift_group_regular(x0, W, dx, &c0, &fx0)) return;        // fix-up launch A (f32)
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    float wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
+
+    oip_h2 E[4][6], O[4][5];                      // tap line t at unrolled step k lives in slot (k+t)&3
+    oip_h2 w2d[16];
+    int cur1 = -2, cur2 = -2, cur3 = -2;
+    int cur_fy = -1;
+    for (long rb = r0; rb < r1; rb += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long r = rb + k;
+            if (r >= r1) break;
+            const RowInfo ri = rows[r];
+            if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B (f32)
+            const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
+            if (slide) {
+                load_src_line11_h(src, ri.src[3], W, c0, src_elems, E[(k + 3) & 3], O[(k + 3) & 3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) load_src_line11_h(src, ri.src[t], W, c0, src_elems, E[(k + t) & 3], O[(k + t) & 3]);
+            }
+            cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+            if (ri.fy != cur_fy) {
+                cur_fy = ri.fy;
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky) {
+                    const float wy = tab1d[cur_fy * 4 + ky];
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        const _Float16 h = (_Float16)__fmul_rn(wy, wx[kx]);
+                        oip_h2 hh = {h, h};
+                        w2d[ky * 4 + kx] = hh;
+                    }
+                }
+            }
+            unsigned out[8];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {             // output pixels 2p, 2p+1
+                oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
+                    acc = __builtin_elementwise_fma(Et[p], w2d[t * 4 + 0], acc);
+                    acc = __builtin_elementwise_fma(Ot[p], w2d[t * 4 + 1], acc);
+                    acc = __builtin_elementwise_fma(Et[p + 1], w2d[t * 4 + 2], acc);
+                    acc = __builtin_elementwise_fma(Ot[p + 1], w2d[t * 4 + 3], acc);
+                }
+                // clamp before the conversion: inf -> 65535, NaN -> 0 (fmaxf returns the non-NaN operand)
+                out[2 * p] = oip_sat_u16(fminf(fmaxf((float)acc.x, 0.f), 65535.f));
+                out[2 * p + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y, 0.f), 65535.f));
+            }
+            uint4 o;
+            o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+            o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+            *reinterpret_cast<uint4 *>(dst + r * (long)W + x0) = o;
+        }
+    }
+}
+
 // fix-up A: irregular 8-column groups, all lines.  blockIdx.x = index into `groups`; the 256
 // lanes are 8 columns x 32 line sub-ranges.
 __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
@@ -355,9 +479,9 @@ extern "C" int oip_remap_shift_src_range(long out_row0, long out_rows, long L, d
     return OIP_OK;
 }
 
-extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows,
-                                           uint16_t *d_dst, long out_row0, long out_rows, int W, long L, double dx,
-                                           double dy, int section_rows, int row_guard)
+static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows, uint16_t *d_dst,
+                            long out_row0, long out_rows, int W, long L, double dx, double dy, int section_rows,
+                            int row_guard, bool f16acc)
 {
     OIP_CHECK_CTX(ctx);
     if (!d_src || !d_dst || W <= 0 || L <= 0 || section_rows <= 3)
@@ -422,9 +546,9 @@ extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
         {
-            OipProfScope prof(ctx, "remap_shift8_kernel");
-            hipLaunchKernelGGL(remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, rows, W,
-                               out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
+            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel");
+            hipLaunchKernelGGL(f16acc ? remap_shift8_f16_kernel : remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0,
+                               ctx->stream, d_src, d_dst, rows, W, out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
         }
         if (!bad_groups.empty()) {
             OipProfScope prof(ctx, "remap_fix_cols_kernel");
@@ -454,4 +578,18 @@ extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, 
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
+}
+
+extern "C" int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows,
+                                           uint16_t *d_dst, long out_row0, long out_rows, int W, long L, double dx,
+                                           double dy, int section_rows, int row_guard)
+{
+    return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, false);
+}
+
+extern "C" int oip_remap_shift_bicubic_u16_f16acc(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows,
+                                                  uint16_t *d_dst, long out_row0, long out_rows, int W, long L, double dx,
+                                                  double dy, int section_rows, int row_guard)
+{
+    return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, true);
 }

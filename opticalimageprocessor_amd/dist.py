@@ -1,22 +1,31 @@
-"""Scan-line-block sharding of one 4-band strip over the GPUs of a node.
+"""Scan-line-block sharding of the two strip work-flows over the GPUs of a node.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI, "gloo" on CPU for
-tests).  Rank r owns PAN lines [r*pb, (r+1)*pb) and MSS lines [r*pb/4, (r+1)*pb/4) of every
-plane.  The path has exactly three exchange steps, none of them a reduction over pixels:
+tests).  Rank r owns lines [r*pb, (r+1)*pb) of every raster (MSS planes: a quarter of that).
 
-  1. correlation windows: a 16000-line correlation section (preproc.h:245-259) that straddles a
-     block boundary is computed by the rank owning its first line; the lines it lacks are sent
-     point-to-point by the neighbour(s) (ncclSend/ncclRecv, one direct xGMI link each);
-  2. an all-gather of the per-(section, slice, band) results (<= 200 x 4 doubles), after which
-     every rank runs the identical fixed-order filter + polynomial fit, so the maps are
-     bit-identical on all ranks and to the 1-GPU run;
-  3. align halo: the few MSS lines above/below a block that the bicubic taps of its output
-     lines reach (oip_align_mss_src_range), again point-to-point.
+  default action (BASELINE config 4; preproc.h:224-468)      -> StripPlan / default_action_step
+  prestitch + stitch (BASELINE config 5; stitcher.h:83-201)   -> CcdPlan / prestitch_stitch_step
 
-Section seams of the reference (20000-line align sections, preproc.h:379-408) are computed
+Both have the same three exchange steps, none of them a reduction over pixels:
+
+  1. correlation windows.  The reference correlates a FIXED number of windows per strip (5 sections
+     x 10 slices x 4 bands, or 10 CCD sections), however long the strip is -- so on N GPUs the
+     windows, not the lines, are the unit of work.  Every (section, slice) unit -- a 16000 x 3000
+     PAN window plus four 4000 x 750 band windows, 120 MB -- is assigned to a rank
+     (`assign_units`: a unit stays on the rank that holds its lines while that rank has room,
+     the surplus goes to the least loaded rank); lines a unit's rank lacks arrive point-to-point
+     as compact windows (ncclSend/ncclRecv, one direct xGMI link each).  The kernels read
+     windows through (pointer, pitch), so resident windows are used in place.
+  2. an all-gather of the per-unit results (<= 200 x 4 doubles), after which every rank runs the
+     identical fixed-order host step (filter + polynomial fit, or the CCD shift mean), so the
+     maps are bit-identical on all ranks and to the 1-GPU run;
+  3. resampling halo: the few source lines above/below a block that the bicubic taps of its
+     output lines reach (oip_align_mss_src_range / oip_remap_shift_src_range), point-to-point.
+
+Section seams of the reference (20000-line align sections, 30000-row remap sections) are computed
 from GLOBAL line indices on every rank, so sharded output == unsharded output bit for bit.
-Everything numerical is delegated to a backend (the HIP context, or the CPU oracle in the
-gloo tests); this module only plans rows and moves them.
+Everything numerical is delegated to a backend (the HIP context, or the CPU oracle in the gloo
+tests); this module only plans rows and moves them.
 """
 from __future__ import annotations
 
@@ -34,6 +43,58 @@ class Transfer:
     kind: str         # "pan" | "mss"
     row0: int         # global first line
     rows: int
+
+
+@dataclass
+class Piece:
+    """lines [row0, row0+rows) x columns [col0, col0+cols) of raster `kind`, held by rank `src`, wanted by
+    rank `dst` as rows [dst_row, ...) of window `kind` of its unit `unit`"""
+    src: int
+    dst: int
+    kind: str         # "pan" | "mss" (all four planes) | "pan1" | "pan2"
+    unit: int         # global unit index
+    row0: int
+    rows: int
+    col0: int
+    cols: int
+    dst_row: int
+
+
+def assign_units(home, world, group=1):
+    """Rank of every unit.  `home[u]` is the rank that holds (most of) unit u's lines.  Units are dealt
+    in consecutive groups of `group` (the inter-band kernels process units two at a time): a group stays
+    at its home while the home holds fewer than ceil(ngroups / world) groups, otherwise it goes to the
+    least loaded rank (lowest index on ties).  Deterministic; identical on every rank."""
+    n = len(home)
+    ngroups = (n + group - 1) // group
+    cap = (ngroups + world - 1) // world
+    load = [0] * world
+    out = [0] * n
+    spill = []
+    for g in range(ngroups):
+        h = home[g * group]
+        if load[h] < cap:
+            load[h] += 1
+            for u in range(g * group, min(n, (g + 1) * group)):
+                out[u] = h
+        else:
+            spill.append(g)
+    for g in spill:
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += 1
+        for u in range(g * group, min(n, (g + 1) * group)):
+            out[u] = r
+    return out
+
+
+def _window_pieces(kind, unit, dst, row0, rows, col0, cols, block, world):
+    """cut the line range of one window at block boundaries"""
+    out = []
+    for r in range(world):
+        lo, hi = max(row0, r * block), min(row0 + rows, (r + 1) * block)
+        if lo < hi:
+            out.append(Piece(r, dst, kind, unit, lo, hi - lo, col0, cols, lo - row0))
+    return out
 
 
 class StripPlan:
@@ -57,7 +118,11 @@ class StripPlan:
         self.base_gap = (Lp_total - self.base_rows * sections) // (sections + 1)
         self.band_rows = self.base_rows // 4
         self.band_gap = self.base_gap // 4
+        self.base_cols = W // slices
+        self.band_cols = self.base_cols // 4
         self.out_rows = self.Lm - line_offset - (0 if keep_leading else overlap)
+        self.n_units = sections * slices
+        self.assign = assign_units([self.owner(u // slices) for u in range(self.n_units)], world, group=2)
 
     # -- blocks
     def pan_block(self, r):
@@ -66,39 +131,36 @@ class StripPlan:
     def mss_block(self, r):
         return r * self.mb, (r + 1) * self.mb
 
-    # -- correlation sections
+    # -- correlation sections and units
     def section(self, sec):
         p0 = self.base_gap + sec * (self.base_rows + self.base_gap)
         m0 = self.band_gap + sec * (self.band_rows + self.band_gap)
         return p0, p0 + self.base_rows, m0, m0 + self.band_rows
 
     def owner(self, sec):
+        """rank holding the section's first PAN line (its `home`)"""
         return min(self.section(sec)[0] // self.pb, self.world - 1)
 
-    def pan_tail(self, r):
-        """PAN lines beyond rank r's block that its owned sections need"""
-        e = self.pan_block(r)[1]
-        return max([0] + [self.section(s)[1] - e for s in range(self.sections) if self.owner(s) == r])
+    def units_of(self, r):
+        return [u for u in range(self.n_units) if self.assign[u] == r]
 
-    def mss_head_tail_capacity(self, r):
-        b0, b1 = self.mss_block(r)
-        tail = max([0] + [self.section(s)[3] - b1 for s in range(self.sections) if self.owner(s) == r])
-        head = max([0] + [b0 - self.section(s)[2] for s in range(self.sections) if self.owner(s) == r])
-        return max(head, self.halo_cap), max(tail, self.halo_cap)
+    def unit_pieces(self, u):
+        """what unit u's rank needs: its PAN window and its band windows, cut at block boundaries"""
+        sec, i = divmod(u, self.slices)
+        p0, p1, m0, m1 = self.section(sec)
+        dst = self.assign[u]
+        return (_window_pieces("pan", u, dst, p0, p1 - p0, i * self.base_cols, self.base_cols, self.pb, self.world) +
+                _window_pieces("mss", u, dst, m0, m1 - m0, i * self.band_cols, self.band_cols, self.mb, self.world))
 
-    def correlation_transfers(self):
-        """lines each section's owner lacks, cut at block boundaries (identical on all ranks)"""
+    def unit_is_local(self, u):
+        return all(p.src == p.dst for p in self.unit_pieces(u))
+
+    def correlation_pieces(self):
+        """every piece of every unit that is not entirely on its rank (identical on all ranks)"""
         out = []
-        for s in range(self.sections):
-            o = self.owner(s)
-            p0, p1, m0, m1 = self.section(s)
-            for kind, a, b, blk in (("pan", p0, p1, self.pb), ("mss", m0, m1, self.mb)):
-                for r in range(self.world):
-                    if r == o:
-                        continue
-                    lo, hi = max(a, r * blk), min(b, (r + 1) * blk)
-                    if lo < hi:
-                        out.append(Transfer(r, o, kind, lo, hi - lo))
+        for u in range(self.n_units):
+            if not self.unit_is_local(u):
+                out += self.unit_pieces(u)
         return out
 
     # -- align
@@ -129,33 +191,35 @@ class StripPlan:
 
 
 class ShardBuffers:
-    """Per-rank device buffers with room for received lines.
+    """Per-rank device buffers of the default action.
 
-    pan:    (pb + pan_tail) x W u16, holds global PAN lines [p_first, ...)
-    planes: 4 x (head + mb + tail) x Wb u16, holds global MSS lines [m_first, ...)
+    pan:    pb x W u16, the rank's own PAN lines
+    planes: 4 x (head + mb + tail) x Wb u16, global MSS lines [m_first, ...): own lines plus align halo
+    win:    compact windows of the units this rank computes but does not hold entirely
     """
 
     def __init__(self, plan: StripPlan, rank: int, device):
         self.plan, self.rank = plan, rank
         W, Wb = plan.W, plan.W // 4
         self.p_first = plan.pan_block(rank)[0]
-        self.pan_rows_cap = plan.pb + plan.pan_tail(rank)
-        self.pan = torch.zeros(self.pan_rows_cap, W, dtype=torch.uint16, device=device)
-        head, tail = plan.mss_head_tail_capacity(rank)
+        self.pan = torch.zeros(plan.pb, W, dtype=torch.uint16, device=device)
         b0, b1 = plan.mss_block(rank)
-        head = min(head, b0)
-        tail = min(tail, plan.Lm - b1)
+        head = min(plan.halo_cap, b0)
+        tail = min(plan.halo_cap, plan.Lm - b1)
         self.m_first = b0 - head
         self.m_rows_cap = head + plan.mb + tail
         self.planes = torch.zeros(4, self.m_rows_cap, Wb, dtype=torch.uint16, device=device)
         self.plane_stride = self.m_rows_cap * Wb
-        # valid extents (global lines), grown as halos arrive
-        self.p_valid = [self.p_first, self.p_first + plan.pb]
         self.m_valid = [b0, b1]
+        self.win = {}
+        for u in plan.units_of(rank):
+            if not plan.unit_is_local(u):
+                self.win[u] = {"pan": torch.zeros(plan.base_rows, plan.base_cols, dtype=torch.uint16, device=device),
+                               "mss": torch.zeros(4, plan.band_rows, plan.band_cols, dtype=torch.uint16, device=device)}
 
-    def pan_view(self, row0, rows):
+    def pan_rows(self, row0, rows):
         a = row0 - self.p_first
-        assert 0 <= a and a + rows <= self.pan_rows_cap, "PAN halo exceeds buffer capacity"
+        assert 0 <= a and a + rows <= self.plan.pb, "PAN lines outside the rank's block"
         return self.pan[a:a + rows]
 
     def mss_view(self, band, row0, rows):
@@ -167,35 +231,64 @@ class ShardBuffers:
         """element offset of the rank's own first MSS line inside each plane"""
         return (self.plan.mss_block(self.rank)[0] - self.m_first) * (self.plan.W // 4)
 
+    # -- views the piece exchange works on
+    def source_views(self, p: Piece):
+        """the 2-D views (lines x columns) piece p covers in this rank's rasters"""
+        if p.kind == "pan":
+            return [self.pan_rows(p.row0, p.rows)[:, p.col0:p.col0 + p.cols]]
+        return [self.mss_view(b, p.row0, p.rows)[:, p.col0:p.col0 + p.cols] for b in range(4)]
 
-def run_transfers(transfers, bufs: ShardBuffers, rank: int, group=None):
-    """execute the point-to-point line transfers (grouped: one launch on RCCL)"""
-    # gloo has no device point-to-point: device lines are staged through host memory (used only
-    # to rehearse the N-rank path on a 1-GPU box; the real runs use RCCL and move HBM to HBM)
-    stage = dist.get_backend(group) == "gloo" and bufs.pan.is_cuda
-    staged = []
-    ops = []
-    for t in transfers:
-        if t.kind == "pan":
-            views = [bufs.pan_view(t.row0, t.rows)] if rank in (t.src, t.dst) else []
-        else:
-            views = [bufs.mss_view(b, t.row0, t.rows) for b in range(4)] if rank in (t.src, t.dst) else []
-        for v in views:
-            # carry the lines as bytes: RCCL/NCCL has no 16-bit integer type, every backend has uint8
-            v16 = v.view(torch.uint8)
-            if stage:
-                h = v16.cpu() if rank == t.src else torch.empty(v16.shape, dtype=torch.uint8)
-                if rank == t.dst:
-                    staged.append((v16, h))
-                v16 = h
-            if rank == t.src:
-                ops.append(dist.P2POp(dist.isend, v16, t.dst, group=group))
-            elif rank == t.dst:
-                ops.append(dist.P2POp(dist.irecv, v16, t.src, group=group))
-        if rank == t.dst:
-            ext = bufs.p_valid if t.kind == "pan" else bufs.m_valid
-            ext[0] = min(ext[0], t.row0)
-            ext[1] = max(ext[1], t.row0 + t.rows)
+    def window_views(self, p: Piece):
+        w = self.win[p.unit]
+        if p.kind == "pan":
+            return [w["pan"][p.dst_row:p.dst_row + p.rows]]
+        return [w["mss"][b, p.dst_row:p.dst_row + p.rows] for b in range(4)]
+
+    def unit_windows(self, u):
+        """(PAN window view, [4 band window views]) of unit u: views of the rasters when the unit is local,
+        the compact windows otherwise"""
+        plan = self.plan
+        if u in self.win:
+            w = self.win[u]
+            return w["pan"], [w["mss"][b] for b in range(4)]
+        sec, i = divmod(u, plan.slices)
+        p0, p1, m0, m1 = plan.section(sec)
+        pan = self.pan_rows(p0, p1 - p0)[:, i * plan.base_cols:(i + 1) * plan.base_cols]
+        bands = [self.mss_view(b, m0, m1 - m0)[:, i * plan.band_cols:(i + 1) * plan.band_cols] for b in range(4)]
+        return pan, bands
+
+
+def _as_bytes(t):
+    """RCCL/NCCL has no 16-bit integer type; every backend has uint8"""
+    return t.view(torch.uint8)
+
+
+def run_pieces(pieces, bufs, rank: int, group=None):
+    """execute window-piece exchanges: the holder packs the (lines x columns) sub-block contiguously and
+    sends it, the unit's rank receives straight into the rows of its compact window; pieces a rank holds
+    itself are plain device copies.  One grouped launch on RCCL."""
+    stage = dist.is_initialized() and dist.get_backend(group) == "gloo" and bufs_is_cuda(bufs)
+    ops, keep, staged = [], [], []
+    for p in pieces:
+        if rank == p.src and rank == p.dst:
+            for s, d in zip(bufs.source_views(p), bufs.window_views(p)):
+                d.copy_(s)
+        elif rank == p.src:
+            for s in bufs.source_views(p):
+                c = s.contiguous()
+                c8 = _as_bytes(c)
+                if stage:
+                    c8 = c8.cpu()
+                keep.append(c8)
+                ops.append(dist.P2POp(dist.isend, c8, p.dst, group=group))
+        elif rank == p.dst:
+            for d in bufs.window_views(p):
+                d8 = _as_bytes(d)
+                if stage:
+                    h = torch.empty(d8.shape, dtype=torch.uint8)
+                    staged.append((d8, h))
+                    d8 = h
+                ops.append(dist.P2POp(dist.irecv, d8, p.src, group=group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
@@ -203,9 +296,59 @@ def run_transfers(transfers, bufs: ShardBuffers, rank: int, group=None):
         dev.copy_(host)
 
 
-def gather_shifts(local: np.ndarray, device, group=None) -> np.ndarray:
-    """all-gather the per-rank correlation tables (NaN = not mine) and merge them in rank
-    order: every rank ends with the same complete table."""
+def bufs_is_cuda(bufs):
+    t = getattr(bufs, "pan", None)
+    if t is None:
+        t = bufs.pan1
+    return t.is_cuda
+
+
+def run_transfers(transfers, bufs, rank: int, group=None):
+    """execute whole-line transfers into the halo rows of a raster (grouped: one launch on RCCL).
+    bufs provides line_views(kind, row0, rows) -> list of contiguous row-block tensors and note_valid()."""
+    # gloo has no device point-to-point: device lines are staged through host memory (used only
+    # to rehearse the N-rank path on a 1-GPU box; the real runs use RCCL and move HBM to HBM)
+    stage = dist.is_initialized() and dist.get_backend(group) == "gloo" and bufs_is_cuda(bufs)
+    staged = []
+    ops = []
+    for t in transfers:
+        views = bufs.line_views(t.kind, t.row0, t.rows) if rank in (t.src, t.dst) else []
+        for v in views:
+            v8 = _as_bytes(v)
+            if stage:
+                h = v8.cpu() if rank == t.src else torch.empty(v8.shape, dtype=torch.uint8)
+                if rank == t.dst:
+                    staged.append((v8, h))
+                v8 = h
+            if rank == t.src:
+                ops.append(dist.P2POp(dist.isend, v8, t.dst, group=group))
+            elif rank == t.dst:
+                ops.append(dist.P2POp(dist.irecv, v8, t.src, group=group))
+        if rank == t.dst:
+            bufs.note_valid(t.kind, t.row0, t.rows)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for dev, host in staged:
+        dev.copy_(host)
+
+
+def _shard_line_views(self, kind, row0, rows):
+    return [self.mss_view(b, row0, rows) for b in range(4)]
+
+
+def _shard_note_valid(self, kind, row0, rows):
+    self.m_valid[0] = min(self.m_valid[0], row0)
+    self.m_valid[1] = max(self.m_valid[1], row0 + rows)
+
+
+ShardBuffers.line_views = _shard_line_views
+ShardBuffers.note_valid = _shard_note_valid
+
+
+def gather_table(local: np.ndarray, device, group=None) -> np.ndarray:
+    """all-gather the per-rank result tables (NaN = not mine) and merge them in rank order: every rank
+    ends with the same complete table."""
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":
         device = "cpu"
@@ -220,33 +363,40 @@ def gather_shifts(local: np.ndarray, device, group=None) -> np.ndarray:
     return out
 
 
+gather_shifts = gather_table
+
+
 def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, raw_mss_bil, kb_pan, kb_mss4, out,
-                        rank: int, threshold=0.4, min_count=5, group=None):
+                        rank: int, threshold=0.4, min_count=5, group=None, fit="reference"):
     """One pass of the sharded default action on this rank.
 
-    backend provides (all on device memory, line windows in GLOBAL indices):
-      rrc(src, dst, w, h, kb); mss_split_rrc(bil, planes_ptr_offset, plane_stride, w, lines, kb4)
-      interband(pan, Lp, prow0, pn, planes, plane_stride, mrow0, mn, W, slices, sections, corr)
-      filter_and_fit(shifts, threshold, min_count); align_src_range(o0, n, cy)
-      align(planes, plane_stride, src_row0, src_rows, dst, out_row0, out_rows, cx, cy)
+    backend provides (all on device memory):
+      rrc(src, dst, w, h, kb); mss_split_rrc(bil, planes, elem_offset, plane_stride, w, lines, kb4)
+      interband_units(pan_windows, band_windows) -> (n, 4, 3)   [2-D views: .data_ptr(), .stride(0)]
+      filter_and_fit(shifts, threshold, min_count, fit); align_src_range(o0, n, cy)
+      align(planes, plane_stride, m_first, mv0, mv1, dst, out_row0, out_rows, cx, cy)
     Returns (cx, cy, (o0, o1)).
     """
     W = plan.W
     multi = plan.world > 1
     # RRC of the rank's own lines, written straight into the halo-capable buffers
-    backend.rrc(raw_pan, bufs.pan_view(bufs.p_first, plan.pb), W, plan.pb, kb_pan)
+    backend.rrc(raw_pan, bufs.pan, W, plan.pb, kb_pan)
     backend.mss_split_rrc(raw_mss_bil, bufs.planes, bufs.own_planes_offset(), bufs.plane_stride, W, plan.mb, kb_mss4)
-    bufs.p_valid = [bufs.p_first, bufs.p_first + plan.pb]
     bufs.m_valid = list(plan.mss_block(rank))
     if multi:
         backend.sync()
-        run_transfers(plan.correlation_transfers(), bufs, rank, group)
-    shifts = backend.interband(bufs.pan, plan.Lp, bufs.p_valid[0], bufs.p_valid[1] - bufs.p_valid[0],
-                               bufs.planes, bufs.plane_stride, bufs.m_first, bufs.m_valid[0], bufs.m_valid[1],
-                               W, plan.slices, plan.sections, plan.corr_lines)
+        run_pieces(plan.correlation_pieces(), bufs, rank, group)
+    mine = plan.units_of(rank)
+    wins = [bufs.unit_windows(u) for u in mine]
+    res = backend.interband_units([w[0] for w in wins], [w[1] for w in wins])
+    shifts = np.full((4, plan.n_units, 4), np.nan)
+    for u in range(plan.n_units):
+        shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2        # preproc.h:326
+    for j, u in enumerate(mine):
+        shifts[:, u, :3] = res[j]
     if multi:
-        shifts = gather_shifts(shifts, bufs.pan.device if bufs.pan.is_cuda else "cpu", group)
-    cx, cy = backend.filter_and_fit(shifts, threshold, min_count)
+        shifts = gather_table(shifts, bufs.pan.device if bufs.pan.is_cuda else "cpu", group)
+    cx, cy = backend.filter_and_fit(shifts, threshold, min_count, fit)
     o0, o1 = plan.align_out_rows(rank)
     if multi:
         transfers, _ = plan.align_transfers(lambda a, n: backend.align_src_range(a, n, cy))
@@ -257,10 +407,171 @@ def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, r
     return cx, cy, (o0, o1)
 
 
-class HipBackend:
-    """adapter from the plan's calls to the C ABI (opticalimageprocessor_amd.Context)"""
+# ------------------------------------------------------------------------------------------------------
+# cross-CCD path: prestitch (CalcSttParameters -> DoRRC -> PreStitch) + RAW stitch, BASELINE config 5
+# ------------------------------------------------------------------------------------------------------
+class CcdPlan:
+    """Row bookkeeping for `prestitch` followed by `stitch` of two CCD segments (main.cpp:270-286, :177-190)."""
 
-    def __init__(self, ctx, plan: StripPlan):
+    def __init__(self, W, L, world, sections=10, lines_per_section=16000, overlap_cols=200, edge_cols=0,
+                 section_rows=30000, row_guard=32767, fold=None):
+        if L % world:
+            raise ValueError("line count must be a multiple of world")
+        # stitcher.h:75-77
+        if L < sections * lines_per_section:
+            raise ValueError("PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)")
+        self.W, self.L, self.world = W, L, world
+        self.pb = L // world
+        self.sections, self.lps = sections, lines_per_section
+        self.ov, self.edge = overlap_cols, edge_cols
+        self.cols = overlap_cols - edge_cols
+        self.section_rows, self.row_guard = section_rows, row_guard
+        self.fold = overlap_cols // 2 if fold is None else fold          # main.cpp:189: --fold-cols is halved
+        # stitcher.h:151-152, :167
+        self.gap = (L - sections * lines_per_section) // (sections + 1)
+        self.step = self.gap + lines_per_section
+        self.n_units = sections
+        self.assign = assign_units([min(self.section(s)[0] // self.pb, world - 1) for s in range(sections)], world)
+
+    def block(self, r):
+        return r * self.pb, (r + 1) * self.pb
+
+    def section(self, s):
+        off = self.gap + s * self.step
+        return off, off + self.lps
+
+    def units_of(self, r):
+        return [u for u in range(self.n_units) if self.assign[u] == r]
+
+    def unit_pieces(self, u):
+        a, b = self.section(u)
+        dst = self.assign[u]
+        # stitcher.h:175-176: PAN1 cols [W-ov, W-edge), PAN2 cols [edge, ov)
+        return (_window_pieces("pan1", u, dst, a, b - a, self.W - self.ov, self.cols, self.pb, self.world) +
+                _window_pieces("pan2", u, dst, a, b - a, self.edge, self.cols, self.pb, self.world))
+
+    def unit_is_local(self, u):
+        return all(p.src == p.dst for p in self.unit_pieces(u))
+
+    def correlation_pieces(self):
+        out = []
+        for u in range(self.n_units):
+            if not self.unit_is_local(u):
+                out += self.unit_pieces(u)
+        return out
+
+    def remap_transfers(self, src_range_fn):
+        """src_range_fn(out_row0, out_rows) -> (first, last) source lines (oip_remap_shift_src_range);
+        returns the line transfers and every rank's needed range"""
+        out, need = [], []
+        for r in range(self.world):
+            b0, b1 = self.block(r)
+            f, l = src_range_fn(b0, b1 - b0)
+            need.append((f, l))
+            for q in range(self.world):
+                if q == r:
+                    continue
+                lo, hi = max(f, q * self.pb), min(l, (q + 1) * self.pb)
+                if lo < hi:
+                    out.append(Transfer(q, r, "pan2", lo, hi - lo))
+        return out, need
+
+
+class CcdBuffers:
+    """raw1/raw2: the rank's own raw lines (inputs, not owned); rrc1: own corrected CCD-1 lines;
+    rrc2: corrected CCD-2 lines [first, ...) incl. the remap halo -- allocated once the shift is known;
+    win: compact windows of sections this rank computes but does not hold entirely"""
+
+    def __init__(self, plan: CcdPlan, rank: int, raw1, raw2):
+        self.plan, self.rank = plan, rank
+        self.pan1, self.pan2 = raw1, raw2
+        dev = raw1.device
+        self.rrc1 = torch.empty_like(raw1)
+        self.rrc2 = None
+        self.r2_first = plan.block(rank)[0]
+        self.win = {}
+        for u in plan.units_of(rank):
+            if not plan.unit_is_local(u):
+                self.win[u] = {"pan1": torch.zeros(plan.lps, plan.cols, dtype=torch.uint16, device=dev),
+                               "pan2": torch.zeros(plan.lps, plan.cols, dtype=torch.uint16, device=dev)}
+
+    def source_views(self, p: Piece):
+        b0 = self.plan.block(self.rank)[0]
+        t = self.pan1 if p.kind == "pan1" else self.pan2
+        return [t[p.row0 - b0:p.row0 - b0 + p.rows, p.col0:p.col0 + p.cols]]
+
+    def window_views(self, p: Piece):
+        return [self.win[p.unit][p.kind][p.dst_row:p.dst_row + p.rows]]
+
+    def unit_windows(self, u):
+        plan = self.plan
+        if u in self.win:
+            return self.win[u]["pan1"], self.win[u]["pan2"]
+        a, b = plan.section(u)
+        b0 = plan.block(self.rank)[0]
+        return (self.pan1[a - b0:b - b0, plan.W - plan.ov:plan.W - plan.edge],
+                self.pan2[a - b0:b - b0, plan.edge:plan.ov])
+
+    def alloc_rrc2(self, first, last):
+        b0, b1 = self.plan.block(self.rank)
+        first, last = min(first, b0), max(last, b1)
+        if self.rrc2 is None or self.r2_first != first or self.rrc2.shape[0] != last - first:
+            self.rrc2 = torch.zeros(last - first, self.plan.W, dtype=torch.uint16, device=self.pan1.device)
+        self.r2_first = first
+
+    def line_views(self, kind, row0, rows):
+        a = row0 - self.r2_first
+        assert 0 <= a and a + rows <= self.rrc2.shape[0], "remap halo exceeds buffer"
+        return [self.rrc2[a:a + rows]]
+
+    def note_valid(self, kind, row0, rows):
+        pass
+
+
+def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, prestt, stitched, rank: int,
+                          threshold=0.4, max_delta_y=0.0, f16acc=False, group=None):
+    """One pass of the sharded cross-CCD path on this rank: CalcSttParameters on the RAW lines (App. B-1) ->
+    RRC of both CCDs -> constant-shift bicubic remap of CCD 2 with row halo -> RAW stitch.
+
+    backend provides:
+      stt_windows(a_windows, b_windows) -> (n, 3);  stt_mean(table, threshold, max_dy) -> (dx, dy, resp, valid)
+      rrc(src, dst, w, h, kb);  remap_src_range(out_row0, out_rows, dy)
+      remap(src, src_row0, src_rows, dst, out_row0, out_rows, dx, dy, f16acc);  stitch(left, right, out, rows)
+    prestt: pb x W (the rank's block of .RRC.PRESTT.RAW); stitched: pb x 2(W - fold).  Returns (dx, dy, table).
+    """
+    W = plan.W
+    multi = plan.world > 1
+    b0, b1 = plan.block(rank)
+    if multi:
+        backend.sync()
+        run_pieces(plan.correlation_pieces(), bufs, rank, group)
+    mine = plan.units_of(rank)
+    wins = [bufs.unit_windows(u) for u in mine]
+    res = backend.stt_windows([w[0] for w in wins], [w[1] for w in wins])
+    table = np.full((plan.sections, 3), np.nan)
+    for j, u in enumerate(mine):
+        table[u] = res[j]
+    if multi:
+        table = gather_table(table, bufs.pan1.device if bufs.pan1.is_cuda else "cpu", group)
+    dx, dy, _, _ = backend.stt_mean(table, threshold, max_delta_y)       # identical on every rank
+    # DoRRC (stitcher.h:141-146): own lines of both CCDs; CCD 2 lands in the halo-capable buffer
+    backend.rrc(bufs.pan1, bufs.rrc1, W, plan.pb, kb1)
+    transfers, need = plan.remap_transfers(lambda a, n: backend.remap_src_range(a, n, dy))
+    f, l = need[rank]
+    bufs.alloc_rrc2(f, l)
+    backend.rrc(bufs.pan2, bufs.rrc2[b0 - bufs.r2_first:b1 - bufs.r2_first], W, plan.pb, kb2)
+    if multi:
+        backend.sync()
+        run_transfers(transfers, bufs, rank, group)
+    backend.remap(bufs.rrc2, bufs.r2_first, bufs.rrc2.shape[0], prestt, b0, plan.pb, dx, dy, f16acc)
+    backend.stitch(bufs.rrc1, prestt, stitched, plan.pb)
+    return dx, dy, table
+
+
+class HipBackend:
+    """adapter from the plans' calls to the C ABI (opticalimageprocessor_amd.Context)"""
+
+    def __init__(self, ctx, plan):
         self.ctx, self.plan = ctx, plan
 
     def sync(self):
@@ -272,16 +583,25 @@ class HipBackend:
     def mss_split_rrc(self, bil, planes, elem_offset, plane_stride, w, lines, kb4):
         self.ctx.mss_split_rrc_u16(bil, planes.data_ptr() + 2 * elem_offset, plane_stride, w, lines, kb4)
 
-    def interband(self, pan, Lp, p0, pn, planes, plane_stride, m_first, mv0, mv1, W, slices, sections, corr):
-        Wb = W // 4
-        base = planes.data_ptr() + 2 * (mv0 - m_first) * Wb
-        pan_base = pan.data_ptr()      # buffer row 0 == global line p0 (own block start)
-        return self.ctx.interband_correlate(pan_base, Lp, p0, pn, base, plane_stride, mv0, mv1 - mv0, W, slices,
-                                            sections, corr)
+    def interband_units(self, pan_wins, band_wins):
+        p = self.plan
+        return self.ctx.interband_correlate_units([w.data_ptr() for w in pan_wins], [w.stride(0) for w in pan_wins],
+                                                  [[b.data_ptr() for b in u] for u in band_wins],
+                                                  [u[0].stride(0) for u in band_wins], p.base_rows, p.base_cols)
 
-    def filter_and_fit(self, shifts, threshold, min_count):
+    def stt_windows(self, a_wins, b_wins):
+        p = self.plan
+        return self.ctx.stt_correlate_windows([w.data_ptr() for w in a_wins], [w.stride(0) for w in a_wins],
+                                              [w.data_ptr() for w in b_wins], [w.stride(0) for w in b_wins],
+                                              p.lps, p.cols)
+
+    def stt_mean(self, table, threshold, max_dy):
+        from .capi import stt_mean
+        return stt_mean(table, threshold, max_dy)
+
+    def filter_and_fit(self, shifts, threshold, min_count, fit="reference"):
         from .capi import filter_and_fit
-        return filter_and_fit(shifts, threshold, min_count)
+        return filter_and_fit(shifts, threshold, min_count, fit)
 
     def align_src_range(self, o0, n, cy):
         from .capi import align_mss_src_range
@@ -295,3 +615,18 @@ class HipBackend:
         self.ctx.align_mss_bicubic_u16x4(base, plane_stride, out, Wb, p.Lm, cx, cy, p.lps, p.line_offset, p.overlap,
                                          p.keep, p.min_lines, src_row0=mv0, src_rows=mv1 - mv0, out_row0=o0,
                                          out_rows=n)
+
+    def remap_src_range(self, out_row0, out_rows, dy):
+        from .capi import remap_shift_src_range
+        p = self.plan
+        if p.L <= p.row_guard:
+            raise ValueError("too few data rows, please use cv::remap()")        # imageop.h:242-244
+        return remap_shift_src_range(out_row0, out_rows, p.L, dy, p.section_rows)
+
+    def remap(self, src, src_row0, src_rows, dst, out_row0, out_rows, dx, dy, f16acc):
+        p = self.plan
+        self.ctx.remap_shift_bicubic_u16(src, dst, p.W, p.L, dx, dy, p.section_rows, p.row_guard, src_row0=src_row0,
+                                         src_rows=src_rows, out_row0=out_row0, out_rows=out_rows, f16acc=f16acc)
+
+    def stitch(self, left, right, out, rows):
+        self.ctx.stitch_rows_u16(left, right, out, self.plan.W, rows, self.plan.fold)

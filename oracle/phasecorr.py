@@ -169,15 +169,19 @@ def calc_interband_correlation(pan: np.ndarray, bands, slices=10, sections=5, co
     return out
 
 
-def filter_and_fit(shifts: np.ndarray, threshold=0.4, min_count=5, method="lstsq"):
+def filter_and_fit(shifts: np.ndarray, threshold=0.4, min_count=5, method="numcpp"):
     """FilterInterBandShiftValues + DoCorrelationPolynomialFitting, preproc.h:492-550.
     Returns (cx[4][2], cy[4][3]) ascending coefficients.
 
+    method="numcpp" (the product's default, OIP_FIT_REFERENCE): NumCpp Poly1d::fit as the
+    reference calls it (preproc.h:535-536), restated operation by operation -- inv(A^T A) A^T y
+    on the raw Vandermonde matrix with NumCpp's own Gauss-Jordan inv().  At W=12288..30000
+    cond(A^T A) ~ 1e16..1e18, so the low digits of the result belong to that operation order.
     method="lstsq": the exact least-squares solution (SVD on a centred/scaled abscissa,
-    coefficients mapped back) -- what the product implements.
-    method="normal": NumCpp Poly1d::fit as recalled -- inv(A^T A) A^T y on the raw
-    Vandermonde matrix.  At W=12288..30000 cond(A^T A) ~ 1e16..1e18, so its low digits depend
-    on NumCpp's own inv(); it is kept only to show how far the two can differ.
+    coefficients mapped back) -- the product's `--fit lstsq`.
+    method="normal": the same normal equations through numpy.linalg.inv (LAPACK) -- a third
+    opinion showing how far inverses of this matrix differ.
+    NumCpp is un-vendored and unpinned (CMakeLists.txt:9): PARITY UNPINNED.
     """
     cxs = np.zeros((4, 2)); cys = np.zeros((4, 3))
     for b in range(4):
@@ -191,8 +195,72 @@ def filter_and_fit(shifts: np.ndarray, threshold=0.4, min_count=5, method="lstsq
     return cxs, cys
 
 
-def polyfit(x, y, deg, method="lstsq"):
+def _numcpp_inv(G):
+    """nc::linalg::inv as recalled: one sweep per diagonal element, no pivoting (the zero-diagonal
+    row swap never triggers for A^T A of distinct abscissae).  Plain Python floats: the same IEEE
+    double operations in the same order as the product's C++."""
+    m = len(G)
+    G = [list(map(float, r)) for r in G]
+    R = [[0.0] * m for _ in range(m)]
+    for k in range(m):
+        if G[k][k] == 0.0:
+            raise ZeroDivisionError("singular normal equations")
+        R[k][k] = -1.0 / G[k][k]
+        for i in range(m):
+            for j in range(m):
+                if i != k and j != k:
+                    R[i][j] = G[i][j] + G[k][j] * G[i][k] * R[k][k]
+                elif i != k and j == k:
+                    R[i][k] = G[i][k] * R[k][k]
+                elif i == k and j != k:
+                    R[k][j] = G[k][j] * R[k][k]
+        G = [r[:] for r in R]
+    return [[v * -1.0 for v in r] for r in R]
+
+
+def polyfit_numcpp(x, y, deg):
+    """nc::polynomial::Poly1d<double>::fit (NumCpp, as recalled; call sites preproc.h:535-536)"""
+    x = [float(v) for v in x]; y = [float(v) for v in y]
+    n, m = len(x), deg + 1
+    A = []
+    for xi in x:
+        row = []
+        for j in range(m):
+            v = 1.0
+            if j > 0:
+                v = xi
+                for _ in range(1, j):
+                    v *= xi
+            row.append(v)
+        A.append(row)
+    G = [[0.0] * m for _ in range(m)]
+    for i in range(m):
+        for j in range(m):
+            acc = 0.0
+            for k in range(n):
+                acc = acc + A[k][i] * A[k][j]
+            G[i][j] = acc
+    R = _numcpp_inv(G)
+    P = [[0.0] * n for _ in range(m)]
+    for i in range(m):
+        for c in range(n):
+            acc = 0.0
+            for k in range(m):
+                acc = acc + R[i][k] * A[c][k]
+            P[i][c] = acc
+    out = []
+    for i in range(m):
+        acc = 0.0
+        for c in range(n):
+            acc = acc + P[i][c] * y[c]
+        out.append(acc)
+    return np.array(out)
+
+
+def polyfit(x, y, deg, method="numcpp"):
     x = np.asarray(x, np.float64); y = np.asarray(y, np.float64)
+    if method == "numcpp":
+        return polyfit_numcpp(x, y, deg)
     if method == "normal":
         A = np.vander(x, deg + 1, increasing=True)
         return np.linalg.inv(A.T @ A) @ A.T @ y

@@ -1,12 +1,17 @@
 """CPU stand-in for the HIP backend of opticalimageprocessor_amd.dist, built on the oracle.
-TESTS ONLY: lets the gloo world_size>1 tests exercise the row planning, halo exchange and
-all-gather of the sharded default action without a GPU."""
+TESTS ONLY: lets the gloo world_size>1 tests exercise the row planning, window / halo exchange and
+all-gather of the sharded work-flows without a GPU."""
 import numpy as np
 import torch
 
 import opticalimageprocessor_amd as oip
 import oracle
 from oracle import phasecorr as pc
+
+
+def _np16(t):
+    """a (possibly strided) uint16 tensor view as a contiguous numpy array"""
+    return np.ascontiguousarray(t.contiguous().numpy())
 
 
 class OracleBackend:
@@ -26,29 +31,29 @@ class OracleBackend:
         for b in range(4):
             planes[b, r0:r0 + lines] = torch.from_numpy(oracle.rrc(bands[b], kb4[b * bw:(b + 1) * bw]))
 
-    def interband(self, pan, Lp, p0, pn, planes, plane_stride, m_first, mv0, mv1, W, slices, sections, corr):
+    def interband_units(self, pan_wins, band_wins):
         p = self.plan
-        out = np.full((4, slices * sections, 4), np.nan)
-        base_cols = W // slices
-        band_cols = base_cols // 4
-        pan_np = pan.numpy()
-        for sec in range(sections):
-            a0, a1, b0, b1 = p.section(sec)
-            for i in range(slices):
-                out[:, sec * slices + i, 3] = i * base_cols + base_cols // 2
-            if a0 < p0 or a1 > p0 + pn or b0 < mv0 or b1 > mv1:
-                continue
-            for i in range(slices):
-                base = oracle.window_u16_to_f32(pan_np, a0 - p0, i * base_cols, a1 - a0, base_cols)
-                for b in range(4):
-                    bs = oracle.window_u16_to_f32(planes[b].numpy(), b0 - m_first, i * band_cols, b1 - b0, band_cols)
-                    up = oracle.resize_cubic(bs, base_cols, a1 - a0)
-                    (dx, dy), rs = pc.phase_correlate(base, up)
-                    out[b, sec * slices + i, :3] = (dx, dy, rs)
+        out = np.zeros((len(pan_wins), 4, 3))
+        for j, (pw, bws) in enumerate(zip(pan_wins, band_wins)):
+            base = _np16(pw).astype(np.float32)
+            for b in range(4):
+                up = oracle.resize_cubic(_np16(bws[b]).astype(np.float32), p.base_cols, p.base_rows)
+                (dx, dy), rs = pc.phase_correlate(base, up)
+                out[j, b] = (dx, dy, rs)
         return out
 
-    def filter_and_fit(self, shifts, threshold, min_count):
-        return oip.filter_and_fit(shifts, threshold, min_count)     # product host code (no GPU needed)
+    def stt_windows(self, a_wins, b_wins):
+        out = np.zeros((len(a_wins), 3))
+        for j, (a, b) in enumerate(zip(a_wins, b_wins)):
+            (dx, dy), rs = pc.phase_correlate(_np16(a).astype(np.float32), _np16(b).astype(np.float32))
+            out[j] = (dx, dy, rs)
+        return out
+
+    def stt_mean(self, table, threshold, max_dy):
+        return oip.stt_mean(table, threshold, max_dy)                   # product host code (no GPU needed)
+
+    def filter_and_fit(self, shifts, threshold, min_count, fit="reference"):
+        return oip.filter_and_fit(shifts, threshold, min_count, fit)    # product host code (no GPU needed)
 
     def align_src_range(self, o0, n, cy):
         p = self.plan
@@ -62,3 +67,19 @@ class OracleBackend:
             full[b][mv0:mv1] = planes[b, mv0 - m_first:mv1 - m_first].numpy()
         res, _ = oracle.align_mss(full, cx, cy, p.lps, p.line_offset, p.overlap, p.keep, p.min_lines)
         out[:n] = torch.from_numpy(res[o0:o0 + n])
+
+    def remap_src_range(self, out_row0, out_rows, dy):
+        p = self.plan
+        return oip.remap_shift_src_range(out_row0, out_rows, p.L, dy, p.section_rows)
+
+    def remap(self, src, src_row0, src_rows, dst, out_row0, out_rows, dx, dy, f16acc):
+        # the whole-strip restatement on a raster that holds ONLY the lines this rank has: if the halo
+        # range were too small, the missing lines (zeros) would change the rank's output rows
+        p = self.plan
+        full = np.zeros((p.L, p.W), np.uint16)
+        full[src_row0:src_row0 + src_rows] = src.numpy()
+        res, _ = oracle.prestitch(full, dx, dy, p.section_rows, p.row_guard)
+        dst[:out_rows] = torch.from_numpy(res[out_row0:out_row0 + out_rows])
+
+    def stitch(self, left, right, out, rows):
+        out.copy_(torch.from_numpy(oracle.stitch_raw(left.numpy(), right.numpy(), self.plan.fold)))

@@ -47,7 +47,8 @@ def _run_rank(rank, world, port, tmp):
     cx, cy, rows = default_action_step(OracleBackend(plan), plan, bufs, raw_pan, raw_mss, kb, kb4, out, rank,
                                        threshold=THR)
     np.savez(os.path.join(tmp, "w%d_r%d.npz" % (world, rank)), out=out.numpy(), cx=cx, cy=cy, rows=np.array(rows),
-             tail=plan.pan_tail(rank))
+             remote=np.array([u for u in plan.units_of(rank) if not plan.unit_is_local(u)]),
+             mine=np.array(plan.units_of(rank)))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -64,8 +65,10 @@ def test_two_rank_shards_equal_single_process(tmp_path):
     mp.spawn(_run_rank, args=(2, _free_port(), tmp), nprocs=2, join=True)
     one = np.load(os.path.join(tmp, "w1_r0.npz"))
     parts = [np.load(os.path.join(tmp, "w2_r%d.npz" % r)) for r in range(2)]
-    # a correlation section straddles the block boundary: rank 0 had to receive PAN lines
-    assert int(parts[0]["tail"]) > 0
+    # a correlation section straddles the block boundary: its units were computed from received windows,
+    # and both ranks computed units
+    assert sum(len(p["remote"]) for p in parts) > 0
+    assert all(len(p["mine"]) > 0 for p in parts)
     # every rank fitted the same polynomials as the single process, bit for bit
     for p in parts:
         assert np.array_equal(p["cx"], one["cx"]) and np.array_equal(p["cy"], one["cy"])
@@ -75,6 +78,115 @@ def test_two_rank_shards_equal_single_process(tmp_path):
     assert np.array_equal(whole, one["out"])
 
 
+# ---- cross-CCD path (BASELINE config 5): prestitch + stitch over 2 ranks ----------------------------
+CW, CL, COV, CSEC, CLPS = 256, 4800, 40, 3, 1200
+CSR, CGUARD = 700, 800          # remap section rows / row guard scaled down with the strip
+
+
+def _run_ccd_rank(rank, world, port, tmp, shift):
+    sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from opticalimageprocessor_amd import synth
+    from opticalimageprocessor_amd.dist import CcdBuffers, CcdPlan, prestitch_stitch_step
+    from _oracle_backend import OracleBackend
+    kb1, kb2 = synth.lut(CW, 1), synth.lut(CW, 2)
+    plan = CcdPlan(CW, CL, world, CSEC, CLPS, COV, 0, CSR, CGUARD)
+    b0, b1 = plan.block(rank)
+    raw1, raw2 = synth.ccd_pair(64 + b0, plan.pb, CW, COV, kb1, kb2, device="cpu", shift=shift)
+    bufs = CcdBuffers(plan, rank, raw1, raw2)
+    prestt = torch.zeros(plan.pb, CW, dtype=torch.uint16)
+    stitched = torch.zeros(plan.pb, 2 * (CW - plan.fold), dtype=torch.uint16)
+    dx, dy, table = prestitch_stitch_step(OracleBackend(plan), plan, bufs, kb1, kb2, prestt, stitched, rank,
+                                          threshold=-1.0, group=None)
+    np.savez(os.path.join(tmp, "c%d_r%d.npz" % (world, rank)), prestt=prestt.numpy(), stitched=stitched.numpy(),
+             shift=np.array([dx, dy]), table=table, halo=np.array([bufs.r2_first, bufs.rrc2.shape[0]]),
+             remote=np.array([u for u in plan.units_of(rank) if not plan.unit_is_local(u)]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shift", [(3, -2), (-2, 3)])
+def test_two_rank_prestitch_stitch_equals_single_process(tmp_path, shift):
+    """stitcher.h:83-201 + imageop.h:340-351 sharded by scan-line block: section windows gathered across the
+    block boundary, all-gathered table -> identical in-order mean, remap with row halo (both signs of dy: the
+    halo is above or below the block), stitch.  Bit-equal to one process."""
+    tmp = str(tmp_path)
+    _run_ccd_rank(0, 1, _free_port(), tmp, shift)
+    mp.spawn(_run_ccd_rank, args=(2, _free_port(), tmp, shift), nprocs=2, join=True)
+    one = np.load(os.path.join(tmp, "c1_r0.npz"))
+    parts = [np.load(os.path.join(tmp, "c2_r%d.npz" % r)) for r in range(2)]
+    assert sum(len(p["remote"]) for p in parts) == 1          # the middle section straddles the boundary
+    for p in parts:
+        assert np.array_equal(p["table"], one["table"]) and np.array_equal(p["shift"], one["shift"])
+    # the shift was found (synthetic truth) and at least one rank needed halo lines of the other
+    assert abs(one["shift"][0] - shift[0]) < 0.3 and abs(one["shift"][1] - shift[1]) < 0.3
+    assert any(int(p["halo"][1]) > CL // 2 for p in parts)
+    assert np.array_equal(np.concatenate([p["prestt"] for p in parts], 0), one["prestt"])
+    assert np.array_equal(np.concatenate([p["stitched"] for p in parts], 0), one["stitched"])
+
+
+def test_unit_assignment_balances_and_prefers_local():
+    from opticalimageprocessor_amd.dist import CcdPlan, StripPlan, assign_units
+    # BASELINE config 4: 30000 x 524288 on 8 ranks, the reference's 5 sections for the WHOLE strip
+    plan = StripPlan(30000, 524288, 8)
+    assert plan.pb == 65536 and plan.n_units == 50
+    load = [len(plan.units_of(r)) for r in range(8)]
+    assert sum(load) == 50 and max(load) == 8 and min(load) >= 2           # 25 pairs over 8 ranks: at most 4 pairs
+    assert all(len(plan.units_of(r)) % 2 == 0 for r in range(8))           # pairs stay together
+    homes = [plan.owner(s) for s in range(5)]
+    local = sum(plan.unit_is_local(u) for u in range(50))
+    assert local >= 30                                                     # most units never move
+    for u in range(50):
+        if plan.unit_is_local(u):
+            assert plan.assign[u] == homes[u // 10]
+    moved = [p for p in plan.correlation_pieces() if p.src != p.dst]
+    assert moved and all(p.rows > 0 and p.cols in (3000, 750) for p in moved)
+    # every unit's pieces tile its windows exactly
+    for u in range(50):
+        pan = sorted((p.dst_row, p.rows) for p in plan.unit_pieces(u) if p.kind == "pan")
+        assert pan[0][0] == 0 and sum(r for _, r in pan) == 16000
+        assert all(pan[i][0] + pan[i][1] == pan[i + 1][0] for i in range(len(pan) - 1))
+    # BASELINE config 5: two 30000 x 262144 segments on 8 ranks, 10 sections of 16000 lines
+    ccd = CcdPlan(30000, 262144, 8)
+    assert ccd.pb == 32768 and ccd.gap == (262144 - 160000) // 11
+    load = [len(ccd.units_of(r)) for r in range(8)]
+    assert sum(load) == 10 and max(load) == 2
+    assert sum(not ccd.unit_is_local(u) for u in range(10)) >= 3           # sections straddle the 32768-line blocks
+    for u in range(10):
+        a = sorted((p.dst_row, p.rows) for p in ccd.unit_pieces(u) if p.kind == "pan1")
+        assert a[0][0] == 0 and sum(r for _, r in a) == 16000
+    # weak-scaling variant (5 N sections): everything is local, nothing moves
+    for world in (2, 4, 8):
+        w = StripPlan(30000, 100000 * world, world, 10, 5 * world)
+        assert all(w.unit_is_local(u) for u in range(w.n_units)) and w.correlation_pieces() == []
+        assert [len(w.units_of(r)) for r in range(world)] == [50] * world
+    assert assign_units([0, 0, 0, 0], 2) == [0, 0, 1, 1]
+
+
+def test_remap_halo_plan_at_config5():
+    """rows each rank must receive for the constant-shift remap at 30000 x 262144 / 8 ranks (host arithmetic)"""
+    from opticalimageprocessor_amd.dist import CcdPlan
+    plan = CcdPlan(30000, 262144, 8)
+    for dy in (-1.62, 2.4):
+        tr, need = plan.remap_transfers(lambda a, n: oip_range(a, n, plan.L, dy))
+        for r, (f, l) in enumerate(need):
+            b0, b1 = plan.block(r)
+            assert f <= b0 + 8 and l >= b1 - 8 and f >= 0 and l <= plan.L
+            if dy < 0 and r > 0:
+                assert f < b0                      # taps reach above the block
+        assert all(t.src != t.dst and t.rows > 0 for t in tr)
+        # interior ranks exchange only a handful of lines with a neighbour
+        assert all(t.rows <= 8 for t in tr if abs(t.src - t.dst) == 1 and t.dst < 7)
+
+
+def oip_range(a, n, L, dy):
+    import opticalimageprocessor_amd as oip
+    return oip.remap_shift_src_range(a, n, L, dy, 30000)
+
+
 def test_plan_geometry():
     from opticalimageprocessor_amd.dist import StripPlan
     plan = StripPlan(30000, 800000, 8)
@@ -82,6 +194,9 @@ def test_plan_geometry():
     assert plan.base_gap == 120000 and plan.section(0)[:2] == (120000, 136000)
     owners = [plan.owner(s) for s in range(5)]
     assert owners == [1, 2, 3, 5, 6]
+    # ... but the 50 units are spread: no rank computes more than 4 pairs, none idles
+    assert sorted(len(plan.units_of(r)) for r in range(8)) == [2, 4, 4, 8, 8, 8, 8, 8] or \
+        max(len(plan.units_of(r)) for r in range(8)) == 8
     covered = []
     for r in range(8):
         o0, o1 = plan.align_out_rows(r)
@@ -101,11 +216,9 @@ def test_weak_scaling_plan_keeps_per_rank_work_fixed(world):
     plan = StripPlan(30000, 100000 * world, world, 10, 5 * world)
     owners = [plan.owner(s) for s in range(plan.sections)]
     assert [owners.count(r) for r in range(world)] == [5] * world
-    assert plan.correlation_transfers() == []
-    assert all(plan.pan_tail(r) == 0 for r in range(world))
+    assert plan.correlation_pieces() == []
+    assert [len(plan.units_of(r)) for r in range(world)] == [50] * world
     # the aligned image is covered once, in order
     rows = [plan.align_out_rows(r) for r in range(world)]
     assert rows[0][0] == 0 and rows[-1][1] == plan.out_rows
     assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
-    # the results of all sections fit the library's result buffer (64 KiB of doubles, 12 per unit)
-    assert plan.slices * plan.sections * 12 * 8 <= 65536

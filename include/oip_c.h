@@ -147,7 +147,9 @@ int oip_interband_correlate(oip_ctx *ctx, const uint16_t *d_pan, long Lp, long p
  * window of rows x cols u16 at d_pan[u] (pitch pan_pitch[u]) and the four band windows of (rows/4) x
  * (cols/4) u16 at d_bands[4*u + b] (pitch band_pitch[u]).  out[12*u + 3*b + {0,1,2}] = dx, dy, rs of band
  * b.  Lets a multi-GPU host hand any unit to any rank (a unit needs 96 MB + 4 x 6 MB of windows at the
- * 30000-wide geometry); units are processed two at a time. */
+ * 30000-wide geometry).  Units are processed two at a time (2u, 2u+1 share transforms), so the last
+ * digits of a unit's result (~1e-6 px) depend on its partner: a host that wants the bits of the
+ * single-GPU run keeps the pairs of oip_interband_correlate's order (section-major, slices in order). */
 int oip_interband_correlate_units(oip_ctx *ctx, const uint16_t *const *d_pan, const size_t *pan_pitch,
                                   const uint16_t *const *d_bands, const size_t *band_pitch, int n, int rows,
                                   int cols, double *out);
@@ -184,8 +186,9 @@ int oip_remap_shift_bicubic_u16(oip_ctx *ctx, const uint16_t *d_src, long src_ro
                                 int W, long L, double dx, double dy, int section_rows,
                                 int row_guard);
 /* The same call with the 16-tap sums of the regular interior pixels accumulated in packed fp16 (BASELINE
- * config 5: "fp16 accumulate (tolerance stated)").  NOT the parity mode: |result - fp32 result| <= 4 DN on
- * 12-bit data (measured max 4), <= 4 + max(sample)/256 DN in general; data above 15 bits overflows fp16.
+ * config 5: "fp16 accumulate (tolerance stated)").  NOT the parity mode: |result - fp32 result| <= 6 DN on
+ * 12-bit data (measured: max 5, mean 0.25 DN, 20-25 % of the pixels differ), <= 6 + max|sample - 2048|/64
+ * DN in general; samples enter as (sample - 2048), so the mode is specified for data up to 15 bits.
  * Geometry, 1/32-px phases, section borders and the irregular columns are identical (and computed in
  * f32); widths that are not a multiple of 8 fall back to the fp32 kernel altogether. */
 int oip_remap_shift_bicubic_u16_f16acc(oip_ctx *ctx, const uint16_t *d_src, long src_row0,

@@ -180,20 +180,27 @@ __host__ __device__ inline bool shift_group_regular(int x0, int W, double dx, in
     return regular && ix0 >= 0 && ix0 + 10 < W;      // every tap of every pixel inside the image in x
 }
 
-__device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
-                                                float g[11])
+// One source line of a lane = 11 consecutive u16 = 6 dwords from a 4-byte aligned address.  The load is split
+// from its use: the raw dwords of the NEXT output line's new source line are requested before the current
+// line's 16-tap sums, so twice the bytes are in flight per wave (these kernels are bound by memory-level
+// parallelism: 1 KiB per wave and line, 16-24 waves per CU, against ~35 KiB per CU that the latency-bandwidth
+// product of HBM asks for).
+__device__ __forceinline__ void load_raw6(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem, uint32_t w[6])
 {
     // c0: source column of tap 0 of pixel 0 (>= 0).  6 dwords from the dword holding it.
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
     const long e0 = (long)row * W + c0;           // W even: parity of e0 == parity of c0
     const long d0 = e0 >> 1;
     const long dmax = (nelem - 1) >> 1;
-    uint32_t w[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         long di = d0 + i;
         w[i] = p32[di > dmax ? dmax : di];
     }
+}
+
+__device__ __forceinline__ void expand_f32(const uint32_t w[6], int c0, float g[11])
+{
     if (c0 & 1) {
 #pragma unroll
         for (int q = 0; q < 11; ++q) g[q] = ((q + 1) & 1) ? (float)(w[(q + 1) >> 1] >> 16) : (float)(w[(q + 1) >> 1] & 0xffffu);
@@ -201,6 +208,14 @@ __device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src
 #pragma unroll
         for (int q = 0; q < 11; ++q) g[q] = (q & 1) ? (float)(w[q >> 1] >> 16) : (float)(w[q >> 1] & 0xffffu);
     }
+}
+
+__device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
+                                                float g[11])
+{
+    uint32_t w[6];
+    load_raw6(src, row, W, c0, nelem, w);
+    expand_f32(w, c0, g);
 }
 
 __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
@@ -223,6 +238,8 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
     float w2d[16];
     int cur1 = -2, cur2 = -2, cur3 = -2;
     int cur_fy = -1;
+    uint32_t nraw[6] = {0u, 0u, 0u, 0u, 0u, 0u};  // raw dwords of source line `nline`, requested one output line ahead
+    int nline = -2;
     for (long rb = r0; rb < r1; rb += 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -232,12 +249,19 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
             if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B
             const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
             if (slide) {
-                load_src_line11(src, ri.src[3], W, c0, src_elems, win[(k + 3) & 3]);
+                if (ri.src[3] == nline) expand_f32(nraw, c0, win[(k + 3) & 3]);
+                else load_src_line11(src, ri.src[3], W, c0, src_elems, win[(k + 3) & 3]);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) load_src_line11(src, ri.src[t], W, c0, src_elems, win[(k + t) & 3]);
             }
             cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+            // the line the next output line will add in the regular case (its taps one line further down)
+            nline = -2;
+            if (r + 1 < r1 && (long)(ri.src[3] + 1) * W < src_elems) {
+                nline = ri.src[3] + 1;
+                load_raw6(src, nline, W, c0, src_elems, nraw);
+            }
             if (ri.fy != cur_fy) {
                 cur_fy = ri.fy;
 #pragma unroll
@@ -273,13 +297,14 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
 // Same geometry, phases, tap positions and border rules as remap_shift8_kernel; only the 16-tap sum of
 // the regular interior pixels changes: samples and the sixteen 2-D weights are rounded to fp16 and the sum
 // is a chain of packed fp16 FMAs (v_pk_fma_f16: two output pixels per instruction, 16 instructions per
-// pixel pair instead of 62 unfused f32 operations).  NOT the parity mode: fp16 carries 11 significant bits,
-// so 12-bit data above 2047 DN is already quantised to even values on the way in and the running sum rounds
-// to 2 DN steps above 2048 (4 DN above 4096, ...).  Measured against the f32 kernel on the 12-bit synthetic
-// strips: max |delta| 4 DN (tests/test_gpu_resample.py::test_remap_f16acc_tolerance); the
-// bound asserted for arbitrary data is |delta| <= 4 + max(sample) / 256.  Samples above 65504 overflow fp16: the
-// mode is specified for data up to 15 bits.  Irregular column groups and section-border lines still go
-// through the f32 fix-up kernels.
+// pixel pair instead of 62 unfused f32 operations).  NOT the parity mode: fp16 carries 11 significant bits.
+// Samples enter as (sample - 2048) -- exact integers for 12-bit data -- and the running sum of 16 products
+// rounds to 0.5..2 DN steps depending on its magnitude.  Measured against the f32 kernel on the 12-bit
+// synthetic strips: tests/test_gpu_config5.py::test_remap_f16acc_tolerance prints max and mean |delta|
+// (DESIGN.md section 4.2 records them: max 5, mean 0.25 DN); the bound asserted for arbitrary data is
+// |delta| <= 6 + max|sample - 2048| / 64.  The mode is specified for data up to 15 bits (the biased
+// sample must fit int16).  Irregular column groups and section-border lines still go through the f32
+// fix-up kernels.
 typedef _Float16 oip_h2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ oip_h2 h2_from_u16pair(uint32_t w)
@@ -296,20 +321,23 @@ __device__ __forceinline__ oip_h2 h2_shift(oip_h2 a, oip_h2 b)
     return __builtin_bit_cast(oip_h2, __builtin_amdgcn_alignbit(ub, ua, 16));
 }
 
-// one source line as packed fp16 pairs: E[i] = (g[2i], g[2i+1]), O[i] = (g[2i+1], g[2i+2]), g[q] = sample c0 + q
-__device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
-                                                  oip_h2 E[6], oip_h2 O[5])
+// one source line as packed fp16 pairs of (sample - kF16Bias): E[i] = (g[2i], g[2i+1]), O[i] = (g[2i+1], g[2i+2]),
+// g[q] = sample c0 + q.  The bias is taken off in 16-bit integer arithmetic (exact), so 12-bit data enters fp16
+// as integers in [-2048, 2047] -- all exactly representable -- and the partial sums stay small; the bicubic
+// weights sum to one, so the bias is added back to the finished sum.
+constexpr int kF16Bias = 2048;
+__device__ __forceinline__ oip_h2 h2_from_biased_pair(uint32_t w)
 {
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
-    const long e0 = (long)row * W + c0;
-    const long d0 = e0 >> 1;
-    const long dmax = (nelem - 1) >> 1;
+    oip_h2 r;
+    r.x = (_Float16)(short)((w & 0xffffu) - kF16Bias);
+    r.y = (_Float16)(short)((w >> 16) - kF16Bias);
+    return r;
+}
+__device__ __forceinline__ void expand_h(const uint32_t w[6], int c0, oip_h2 E[6], oip_h2 O[5])
+{
     oip_h2 H[6], S[5];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        long di = d0 + i;
-        H[i] = h2_from_u16pair(p32[di > dmax ? dmax : di]);
-    }
+    for (int i = 0; i < 6; ++i) H[i] = h2_from_biased_pair(w[i]);
 #pragma unroll
     for (int i = 0; i < 5; ++i) S[i] = h2_shift(H[i], H[i + 1]);
     const bool odd = c0 & 1;
@@ -319,6 +347,13 @@ __device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ s
         O[i] = odd ? H[i + 1] : S[i];
     }
     E[5] = H[5];        // only its first half is ever used (sample 10), and only for even c0; odd c0 never reads E[5]
+}
+__device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
+                                                  oip_h2 E[6], oip_h2 O[5])
+{
+    uint32_t w[6];
+    load_raw6(src, row, W, c0, nelem, w);
+    expand_h(w, c0, E, O);
 }
 
 __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
@@ -341,6 +376,8 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
     oip_h2 w2d[16];
     int cur1 = -2, cur2 = -2, cur3 = -2;
     int cur_fy = -1;
+    uint32_t nraw[6] = {0u, 0u, 0u, 0u, 0u, 0u};  // one-line lookahead, as in remap_shift8_kernel
+    int nline = -2;
     for (long rb = r0; rb < r1; rb += 4) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -350,12 +387,18 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
             if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B (f32)
             const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
             if (slide) {
-                load_src_line11_h(src, ri.src[3], W, c0, src_elems, E[(k + 3) & 3], O[(k + 3) & 3]);
+                if (ri.src[3] == nline) expand_h(nraw, c0, E[(k + 3) & 3], O[(k + 3) & 3]);
+                else load_src_line11_h(src, ri.src[3], W, c0, src_elems, E[(k + 3) & 3], O[(k + 3) & 3]);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) load_src_line11_h(src, ri.src[t], W, c0, src_elems, E[(k + t) & 3], O[(k + t) & 3]);
             }
             cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+            nline = -2;
+            if (r + 1 < r1 && (long)(ri.src[3] + 1) * W < src_elems) {
+                nline = ri.src[3] + 1;
+                load_raw6(src, nline, W, c0, src_elems, nraw);
+            }
             if (ri.fy != cur_fy) {
                 cur_fy = ri.fy;
 #pragma unroll
@@ -381,9 +424,9 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
                     acc = __builtin_elementwise_fma(Et[p + 1], w2d[t * 4 + 2], acc);
                     acc = __builtin_elementwise_fma(Ot[p + 1], w2d[t * 4 + 3], acc);
                 }
-                // clamp before the conversion: inf -> 65535, NaN -> 0 (fmaxf returns the non-NaN operand)
-                out[2 * p] = oip_sat_u16(fminf(fmaxf((float)acc.x, 0.f), 65535.f));
-                out[2 * p + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y, 0.f), 65535.f));
+                // bias back in f32; clamp before the conversion: inf -> 65535, NaN -> 0 (fmaxf returns the non-NaN operand)
+                out[2 * p] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
+                out[2 * p + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
             }
             uint4 o;
             o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);

@@ -49,13 +49,10 @@ __global__ void align_rows_kernel(AlignRow *rows, OipAlignGeom g, long out_row0,
     rows[r] = a;
 }
 
-// One lane = one (output column, band): lane 16b+p of a wave handles pixel p, band b, so a wave
-// writes 128 contiguous bytes of the interleaved 16UC4 line (as 2-byte stores 8 bytes apart per
-// 16-lane group) and keeps a single 4x4 source window per lane (~50 VGPRs instead of ~190 for four
-// bands per lane: 8 waves/SIMD instead of 2).
-// For a fixed column the first tap line iy advances by exactly one per output line except where
-// the f32 rounding of mapY flips (rare) or a section seam restarts the section-relative line,
-// so the window normally loads only the newest source line (4 taps per pixel instead of 16).
+// ---- general path: one lane = one (output column, band), any geometry, every border case ------------------
+// For a fixed column the first tap line iy advances by exactly one per output line except where the f32
+// rounding of mapY flips (rare) or a section seam restarts the section-relative line, so the window
+// normally loads only the newest source line (4 taps per pixel instead of 16).
 __device__ __forceinline__ void align_load_row(const uint16_t *__restrict__ pl, long lr, bool yok, int Wb, int cix,
                                                unsigned xmask, float out[4])
 {
@@ -67,28 +64,25 @@ __device__ __forceinline__ void align_load_row(const uint16_t *__restrict__ pl, 
     }
 }
 
-template <int KB>
-__global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
-                                                           long src_rows, uint16_t *__restrict__ dst,
-                                                           const AlignRow *__restrict__ rows, int Wb, long out_rows,
-                                                           AlignCoef co, const float *__restrict__ tab1d,
-                                                           int rows_per_block)
+// the lane's band picks its coefficients from the kernel arguments (selects on scalar registers, no memory)
+#define OIP_COEF(arr, b, k) ((b) == 0 ? (arr)[0][k] : ((b) == 1 ? (arr)[1][k] : ((b) == 2 ? (arr)[2][k] : (arr)[3][k])))
+struct BandCoef {
+    double cx0, cx1, cy0, cy1, cy2;
+};
+#define OIP_BAND_COEF(bc, co, b)                                                                      \
+    BandCoef bc;                                                                                      \
+    bc.cx0 = OIP_COEF((co).cx, b, 0); bc.cx1 = OIP_COEF((co).cx, b, 1);                               \
+    bc.cy0 = OIP_COEF((co).cy, b, 0); bc.cy1 = OIP_COEF((co).cy, b, 1); bc.cy2 = OIP_COEF((co).cy, b, 2);
+
+// output lines [r0, r1) of column x, band b
+__device__ __forceinline__ void align_column(const uint16_t *__restrict__ planes, size_t plane_stride, long src_rows,
+                                             uint16_t *__restrict__ dst, const AlignRow *__restrict__ rows, int Wb,
+                                             const BandCoef bc, const float *__restrict__ tab1d, int x, int b, long r0, long r1)
 {
-    // lane = 16 * band + pixel: the 2-byte taps of a 16-lane group are 32 contiguous bytes of one
-    // plane (band-minor lanes put the four lanes of every quad on four different planes, which the
-    // texture addresser serialises -- measured 2.4x slower)
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int x = (gid >> 6) * 16 + (gid & 15), b = (gid >> 4) & 3;
-    if (x >= Wb) return;
     const int xx = x * 4;
     const double dxx = (double)xx;
     // column-only part of the maps (preproc.h:447-448), fp64, left to right
-    // the lane's band picks its coefficients from the kernel arguments (selects, no memory)
-    const double cx0 = b == 0 ? co.cx[0][0] : (b == 1 ? co.cx[1][0] : (b == 2 ? co.cx[2][0] : co.cx[3][0]));
-    const double cx1 = b == 0 ? co.cx[0][1] : (b == 1 ? co.cx[1][1] : (b == 2 ? co.cx[2][1] : co.cx[3][1]));
-    const double cy0 = b == 0 ? co.cy[0][0] : (b == 1 ? co.cy[1][0] : (b == 2 ? co.cy[2][0] : co.cy[3][0]));
-    const double cy1 = b == 0 ? co.cy[0][1] : (b == 1 ? co.cy[1][1] : (b == 2 ? co.cy[2][1] : co.cy[3][1]));
-    const double cy2 = b == 0 ? co.cy[0][2] : (b == 1 ? co.cy[1][2] : (b == 2 ? co.cy[2][2] : co.cy[3][2]));
+    const double cx0 = bc.cx0, cx1 = bc.cx1, cy0 = bc.cy0, cy1 = bc.cy1, cy2 = bc.cy2;
     const double mx = __dadd_rn(__dadd_rn(__dmul_rn(cx1, dxx), cx0), dxx) * 0.25;
     const int sx = oip_cvround((float)mx * 32.0f);
     const int cix = oip_sat_short(sx >> 5) - 1;
@@ -108,49 +102,15 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
 
     float win[4][4];               // [tap row][tap col]
     int cur_iy = INT_MIN, cur_base = INT_MIN;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > out_rows) r1 = out_rows;
-
-    // first-tap line and y phase of output line r for this lane's column and band
-    auto map_y = [&](const AlignRow &a, int *iy, int *fy) {
-        const double yy = (double)((long)a.yrel * 4);
-        const double my = __dadd_rn(coly, yy) * 0.25;
-        const int sy = oip_cvround((float)my * 32.0f);
-        *iy = oip_sat_short(sy >> 5) - 1;
-        *fy = sy & 31;
-    };
-    // the 16-tap sum for the window as it stands (interior / border / fully outside)
-    auto resample = [&](const AlignRow &a, int iy, int fy) -> unsigned {
-        float sum;
-        if (x_out || iy >= a.lines || iy + 4 <= 0) {
-            sum = 0.f;
-        } else {
-            float wy[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
-            if (x_in && (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0)) {
-                sum = oip_bicubic_interior(win, wx, wy);
-            } else {
-                unsigned ymask = 0;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int rr = iy + t;
-                    const long lr = (long)a.base + rr;
-                    if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
-                }
-                sum = oip_bicubic_border(win, wx, wy, xmask, ymask);
-            }
-        }
-        return oip_sat_u16(sum);
-    };
-    // one output line the careful way: any jump of the first tap line reloads what is missing
-    auto one_row = [&](long r, const AlignRow &a) {
+    for (long r = r0; r < r1; ++r) {
+        const AlignRow a = rows[r];
         unsigned res = 0;
         if (a.valid) {
             if (a.base != cur_base) { cur_base = a.base; cur_iy = INT_MIN; }       // new section: window stale
-            int iy, fy;
-            map_y(a, &iy, &fy);
+            const double yy = (double)((long)a.yrel * 4);
+            const double my = __dadd_rn(coly, yy) * 0.25;
+            const int sy = oip_cvround((float)my * 32.0f);
+            const int iy = oip_sat_short(sy >> 5) - 1, fy = sy & 31;
             if (iy == cur_iy + 1 && cur_iy != INT_MIN) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
@@ -169,103 +129,272 @@ __global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__res
                 }
             }
             cur_iy = iy;
-            res = resample(a, iy, fy);
-        }
-        dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
-    };
-
-    // Lines can be taken KB at a time: in the regular case -- same section, first tap line advancing
-    // by one per output line, window already primed -- the new source lines are known before any of
-    // them is used, so their loads go out together.  Measured, the extra registers cost more
-    // (occupancy) than the shorter dependency chains gain, so KB = 1 is the default.
-    if (KB == 0) {
-        // One-line lookahead: after the window for output line r is complete, the source line that line
-        // r + 1 will need in the regular case (same section, first tap line + 1) is requested BEFORE the 16-tap
-        // sum of line r, so its latency hides under ~50 f32 operations instead of stalling the next iteration.
-        // A wrong guess (section seam, rounding flip of the map) is detected by (base, line) tags and reloaded.
-        float nl[4] = {0.f, 0.f, 0.f, 0.f};
-        int nl_iy = INT_MIN, nl_base = INT_MIN;
-        for (long r = r0; r < r1; ++r) {
-            const AlignRow a = rows[r];
-            unsigned res = 0;
-            if (a.valid) {
-                if (a.base != cur_base) { cur_base = a.base; cur_iy = INT_MIN; }
-                int iy, fy;
-                map_y(a, &iy, &fy);
-                if (iy == cur_iy + 1 && cur_iy != INT_MIN) {
+            float sum;
+            if (x_out || iy >= a.lines || iy + 4 <= 0) {
+                sum = 0.f;
+            } else {
+                float wy[4];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) win[t][j] = win[t + 1][j];
-                    }
-                    if (nl_base == a.base && nl_iy == iy) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) win[3][j] = nl[j];
-                    } else {
-                        const int rr = iy + 3;
-                        const long lr = (long)a.base + rr;
-                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[3]);
-                    }
-                } else if (iy != cur_iy) {
+                for (int j = 0; j < 4; ++j) wy[j] = tab1d[fy * 4 + j];
+                if (x_in && (unsigned)iy < (unsigned)(a.lines - 3 > 0 ? a.lines - 3 : 0)) {
+                    sum = oip_bicubic_interior(win, wx, wy);
+                } else {
+                    unsigned ymask = 0;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const int rr = iy + t;
                         const long lr = (long)a.base + rr;
-                        align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, win[t]);
+                        if (rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows) ymask |= 1u << t;
                     }
+                    sum = oip_bicubic_border(win, wx, wy, xmask, ymask);
                 }
-                cur_iy = iy;
-                {
-                    const int rr = iy + 4;
-                    const long lr = (long)a.base + rr;
-                    align_load_row(pl, lr, rr >= 0 && rr < a.lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, nl);
-                    nl_iy = iy + 1;
-                    nl_base = a.base;
-                }
-                res = resample(a, iy, fy);
             }
-            dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
+            res = oip_sat_u16(sum);
         }
-        return;
+        dst[((size_t)r * Wb + x) * 4 + b] = (uint16_t)res;
     }
-    constexpr int kBatch = KB > 0 ? KB : 1;
-    long r = r0;
-    for (; r + kBatch <= r1; r += kBatch) {
-        AlignRow a[kBatch];
-        int iy[kBatch], fy[kBatch];
-        bool regular = cur_iy != INT_MIN;
+}
+
+__global__ __launch_bounds__(kBlock) void align_mss_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
+                                                           long src_rows, uint16_t *__restrict__ dst,
+                                                           const AlignRow *__restrict__ rows, int Wb, long out_rows,
+                                                           AlignCoef co, const float *__restrict__ tab1d,
+                                                           int rows_per_block)
+{
+    // lane = 16 * band + pixel: the 2-byte taps of a 16-lane group are 32 contiguous bytes of one plane
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int x = (gid >> 6) * 16 + (gid & 15), b = (gid >> 4) & 3;
+    if (x >= Wb) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    OIP_BAND_COEF(bc, co, b)
+    align_column(planes, plane_stride, src_rows, dst, rows, Wb, bc, tab1d, x, b, r0, r1);
+}
+
+// ---- fast path: one lane = 8 consecutive output pixels of ONE band ------------------------------------------
+// Lane l of a wave: band l >> 4, pixel group l & 15 (8 pixels each): the 16 lanes of a band read 16 x 16
+// contiguous bytes of its plane per source line (6 dwords per lane from a 4-byte aligned address, 11
+// samples: the taps of its 8 pixels), and the wave covers 128 output pixels x 4 bands.  What makes 8
+// pixels share their work:
+//   * x: the group is REGULAR when its 8 map values land on consecutive source columns with one x phase
+//     (checked per lane at start, in the reference's fp64 order) -- then the 16 weights wy*wx are shared;
+//   * y: mapY = (colY(x) + 4 y) / 4.  Per line the exact (first tap line, phase) pair is evaluated for the
+//     group's first and last pixel only: colY is checked to be monotonic across the 8 pixels (once per
+//     lane), every later operation is monotonic, so equal end points mean equal values in between.
+// Lines where a group's pixels disagree, lines whose window touches a border of the section buffer or of
+// the image, and irregular groups are not computed here: the lane appends (group, band, line range) to a
+// list and a second launch runs the general code on exactly those.  Arithmetic per pixel is
+// oip_bicubic_interior's (w = wy*wx rounded once, row sums left to right, rows added in order).
+// The four bands of a pixel sit in four different lanes; two permlane swaps (a 4x4 transpose over the
+// 16-lane rows) and one bpermute per dword bring them together so that every lane stores 16 contiguous
+// bytes = 2 interleaved 16UC4 pixels, the wave 1 KiB.
+struct AlignFix {
+    int group, band, ra, rb;
+};
+
+__device__ __forceinline__ void align_load_raw6(const uint16_t *__restrict__ pl, long row, int Wb, int c0, long nelem, uint32_t w[6])
+{
+    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pl);
+    const long e0 = row * Wb + c0;
+    const long d0 = e0 >> 1;
+    const long dmax = (nelem - 1) >> 1;
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            a[k] = rows[r + k];
-            map_y(a[k], &iy[k], &fy[k]);
-            regular = regular && a[k].valid && a[k].base == cur_base && iy[k] == cur_iy + 1 + k;
+    for (int i = 0; i < 6; ++i) {
+        long di = d0 + i;
+        di = di < 0 ? 0 : (di > dmax ? dmax : di);
+        w[i] = p32[di];
+    }
+}
+__device__ __forceinline__ void align_expand(const uint32_t w[6], bool odd, float g[11])
+{
+    // samples start at the low half of w[0] for an even first column, at its high half for an odd one: bring the
+    // odd case to the even layout with one funnel shift per dword, then one conversion per sample
+    uint32_t e[6];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) e[i] = odd ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 16) : w[i];
+    e[5] = odd ? (w[5] >> 16) : w[5];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) g[q] = (q & 1) ? (float)(e[q >> 1] >> 16) : (float)(e[q >> 1] & 0xffffu);
+}
+
+__global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
+                                                               long src_rows, uint16_t *__restrict__ dst,
+                                                               const AlignRow *__restrict__ rows, int Wb, long out_rows,
+                                                               AlignCoef co, const float *__restrict__ tab1d,
+                                                               int rows_per_block, AlignFix *__restrict__ fix,
+                                                               int *__restrict__ fix_count, int fix_cap)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = lane >> 4;
+    const int G = ((int)blockIdx.x * (kBlock / 64) + wave) * 16 + (lane & 15);
+    const int x0 = G * 8;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    const bool live = x0 < Wb;                    // lanes past the line end still take part in the exchanges
+    const uint16_t *pl = planes + (size_t)b * plane_stride;
+    const long nelem = src_rows * (long)Wb;
+
+    // x maps of the 8 pixels (preproc.h:447), fp64 left to right, and the column part of the y maps
+    OIP_BAND_COEF(bc, co, b)
+    const double cx0 = bc.cx0, cx1 = bc.cx1, cy0 = bc.cy0, cy1 = bc.cy1, cy2 = bc.cy2;
+    int ix0 = 0, fx0 = 0;
+    bool xreg = live && x0 + 7 < Wb;
+    double c4_first = 0.0, c4_last = 0.0;
+    {
+        double prev = 0.0;
+        int dir = 0;            // +1 non-decreasing so far, -1 non-increasing, 0 flat
+        bool mono = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double dxx = (double)((x0 + j) * 4);
+            const double mx = __dadd_rn(__dadd_rn(__dmul_rn(cx1, dxx), cx0), dxx) * 0.25;
+            const int sx = oip_cvround((float)mx * 32.0f);
+            const int ix = oip_sat_short(sx >> 5) - 1, fx = sx & 31;
+            if (j == 0) { ix0 = ix; fx0 = fx; }
+            else xreg = xreg && ix == ix0 + j && fx == fx0;
+            // (colY + yy) / 4 == colY / 4 + y exactly (scaling by 4 commutes with rounding)
+            const double c4 = __dadd_rn(__dadd_rn(__dmul_rn(__dmul_rn(cy2, dxx), dxx), __dmul_rn(cy1, dxx)), cy0) * 0.25;
+            if (j == 0) c4_first = c4;
+            else {
+                if (c4 > prev) { mono = mono && dir >= 0; dir = 1; }
+                else if (c4 < prev) { mono = mono && dir <= 0; dir = -1; }
+            }
+            prev = c4;
+            if (j == 7) c4_last = c4;
         }
-        if (regular) {
-            float nl[kBatch][4];
+        xreg = xreg && mono && ix0 >= 0 && ix0 + 10 < Wb;
+    }
+    const int c0 = xreg ? ix0 : 0;
+    const bool odd = c0 & 1;
+    float wx[4];
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                const int rr = iy[k] + 3;
-                const long lr = (long)a[k].base + rr;
-                align_load_row(pl, lr, rr >= 0 && rr < a[k].lines && lr >= 0 && lr < src_rows, Wb, cix, xmask, nl[k]);
-            }
+    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
+
+    float win[4][11];
+    float w2d[16];
+    uint32_t nraw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    long nline = -1;                 // global plane line whose raw dwords are in nraw (-1: none)
+    int cur_iy = INT_MIN, cur_base = INT_MIN, cur_fy = -1;
+    int bad_lo = INT_MAX, bad_hi = INT_MIN;
+    if (live && !xreg) { bad_lo = (int)r0; bad_hi = (int)r1; }
+
+    for (long rb = r0; rb < r1; rb += 4) {
 #pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
+        for (int k = 0; k < 4; ++k) {
+            const long r = rb + k;
+            if (r >= r1) break;
+            const AlignRow a = rows[r];
+            unsigned out[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            if (a.valid) {                                    // uniform over the wave
+                const double yrel = (double)a.yrel;
+                const int sy0 = oip_cvround((float)__dadd_rn(c4_first, yrel) * 32.0f);
+                const int sy7 = oip_cvround((float)__dadd_rn(c4_last, yrel) * 32.0f);
+                const int iy = oip_sat_short(sy0 >> 5) - 1, fy = sy0 & 31;
+                const long l0 = (long)a.base + iy;
+                const bool ok = xreg && sy0 == sy7 && iy >= 0 && iy + 3 < a.lines && l0 >= 0 && l0 + 3 < src_rows;
+                if (ok) {
+                    const bool slide = a.base == cur_base && iy == cur_iy + 1;
+                    if (slide) {
+                        // rotate: this unrolled step's slot order is (k + t) & 3
+                        if (nline == l0 + 3) align_expand(nraw, odd, win[(k + 3) & 3]);
+                        else { uint32_t w[6]; align_load_raw6(pl, l0 + 3, Wb, c0, nelem, w); align_expand(w, odd, win[(k + 3) & 3]); }
+                    } else {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                        for (int t = 0; t < 4; ++t) { uint32_t w[6]; align_load_raw6(pl, l0 + t, Wb, c0, nelem, w); align_expand(w, odd, win[(k + t) & 3]); }
+                    }
+                    cur_base = a.base; cur_iy = iy;
+                    // next line's newest source line, in flight under this line's sums
+                    nline = l0 + 4;
+                    if (nline < src_rows) align_load_raw6(pl, nline, Wb, c0, nelem, nraw); else nline = -1;
+                    if (fy != cur_fy) {
+                        cur_fy = fy;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) win[t][j] = win[t + 1][j];
+                        for (int ky = 0; ky < 4; ++ky) {
+                            const float wy = tab1d[fy * 4 + ky];
+#pragma unroll
+                            for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float *L = win[(k + t) & 3];
+                            float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
+                            rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
+                            rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
+                            sum = t == 0 ? rr : __fadd_rn(sum, rr);
+                        }
+                        out[j] = oip_sat_u16(sum);
+                    }
+                } else {
+                    // the slot rotation of the unrolled loop assumes one slide per step: a skipped line breaks it
+                    cur_iy = INT_MIN;
+                    if (live) { bad_lo = bad_lo < (int)r ? bad_lo : (int)r; bad_hi = bad_hi > (int)r + 1 ? bad_hi : (int)r + 1; }
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) win[3][j] = nl[k][j];
-                cur_iy = iy[k];
-                dst[((size_t)(r + k) * Wb + x) * 4 + b] = (uint16_t)resample(a[k], iy[k], fy[k]);
+            } else {
+                cur_iy = INT_MIN;
             }
-        } else {
-#pragma unroll 1
-            for (int k = 0; k < kBatch; ++k) one_row(r + k, a[k]);
+            // d[j] = this band's pixels 2j, 2j+1; transpose over the four 16-lane rows, then lane (row r, group g)
+            // holds pixels 2r, 2r+1 of group g for all four bands
+            uint32_t d0 = out[0] | (out[1] << 16), d1 = out[2] | (out[3] << 16), d2 = out[4] | (out[5] << 16), d3 = out[6] | (out[7] << 16);
+            {
+                auto s02 = __builtin_amdgcn_permlane32_swap(d0, d2, false, false);
+                auto s13 = __builtin_amdgcn_permlane32_swap(d1, d3, false, false);
+                auto t01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                auto t23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                d0 = t01[0]; d1 = t01[1]; d2 = t23[0]; d3 = t23[1];       // band 0..3 of this lane's pixel pair
+            }
+            // lane 4g + r takes over from lane (r, g) = 16 r + g: consecutive lanes then store consecutive 16 bytes
+            const int src_lane = ((lane & 3) << 4) | (lane >> 2);
+            d0 = __builtin_amdgcn_ds_bpermute(src_lane << 2, d0);
+            d1 = __builtin_amdgcn_ds_bpermute(src_lane << 2, d1);
+            d2 = __builtin_amdgcn_ds_bpermute(src_lane << 2, d2);
+            d3 = __builtin_amdgcn_ds_bpermute(src_lane << 2, d3);
+            // pixel pair p = (lane & 3) of group (lane >> 2): pixels xs, xs + 1
+            const int gw = ((int)blockIdx.x * (kBlock / 64) + wave) * 16 + (lane >> 2);
+            const int xs = gw * 8 + 2 * (lane & 3);
+            if (xs + 1 < Wb) {
+                uint4 o;
+                o.x = (d0 & 0xffffu) | (d1 << 16);            // pixel xs: bands 0, 1
+                o.y = (d2 & 0xffffu) | (d3 << 16);            //           bands 2, 3
+                o.z = (d0 >> 16) | (d1 & 0xffff0000u);        // pixel xs + 1
+                o.w = (d2 >> 16) | (d3 & 0xffff0000u);
+                *reinterpret_cast<uint4 *>(dst + ((size_t)r * Wb + xs) * 4) = o;
+            }
         }
     }
-    for (; r < r1; ++r) one_row(r, rows[r]);
+    if (bad_hi > bad_lo) {
+        const int i = atomicAdd(fix_count, 1);
+        if (i < fix_cap) fix[i] = AlignFix{G, b, bad_lo, bad_hi};
+    }
+}
+
+// second launch: the listed (group, band, line range) entries through the general code; 64 lanes = 8 pixels x
+// 8 line sub-ranges
+__global__ __launch_bounds__(64) void align_fix_kernel(const uint16_t *__restrict__ planes, size_t plane_stride, long src_rows,
+                                                       uint16_t *__restrict__ dst, const AlignRow *__restrict__ rows, int Wb,
+                                                       AlignCoef co, const float *__restrict__ tab1d,
+                                                       const AlignFix *__restrict__ fix, const int *__restrict__ fix_count, int fix_cap)
+{
+    int n = *fix_count;
+    if (n > fix_cap) n = fix_cap;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const AlignFix f = fix[e];
+        const int x = f.group * 8 + (threadIdx.x & 7);
+        if (x >= Wb) continue;
+        const int sub = threadIdx.x >> 3;
+        const int per = (f.rb - f.ra + 7) / 8;
+        const long a = f.ra + (long)sub * per;
+        long bnd = a + per;
+        if (bnd > f.rb) bnd = f.rb;
+        const int fb = f.band;
+        OIP_BAND_COEF(bc, co, fb)
+        if (a < bnd) align_column(planes, plane_stride, src_rows, dst, rows, Wb, bc, tab1d, x, fb, a, bnd);
+    }
 }
 
 // host mirror of the kernel's first-tap line for one band/column/line (range queries)
@@ -381,10 +510,28 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
                             "oip_align_mss_bicubic_u16x4: source window [%ld,%ld) lacks halo lines, need [%ld,%ld)",
                             src_row0, src_row0 + src_rows, first, last);
     }
+    // fast path: 8 pixels of one band per lane; needs even widths (dword-aligned sample pairs) and 16-byte aligned
+    // output lines
+    static const char *envf = getenv("OIP_ALIGN_GENERAL");              // test knob: force the general kernel
+    const bool fast = !(envf && atoi(envf)) && Wb % 2 == 0 && Wb >= 16 && (((uintptr_t)d_dst) & 15) == 0 &&
+                      (((uintptr_t)d_planes) & 3) == 0 && (plane_stride % 2) == 0 && src_rows * (long)Wb >= 16;
+    const int groups = (Wb + 7) / 8;
+    int gx = (groups + 63) / 64;                                  // 4 waves x 16 groups per workgroup
+    long want = (long)ctx->cu_count * 16 / gx;
+    if (want < 1) want = 1;
+    long rpb = (out_rows + want - 1) / want;
+    if (rpb < 32) rpb = 32;
+    rpb = (rpb + 3) / 4 * 4;
+    long gy = (out_rows + rpb - 1) / rpb;
+    if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
+    const size_t rows_bytes = ((size_t)out_rows * sizeof(AlignRow) + 255) / 256 * 256;
+    const long fix_cap = (long)groups * OIP_MSS_BANDS * gy;       // one entry per (group, band, line block) at most
     void *ws = nullptr;
-    int rc = oip_workspace(ctx, (size_t)out_rows * sizeof(AlignRow) + 512, &ws);
+    int rc = oip_workspace(ctx, rows_bytes + 256 + sizeof(AlignFix) * (size_t)fix_cap + 512, &ws);
     if (rc) return rc;
     AlignRow *rows = reinterpret_cast<AlignRow *>(ws);
+    int *d_fix_count = reinterpret_cast<int *>((char *)ws + rows_bytes);
+    AlignFix *d_fix = reinterpret_cast<AlignFix *>((char *)ws + rows_bytes + 256);
     {
         OipProfScope prof(ctx, "align_rows_kernel");
         int blocks = (int)((out_rows + 255) / 256);
@@ -393,20 +540,32 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
     AlignCoef co;
     memcpy(co.cx, cx, sizeof co.cx);
     memcpy(co.cy, cy, sizeof co.cy);
-    {
+    if (fast) {
+        ctx->prof_chain = nullptr;
+        OIP_HIP(ctx, hipMemsetAsync(d_fix_count, 0, sizeof(int), ctx->stream));
+        {
+            OipProfScope prof(ctx, "align_mss_kernel");
+            hipLaunchKernelGGL(align_mss8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
+                               src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpb, d_fix, d_fix_count, (int)fix_cap);
+        }
+        {
+            OipProfScope prof(ctx, "align_fix_kernel");
+            long nb = fix_cap < (long)ctx->cu_count * 64 ? fix_cap : (long)ctx->cu_count * 64;
+            if (nb < 1) nb = 1;
+            hipLaunchKernelGGL(align_fix_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, d_planes, plane_stride, src_rows,
+                               d_dst, rows, Wb, co, ctx->d_tab1d, d_fix, d_fix_count, (int)fix_cap);
+        }
+    } else {
         OipProfScope prof(ctx, "align_mss_kernel");
-        int gx = (Wb + kBlock / 4 - 1) / (kBlock / 4);          // 16 pixels x 4 bands per wave
-        long want = (long)ctx->cu_count * 16 / gx;
-        if (want < 1) want = 1;
-        long rpb = (out_rows + want - 1) / want;
-        if (rpb < 32) rpb = 32;
-        long gy = (out_rows + rpb - 1) / rpb;
-        if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
-        static const char *envb = getenv("OIP_ALIGN_BATCH");                 // experiment knob
-        const int kb = envb ? atoi(envb) : 0;       // measured on MI355X: 3.9 ms lookahead (0); 4.4 / 5.4 / 6.8 ms for batches of 1 / 2 / 4
-        auto fn = kb == 0 ? align_mss_kernel<0> : (kb == 1 ? align_mss_kernel<1> : (kb == 2 ? align_mss_kernel<2> : align_mss_kernel<4>));
-        hipLaunchKernelGGL(fn, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
-                           src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpb);
+        int gxg = (Wb + kBlock / 4 - 1) / (kBlock / 4);          // 16 pixels x 4 bands per wave
+        long wantg = (long)ctx->cu_count * 16 / gxg;
+        if (wantg < 1) wantg = 1;
+        long rpbg = (out_rows + wantg - 1) / wantg;
+        if (rpbg < 32) rpbg = 32;
+        long gyg = (out_rows + rpbg - 1) / rpbg;
+        if (gyg > 65535) { gyg = 65535; rpbg = (out_rows + gyg - 1) / gyg; gyg = (out_rows + rpbg - 1) / rpbg; }
+        hipLaunchKernelGGL(align_mss_kernel, dim3(gxg, (unsigned)gyg), dim3(kBlock), 0, ctx->stream, d_planes, plane_stride,
+                           src_rows, d_dst, rows, Wb, out_rows, co, ctx->d_tab1d, (int)rpbg);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;

@@ -681,6 +681,157 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
     }
 }
 
+// ---- last inverse column pass (peak role), 128 points x 16 lanes, first and last stage in registers ----------
+// The generic pass kernel moves every point through LDS four times (commit, three stages) and reads it a fifth
+// time for the arg-max scan; with eight workgroups per CU the SIMDs' vector issue is the limit (VALU active
+// 12 % of the wave cycles x 8 waves per SIMD; profiles/r02_pmc_passes_before.json), not HBM.  Here thread
+// (q, v) = (threadIdx >> 4, threadIdx & 15) loads the eight points q + 16 m of lane v straight from memory (for
+// a fixed m a wave covers four 128-byte row segments) -- exactly the inputs of its radix-8 butterfly of the
+// first Stockham stage -- and the outputs of the last radix-4 stage are scanned in registers: two LDS round
+// trips and four barriers instead of five and nine.  The tile maximum is folded into the arg-max slots per
+// WAVE (a value reduction with shuffles, then an atomicMax by the lanes that hold the maximum -- one lane
+// unless values tie, and atomicMax orders ties by key itself): no LDS hand-off between the waves.
+// Measured 0.128 -> 0.104 ms per launch (3.7 TB/s).  Walking several tile rows per workgroup with the next
+// tile's loads in flight (OIP_PEAK_TILES) changes nothing: what is left is the cost of reading 128-byte
+// segments 125 lines (3 MB) apart, the same 0.03-0.04 ms the first forward pass pays for its strided stores.
+__global__ __launch_bounds__(256) void fft_col128_peak_kernel(const float2 *__restrict__ data, OipFftPass p, OipFftIo io,
+                                                              const float2 *__restrict__ twF, const float2 *__restrict__ twT)
+{
+    constexpr int F = 128, V = 16, Vp = V + 1;
+    __shared__ float2 buf[F * Vp];
+    __shared__ float2 tw[32];
+    __shared__ float2 twj[F];
+    // lane tile: contiguous chunks per XCD (see decode_tile); the workgroup keeps it and walks the row offsets
+    // o1 = blockIdx.y, + gridDim.y, ...: the loads of the next tile are issued before the later stages of the current one
+    const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
+    const int rel = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
+    if (rel >= ltn) return;
+    const int lt = p.lt0 + rel;
+    const int lane0 = lt << 4;
+    const int nv = p.lanes - lane0 < V ? (int)(p.lanes - lane0) : V;
+    const int v = threadIdx.x & (V - 1);
+    const bool lane_ok = v < nv;
+    const long none = (long)p.M * p.N;
+    const int ym = p.M >> 1, xm = p.N >> 1;
+    int xs = lane0 + v + xm; if (xs >= p.N) xs -= p.N;
+
+    int o1 = blockIdx.y;
+    if (o1 >= p.O1) return;
+    float2 x[8];
+    float2 rtw = make_float2(1.f, 0.f);
+    auto fetch = [&](int o, int tid) {
+        const long base = (long)o * p.o1_stride + lane0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            x[m] = make_float2(0.f, 0.f);
+            if (lane_ok) x[m] = data[base + (long)((tid >> 4) + 16 * m) * p.nstride + v];
+        }
+        if (tid < F) rtw = twT[(long)o * tid];
+    };
+    // inverse = conj(forward(conj(.))); the inter-pass twiddle of point n multiplies the conjugated input
+    auto stage1 = [&](int tid) {
+        const int qq = tid >> 4;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = cmul(make_float2(x[m].x, -x[m].y), twj[qq + 16 * m]);
+        bf8(x);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) buf[(qq * 8 + m) * Vp + v] = x[m];
+    };
+    fetch(o1, threadIdx.x);
+    if (threadIdx.x < 32) tw[threadIdx.x] = twF[threadIdx.x];
+    if (threadIdx.x < F) twj[threadIdx.x] = rtw;
+    __syncthreads();
+    stage1(threadIdx.x);
+    __syncthreads();
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));           // per-iteration opaque copy: no loop-invariant stage addressing held in registers
+        const int qq = tid >> 4;
+        const int o1n = o1 + gridDim.y;
+        const bool more = o1n < p.O1;
+        if (more) fetch(o1n, tid);              // in flight under stages 2 and 3 and the scan of the current tile
+        __builtin_amdgcn_sched_barrier(0);
+        // stage 2: radix 4, Ns = 8
+        float2 y[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int b = qq + 16 * i;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int b = qq + 16 * i, k = b & 7;
+            const float2 w1 = tw[k * 4];
+            const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            y[i][1] = cmul(y[i][1], w1);
+            y[i][2] = cmul(y[i][2], w2);
+            y[i][3] = cmul(y[i][3], w3);
+            bf4(y[i]);
+            const int j0 = (b - k) * 4 + k;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) buf[(j0 + 8 * m) * Vp + v] = y[i][m];
+        }
+        __syncthreads();
+        // stage 3: radix 4, Ns = 32: outputs n = b + 32 m stay in registers
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int b = qq + 16 * i;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
+            const float2 w1 = tw[b];
+            const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            y[i][1] = cmul(y[i][1], w1);
+            y[i][2] = cmul(y[i][2], w2);
+            y[i][3] = cmul(y[i][3], w3);
+            bf4(y[i]);
+        }
+        // Arg-max of the thread's eight points in fftShift-ed scan order: row y = o1 + n S moves to (y + M/2) mod M, so
+        // the points n >= 64 (m = 2, 3) come first, each half in increasing n: (i, m) = (0,2) (1,2) (0,3) (1,3) (0,0)
+        // (1,0) (0,1) (1,1).  Strict comparisons keep the first maximum; NaN never wins.
+        float bv0 = -INFINITY, bv1 = -INFINITY;
+        int bn0 = -1, bn1 = -1;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int i = s2 & 1, m = ((s2 >> 1) + 2) & 3;
+            const int n = qq + 16 * i + 32 * m;
+            const float re = y[i][m].x, im = -y[i][m].y;         // conj back
+            if (re > bv0) { bv0 = re; bn0 = n; }
+            if (im > bv1) { bv1 = im; bn1 = n; }
+        }
+        if (!lane_ok) { bv0 = bv1 = -INFINITY; bn0 = bn1 = -1; }
+        const long gtile = (long)o1 * p.lane_tiles + lt;            // as decode_tile numbers them (O2 == 1)
+        const int slot = (int)(gtile & (kPeakSlots - 1));
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const float mine = part ? bv1 : bv0;
+            const int bn = part ? bn1 : bn0;
+            float wmax = mine;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+            // the generic kernel publishes (-inf, none) for a tile without any comparable value: keep that (lane 0 only)
+            const bool holder = mine == wmax && (mine > -INFINITY || (tid & 63) == 0);
+            if (holder) {
+                long key = none;
+                if (bn >= 0 && lane_ok) {
+                    int ys = o1 + bn * p.S + ym; if (ys >= p.M) ys -= p.M;
+                    key = (long)ys * p.N + xs;
+                }
+                const unsigned long long packed = oip_peak_pack(mine, key);
+                if (packed) atomicMax(&io.slots[part * kPeakSlots + slot], packed);
+            }
+        }
+        if (!more) break;
+        __syncthreads();                        // every stage-3 read of buf and every use of twj is done
+        if (tid < F) twj[tid] = rtw;
+        __syncthreads();
+        stage1(tid);
+        __syncthreads();
+        o1 = o1n;
+    }
+}
+
 // ---- first forward column pass with fused x4 up-sampling: persistent over rows, register prefetch ----
 // The generic fused loader above spends most of its time waiting: a tile's source rows are S rows apart
 // (a DRAM page and a TLB entry each), eight workgroups per CU are all the LDS allows, and each of them
@@ -1156,6 +1307,20 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
                 OIP_HIP(ctx, hipGetLastError());
                 return OIP_OK;
             }
+    }
+    // the register-staged peak pass for the 128-point inverse column pass (see the kernel)
+    if (blocks_override <= 0 && inverse && io.store_kind == 1 && p.mode == 0 && p.axis == 1 && p.F == 128 && p.vshift == 4 &&
+        p.tw_mode == 2 && p.grid3) {
+        static const char *envk = getenv("OIP_PEAK_V2");                  // experiment knob: 0 = generic pass kernel
+        if (!(envk && atoi(envk) == 0)) {
+            static const char *envt = getenv("OIP_PEAK_TILES");             // experiment knob: tile rows per workgroup
+            const int tiles = envt && atoi(envt) > 0 ? atoi(envt) : 1;      // measured: 0.104 / 0.106 / 0.106 / 0.110 ms for 1 / 2 / 3 / 5
+            if (p.O2 != 1) return oip_fail(ctx, OIP_E_RUNTIME, "peak pass: the last inverse pass spans the whole axis");
+            grid3.y = (unsigned)((p.O1 + tiles - 1) / tiles);
+            hipLaunchKernelGGL(fft_col128_peak_kernel, grid3, dim3(256), 0, ctx->stream, data, p, io, twF, twT);
+            OIP_HIP(ctx, hipGetLastError());
+            return OIP_OK;
+        }
     }
     if (p.fast >= 0) {
         p.ntiles = blocks;

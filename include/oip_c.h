@@ -96,6 +96,30 @@ int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, lon
  * place through pinned, double-buffered line blocks (H2D || kernel || D2H). */
 int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb);
 
+/* ---- raster I/O staging (imageop.h:43-127, stitcher.h:103-120) ---------------------------------------
+ * IMO::ReadFileContent + LoadRawImage / WriteBufferToFile move a raster through one pageable heap buffer,
+ * serially with the arithmetic.  These entry points move it in 32 MiB blocks through a ring of pinned
+ * buffers on a staging stream of the context's own, so disk, host copies, PCIe and the kernels of the
+ * compute stream overlap.  Staging calls may run on a second host thread while the first drives kernels
+ * through the same context; two staging calls must not overlap each other.
+ *   ticket != NULL : the call returns once the last block's DMA is ENQUEUED and *ticket identifies it;
+ *                    oip_stage_wait(ctx, t) makes the compute stream wait (on the device) for everything up
+ *                    to t.  ticket == NULL: the compute stream is ordered behind the transfer by the call itself.
+ *   downloads start after the compute-stream work enqueued before the call and return when the host side
+ *   (file or buffer) is complete. */
+/* ReadFileContent(filePath, size, offset, total, buff) with `buff` in HBM; bytes == 0: to the end of the file */
+int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t offset, size_t bytes, void *d_dst,
+                            size_t *bytes_read, long *ticket);
+/* WriteBufferToFile(buff, size, saveFilePath) with `buff` in HBM (append != 0: "ab", as the section writes of
+ * stitcher.h:114-120 accumulate one output file) */
+int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append);
+/* the same between a pageable host buffer and HBM (copies to/from the pinned ring run on a thread pool) */
+int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes, long *ticket);
+int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes);
+int oip_stage_wait(oip_ctx *ctx, long ticket);
+int oip_stage_sync(oip_ctx *ctx);
+int oip_stage_threads(void);                          /* threads of the host copy pool (OIP_HOST_COPY_THREADS) */
+
 /* PreProcessor::LoadMSS split (preproc.h:62-75) fused with DoRRC4MSS (preproc.h:202-222):
  * one pass over the BIL MSS raster (each line = 4 bands x w/4 px) writing 4 planar,
  * RRC-corrected bands (band b at d_planes + b*plane_stride).  d_kb4: 4 x (w/4) (k,b)

@@ -61,6 +61,13 @@ _SIGS = {
     "oip_load_rrc_param_file": ([_cp, _i, _dp, _cp, _i], _i),
     "oip_rrc_u16": ([_vp, _vp, _vp, _i, _l, _vp], _i),
     "oip_rrc_u16_host": ([_vp, _vp, _i, _l, _dp], _i),
+    "oip_read_file_to_device": ([_vp, _cp, _sz, _sz, _vp, C.POINTER(_sz), _lp], _i),
+    "oip_write_device_to_file": ([_vp, _vp, _sz, _cp, _i], _i),
+    "oip_upload_staged": ([_vp, _vp, _vp, _sz, _lp], _i),
+    "oip_download_staged": ([_vp, _vp, _vp, _sz], _i),
+    "oip_stage_wait": ([_vp, _l], _i),
+    "oip_stage_sync": ([_vp], _i),
+    "oip_stage_threads": ([], _i),
     "oip_mss_split_rrc_u16": ([_vp, _vp, _vp, _sz, _i, _l, _vp], _i),
     "oip_phase_correlate_f32": ([_vp, _vp, _vp, _i, _i, _dp, _dp, _dp], _i),
     "oip_window_u16_to_f32": ([_vp, _vp, _sz, _l, _i, _i, _i, _vp], _i),
@@ -257,6 +264,33 @@ class Context:
         kb = _dbl(kb, buff.shape[1] * 2)
         self._ck(self.lib.oip_rrc_u16_host(self.h, buff.ctypes.data, buff.shape[1], buff.shape[0],
                                            kb.ctypes.data_as(_dp)))
+
+    # -- raster I/O staging
+    def read_file_to_device(self, path, d_dst, offset=0, nbytes=0, want_ticket=False):
+        got, t = C.c_size_t(), C.c_long()
+        self._ck(self.lib.oip_read_file_to_device(self.h, os.fsencode(path), offset, nbytes, _ptr(d_dst), C.byref(got),
+                                                  C.byref(t) if want_ticket else None))
+        return (got.value, t.value) if want_ticket else got.value
+
+    def write_device_to_file(self, d_src, nbytes, path, append=False):
+        self._ck(self.lib.oip_write_device_to_file(self.h, _ptr(d_src), nbytes, os.fsencode(path), int(append)))
+
+    def upload_staged(self, d_dst, host: np.ndarray, want_ticket=False, byte_offset=0):
+        assert host.flags.c_contiguous
+        t = C.c_long()
+        self._ck(self.lib.oip_upload_staged(self.h, _ptr(d_dst) + byte_offset, host.ctypes.data, host.nbytes,
+                                            C.byref(t) if want_ticket else None))
+        return t.value if want_ticket else None
+
+    def download_staged(self, host: np.ndarray, d_src, byte_offset=0):
+        assert host.flags.c_contiguous and host.flags.writeable
+        self._ck(self.lib.oip_download_staged(self.h, host.ctypes.data, _ptr(d_src) + byte_offset, host.nbytes))
+
+    def stage_wait(self, ticket):
+        self._ck(self.lib.oip_stage_wait(self.h, ticket))
+
+    def stage_sync(self):
+        self._ck(self.lib.oip_stage_sync(self.h))
 
     def mss_split_rrc_u16(self, bil, planes, plane_stride, w, lines, d_kb4):
         self._ck(self.lib.oip_mss_split_rrc_u16(self.h, _ptr(bil), _ptr(planes), plane_stride, w, lines, _ptr(d_kb4)))

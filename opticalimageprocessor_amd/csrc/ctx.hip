@@ -85,11 +85,9 @@ extern "C" void oip_destroy(oip_ctx *ctx)
     if (ctx->d_small) hipFree(ctx->d_small);
     if (ctx->h_small) hipHostFree(ctx->h_small);
     if (ctx->d_work) hipFree(ctx->d_work);
-    for (int i = 0; i < 2; ++i) {
-        if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+    oip_stage_destroy(ctx);
+    for (int i = 0; i < 2; ++i)
         if (ctx->d_stage[i]) hipFree(ctx->d_stage[i]);
-        if (ctx->stage_stream[i]) hipStreamDestroy(ctx->stage_stream[i]);
-    }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -72,6 +72,22 @@ struct stop_watch {
     }
 };
 
+// Which compression a TIFF product gets.  "reference" (default) = what the reference's libraries do for that product:
+// cv::imwrite -> LZW + horizontal predictor (ALIGNED.TIFF, stitched MSS without -g), GDAL with COMPRESS=LZW
+// PREDICTOR=2 (stitched MSS with -g, imageop.h:471-472), GDAL with default options -> none (stitched PAN,
+// imageop.h:316-328).  --tiff-compress none|lzw (or $OIP_TIFF_COMPRESS) forces one for every product.
+inline int &tiff_policy() { static int p = -1; return p; }       // -1 reference, else TIFF_NONE / TIFF_LZW
+inline int tiff_compression(int reference_choice)
+{
+    if (tiff_policy() < 0) {
+        const char *e = getenv("OIP_TIFF_COMPRESS");
+        if (e && std::string(e) == "none") return TIFF_NONE;
+        if (e && std::string(e) == "lzw") return TIFF_LZW;
+        return reference_choice;
+    }
+    return tiff_policy();
+}
+
 inline std::string to_lower(std::string s)
 {
     for (auto &c : s) c = (char)tolower((unsigned char)c);
@@ -121,11 +137,37 @@ template <typename T> struct DevBuf {              // RAII device buffer
         n = count;
     }
     void release() { if (p) oip_free(Device::get().ctx(), p); p = nullptr; n = 0; }
-    void upload(const T *h, size_t count) { Device::get().check(oip_memcpy_h2d(Device::get().ctx(), p, h, count * sizeof(T))); }
+    // pageable host memory moves through the pinned staging ring (include/oip_c.h, raster I/O staging); small
+    // tables take the plain copy
+    void upload(const T *h, size_t count)
+    {
+        if (count * sizeof(T) >= ((size_t)8 << 20)) Device::get().check(oip_upload_staged(Device::get().ctx(), p, h, count * sizeof(T), nullptr));
+        else Device::get().check(oip_memcpy_h2d(Device::get().ctx(), p, h, count * sizeof(T)));
+    }
     void download(T *h, size_t count) const
     {
+        if (count * sizeof(T) >= ((size_t)8 << 20)) { Device::get().check(oip_download_staged(Device::get().ctx(), h, p, count * sizeof(T))); return; }
         Device::get().check(oip_memcpy_d2h(Device::get().ctx(), h, p, count * sizeof(T)));
         Device::get().check(oip_sync(Device::get().ctx()));
+    }
+    // ReadFileContent / LoadRawImage with the buffer in HBM (imageop.h:52-82, :110-127): the whole file, which
+    // must hold exactly `count` elements
+    void load_file(const std::string &filePath, size_t count)
+    {
+        OLOG("Reading raw image from file `%s' ...", filePath.c_str());
+        stop_watch sw;
+        size_t got = 0;
+        Device::get().check(oip_read_file_to_device(Device::get().ctx(), filePath.c_str(), 0, count * sizeof(T), p, &got, nullptr));
+        if (got != count * sizeof(T))
+            throw std::runtime_error("file size(" + std::to_string(count * sizeof(T)) + ") doesn't match with read byte count(" +
+                                     std::to_string(got) + ")");
+        double es = sw.tick();
+        OLOG("%zu bytes read in %.3f seconds (%.1f MBps).", got, es, got / es / 1024.0 / 1024.0);
+    }
+    // WriteBufferToFile with the buffer in HBM (imageop.h:84-97)
+    void save_file(const std::string &filePath, size_t count) const
+    {
+        Device::get().check(oip_write_device_to_file(Device::get().ctx(), p, count * sizeof(T), filePath.c_str(), 0));
     }
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     ~DevBuf() { release(); }
@@ -236,27 +278,36 @@ public:
         return p.release();
     }
 
-    // imageop.h:194-228
+    // imageop.h:194-228.  The raster goes file -> HBM -> file through the staging ring (no whole-file heap buffer);
+    // keepBuffer hands back a heap copy like the reference does.
     static uint16_t *DoRRC4RAW(const std::string &raw, int pixelPerLine, const std::string &rrc,
                                const std::string saveRaw = "", bool keepBuffer = false)
     {
         size_t size = FileSize(raw);
-        std::unique_ptr<uint16_t[]> image((uint16_t *)LoadRawImage(raw, 0, 0, size));
-        int lines = (int)(size / ((size_t)pixelPerLine * BYTES_PER_PIXEL));
+        const size_t npx = size / BYTES_PER_PIXEL;
+        DevBuf<uint16_t> image(npx ? npx : 1);
+        image.load_file(raw, npx);
+        long lines = (long)(size / ((size_t)pixelPerLine * BYTES_PER_PIXEL));
         std::unique_ptr<RRCParam[]> rrcParam(LoadRRCParamFile(rrc.c_str(), pixelPerLine));
+        DevBuf<double> kb((size_t)pixelPerLine * 2);
+        kb.upload((double *)rrcParam.get(), (size_t)pixelPerLine * 2);
         OLOG("Do inplace RRC ...");
         stop_watch sw;
-        InplaceRRC(image.get(), pixelPerLine, lines, rrcParam.get());
+        Device::get().check(oip_rrc_u16(Device::get().ctx(), image.p, image.p, pixelPerLine, lines, kb.p));
+        Device::get().check(oip_sync(Device::get().ctx()));
         double es = sw.tick();
         OLOG("Done for %zu bytes in %.3f seconds (%.1f MBps).", size, es, size / es / (1024.0 * 1024.0));
         if (!saveRaw.empty()) {
             OLOG("Write RRC result as file \"%s\" ...", saveRaw.c_str());
             sw.tick();
-            WriteBufferToFile((const char *)image.get(), size, saveRaw);
+            image.save_file(saveRaw, npx);
             es = sw.tick();
             OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", size, es, size / es / (1024.0 * 1024.0));
         }
-        return keepBuffer ? image.release() : nullptr;
+        if (!keepBuffer) return nullptr;
+        std::unique_ptr<uint16_t[]> out(new uint16_t[npx ? npx : 1]);
+        image.download(out.get(), npx);
+        return out.release();
     }
 
     // imageop.h:277-363, RAW output only (the GTiff writer is "next")
@@ -278,18 +329,27 @@ public:
         } else {
             outputIsTiff = to_lower(std::filesystem::path(stitchedFilePath).extension().string()) == ".tiff";
         }
-        std::unique_ptr<char[]> l((char *)LoadRawImage(leftImagePath, 0, 0, szl)), r((char *)LoadRawImage(rightImagePath, 0, 0, szr));
-        OLOG("Begin stitching two images ...");
-        stop_watch sw;
         const size_t npx = (size_t)pixelPerLine * imageLines, nout = (size_t)outputFullLinePixels * imageLines;
         DevBuf<uint16_t> dl(npx), dr(npx), dout(nout);
-        dl.upload((uint16_t *)l.get(), npx);
-        dr.upload((uint16_t *)r.get(), npx);
+        dl.load_file(leftImagePath, npx);
+        dr.load_file(rightImagePath, npx);
+        OLOG("Begin stitching two images ...");
+        stop_watch sw;
         Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, pixelPerLine, imageLines, foldColPixels));
-        std::unique_ptr<uint16_t[]> out(new uint16_t[nout]);
-        dout.download(out.get(), nout);
-        if (outputIsTiff) write_tiff_u16(outputFilePath, out.get(), outputFullLinePixels, imageLines, 1, false);   // 1-band GTiff (imageop.h:316-328)
-        else WriteBufferToFile((const char *)out.get(), nout * 2, outputFilePath);
+        if (outputIsTiff) {                                            // 1-band GTiff (imageop.h:316-328), row blocks as they come down
+            TiffWriterU16 tw(outputFilePath, outputFullLinePixels, imageLines, 1, false, tiff_compression(TIFF_NONE));
+            const long chunk = std::max<long>(1, (long)(((size_t)64 << 20) / ((size_t)outputFullLinePixels * 2)));
+            std::vector<uint16_t> rows((size_t)chunk * outputFullLinePixels);
+            for (long r0 = 0; r0 < imageLines; r0 += chunk) {
+                const long n = std::min(chunk, imageLines - r0);
+                Device::get().check(oip_download_staged(Device::get().ctx(), rows.data(), dout.p + (size_t)r0 * outputFullLinePixels,
+                                                        (size_t)n * outputFullLinePixels * 2));
+                tw.write_rows(rows.data(), n);
+            }
+            tw.close();
+        } else {
+            dout.save_file(outputFilePath, nout);
+        }
         double es = sw.tick();
         OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", nout * 2, es, nout * 2 / es / (1024.0 * 1024.0));
         return outputFilePath;
@@ -332,12 +392,12 @@ public:
         const size_t bytes = nout * 2;
         if (!useGDAL && bytes / 2 < 4000000000ull) {
             int ident[4] = {0, 1, 2, 3};                       // same on-disk order in and out
-            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, ident);
+            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, ident, tiff_compression(TIFF_LZW));
         } else {
             const int mat2file[4] = {2, 1, 0, 3};              // Mat channel c lives at file sample mat2file[c]
             int order[4];
             for (int b = 0; b < 4; ++b) order[b] = mat2file[bandMap ? bandMap[b] - 1 : b];
-            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, order);
+            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, order, tiff_compression(TIFF_LZW));
         }
         return outputFilePath;
     }
@@ -382,57 +442,78 @@ public:
         mRrcFilePAN2 = mFilePAN2;
     }
 
+    // The reference reads both PAN files three times (CalcSttParameters, DoRRC, PreStitch) and writes two of them
+    // back in between; here each raw strip is read ONCE into HBM and every step works on the resident copy -- the
+    // .RRC.RAW / .RRC.PRESTT.RAW products are still written, from the device.
+    void LoadRawOnce()
+    {
+        const size_t npx = (size_t)mW * mLinesPAN;
+        if (!mD1.p) { mD1.alloc(npx); mD1.load_file(mFilePAN1, npx); }
+        if (!mD2.p) { mD2.alloc(npx); mD2.load_file(mFilePAN2, npx); }
+    }
+
     // stitcher.h:148-201 (runs on the files mRrcFilePAN1/2 point at: the raw ones, App.B-1)
     void CalcSttParameters(double threshold = OIP_STT_DEF_PHCTHRHLD, double maxDeltaY = 0.0, int edgeCols = 0)
     {
-        const size_t npx = (size_t)mW * mLinesPAN;
-        std::unique_ptr<char[]> h1((char *)IMO::LoadRawImage(mRrcFilePAN1, 0, 0, mSizePAN));
-        std::unique_ptr<char[]> h2((char *)IMO::LoadRawImage(mRrcFilePAN2, 0, 0, mSizePAN));
-        DevBuf<uint16_t> d1(npx), d2(npx);
-        d1.upload((uint16_t *)h1.get(), npx);
-        d2.upload((uint16_t *)h2.get(), npx);
+        LoadRawOnce();
         std::vector<double> r(3 * (size_t)mSections);
-        Device::get().check(oip_stt_correlate(Device::get().ctx(), d1.p, d2.p, mW, mLinesPAN, 0, mLinesPAN, mSections,
+        Device::get().check(oip_stt_correlate(Device::get().ctx(), mD1.p, mD2.p, mW, mLinesPAN, 0, mLinesPAN, mSections,
                                               mLinePerSection, mOverlapCols, edgeCols, r.data()));
         const int gapLines = (mLinesPAN - mSections * mLinePerSection) / (mSections + 1);
         const int stepLines = gapLines + mLinePerSection;
-        mDeltaX = mDeltaY = mResponse = 0.0;
-        int valid = 0;
         OLOG("Calculating stitching delta values ...");
         RLOG("| offset |  delta x |  delta y | response | r |");
         RLOG("-----------------------------------------------");
         for (int i = 0; i < mSections; ++i) {
             double dx = r[3 * i], dy = r[3 * i + 1], resp = r[3 * i + 2];
             bool isValid = resp >= threshold && (maxDeltaY <= 0.0 || std::abs(dy) <= maxDeltaY);
-            if (isValid) { mDeltaX += dx; mDeltaY += dy; mResponse += resp; valid++; }
             RLOG("|%7d |%10.4f|%10.4f|%10.4f|%s|", gapLines + i * stepLines, dx, dy, resp, isValid ? " Y " : " N ");
         }
-        if (valid == 0) throw std::runtime_error("No valid delta value found for stitching parameter calculating");
-        mDeltaX /= valid; mDeltaY /= valid; mResponse /= valid;
+        int valid = 0;                                                  // stitcher.h:181-198
+        if (oip_stt_mean(r.data(), mSections, threshold, maxDeltaY, &mDeltaX, &mDeltaY, &mResponse, &valid) != OIP_OK)
+            throw std::runtime_error("No valid delta value found for stitching parameter calculating");
         OLOG("Total %d valid delta value pairs found, everage value:", valid);
         OLOG("    dx: %.5f, dy: %.5f, r: %.5f", mDeltaX, mDeltaY, mResponse);
     }
 
     void DoRRC()                                                        // stitcher.h:141-146
     {
+        LoadRawOnce();
         mRrcFilePAN1 = IMO::BuildOutputFilePath(mFilePAN1, ".RRC");
         mRrcFilePAN2 = IMO::BuildOutputFilePath(mFilePAN2, ".RRC");
-        IMO::DoRRC4RAW(mFilePAN1, mW, mParamFileRRC1, mRrcFilePAN1);
-        IMO::DoRRC4RAW(mFilePAN2, mW, mParamFileRRC2, mRrcFilePAN2);
+        const size_t npx = (size_t)mW * mLinesPAN;
+        DevBuf<double> kb((size_t)mW * 2);
+        for (int c = 0; c < 2; ++c) {                                   // IMO::DoRRC4RAW on the resident strip
+            std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile((c ? mParamFileRRC2 : mParamFileRRC1).c_str(), mW));
+            kb.upload((double *)prm.get(), (size_t)mW * 2);
+            DevBuf<uint16_t> &d = c ? mD2 : mD1;
+            OLOG("Do inplace RRC ...");
+            stop_watch sw;
+            Device::get().check(oip_rrc_u16(Device::get().ctx(), d.p, d.p, mW, (long)mLinesPAN, kb.p));
+            Device::get().check(oip_sync(Device::get().ctx()));
+            double es = sw.tick();
+            OLOG("Done for %zu bytes in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
+            const std::string &save = c ? mRrcFilePAN2 : mRrcFilePAN1;
+            OLOG("Write RRC result as file \"%s\" ...", save.c_str());
+            sw.tick();
+            d.save_file(save, npx);
+            es = sw.tick();
+            OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
+        }
     }
 
-    int PreStitch()                                                     // stitcher.h:83-139
+    // fp16acc: the fp16-accumulate resampling variant (BASELINE config 5; not the parity mode)
+    int PreStitch(bool fp16acc = false)                                 // stitcher.h:83-139
     {
+        LoadRawOnce();                                                  // mD2 holds what mRrcFilePAN2 names (raw with --no-rrc)
         mPreSttFilePAN2 = IMO::BuildOutputFilePath(mRrcFilePAN2, ".PRESTT");
         const size_t npx = (size_t)mW * mLinesPAN;
-        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mRrcFilePAN2, 0, 0, mSizePAN));
         stop_watch sw;
-        DevBuf<uint16_t> src(npx), dst(npx);
-        src.upload((uint16_t *)h.get(), npx);
-        Device::get().check(oip_remap_shift_bicubic_u16(Device::get().ctx(), src.p, 0, mLinesPAN, dst.p, 0, mLinesPAN, mW,
-                                                        mLinesPAN, mDeltaX, mDeltaY, OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
-        dst.download((uint16_t *)h.get(), npx);
-        IMO::WriteBufferToFile(h.get(), mSizePAN, mPreSttFilePAN2);
+        DevBuf<uint16_t> dst(npx);
+        auto fn = fp16acc ? oip_remap_shift_bicubic_u16_f16acc : oip_remap_shift_bicubic_u16;
+        Device::get().check(fn(Device::get().ctx(), mD2.p, 0, mLinesPAN, dst.p, 0, mLinesPAN, mW, mLinesPAN, mDeltaX, mDeltaY,
+                               OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
+        dst.save_file(mPreSttFilePAN2, npx);
         double es = sw.tick();
         OLOG("Pre-stitched PAN2 written to file '%s'.", mPreSttFilePAN2.c_str());
         OLOG("%zu bytes processed & written in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
@@ -449,6 +530,7 @@ private:
     double mDeltaX = 0, mDeltaY = 0, mResponse = 0;
     size_t mSizePAN = 0;
     int mSections, mLinePerSection, mOverlapCols, mLinesPAN = 0, mW;
+    DevBuf<uint16_t> mD1, mD2;                  // the two strips, resident from the first step that needs them
 };
 
 // ---- PreProcessor (preproc.h:30-599) ---------------------------------------------------------------
@@ -467,22 +549,22 @@ public:
     void LoadPAN()                                                      // preproc.h:51-54
     {
         OLOG("Loading PAN raw image ...");
-        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mPanFile, 0, 0, mSizePAN));
         mPAN.alloc(mSizePAN / 2);
-        mPAN.upload((uint16_t *)h.get(), mSizePAN / 2);
-        Device::get().check(oip_sync(Device::get().ctx()));
+        mPAN.load_file(mPanFile, mSizePAN / 2);
     }
 
     // Fused task: the PAN strip is already on the device (RRC'd / pre-stitched by the
     // previous step of the same process) -- no file round trip.  Not owned.
     void UseDevicePAN(const uint16_t *d_pan) { mPanView = d_pan; }
 
+    // --fit reference (default): NumCpp Poly1d::fit as the reference calls it; --fit lstsq: QR on a scaled abscissa
+    void SetFitMode(int mode) { mFitMode = mode; }
+
     void LoadMSS()                                                      // preproc.h:56-80 (split deferred to DoRRC4MSS)
     {
         OLOG("Loading MSS raw image ...");
-        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(mMssFile, 0, 0, mSizeMSS));
         mMssBil.alloc(mSizeMSS / 2);
-        mMssBil.upload((uint16_t *)h.get(), mSizeMSS / 2);
+        mMssBil.load_file(mMssFile, mSizeMSS / 2);
         mPlaneStride = (size_t)(mW / MSS_BANDS) * mLinesMSS;
         mPlanes.alloc(mPlaneStride * MSS_BANDS);
         Device::get().check(oip_sync(Device::get().ctx()));
@@ -553,7 +635,7 @@ public:
         DumpInterBandShiftValues(slices, sections);
         OLOG("Filter invalid correlation values & try polynomial fitting ...");
         char err[512];
-        int rc = oip_filter_and_fit(t.data(), n, threshold, OIP_IBCV_MIN_COUNT, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0], err, sizeof err);
+        int rc = oip_filter_and_fit_mode(t.data(), n, threshold, OIP_IBCV_MIN_COUNT, mFitMode, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0], err, sizeof err);
         if (rc != OIP_OK) { OLOG("%s.", err); throw std::runtime_error(err); }
         for (int b = 0; b < MSS_BANDS; ++b) {
             OLOG("BAND %d\tdeltaX coeff: [1] %.15f, [0] %.9f", b, mDeltaXcoeffs[b][1], mDeltaXcoeffs[b][0]);
@@ -597,7 +679,7 @@ public:
         // preproc.h:167-185 WriteAlignedMSS_TIFF: 4-channel 16-bit TIFF, samples in OpenCV's on-disk order
         auto save = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
         OLOG("Outputing aligned TIFF image (%d x %ld x 4) to [%s] ...", Wb, rows, save.c_str());
-        write_tiff_u16(save, h.get(), Wb, rows, MSS_BANDS, true);
+        write_tiff_u16(save, h.get(), Wb, rows, MSS_BANDS, true, tiff_compression(TIFF_LZW));
         OLOG("Output done.");
         if (autoUnloadRawMSS) mPlanes.release();
         OLOG("DoInterBandAlignment(): done.");
@@ -606,9 +688,7 @@ public:
     void WriteRRCedPAN()                                                // preproc.h:93-105
     {
         auto save = IMO::BuildOutputFilePath(mPanFile, ".RRC");
-        std::unique_ptr<uint16_t[]> h(new uint16_t[mSizePAN / 2]);
-        mPAN.download(h.get(), mSizePAN / 2);
-        IMO::WriteBufferToFile((const char *)h.get(), mSizePAN, save);
+        mPAN.save_file(save, mSizePAN / 2);
         OLOG("Written to file [%s].", save.c_str());
     }
 
@@ -655,6 +735,7 @@ private:
     DevBuf<uint16_t> mPAN, mMssBil, mPlanes;
     const uint16_t *mPanView = nullptr;
     bool mSplitDone = false;
+    int mFitMode = OIP_FIT_REFERENCE;
     std::vector<InterBandShift> mBandShift[MSS_BANDS];
     double mDeltaXcoeffs[MSS_BANDS][2] = {};
     double mDeltaYcoeffs[MSS_BANDS][3] = {};
@@ -681,6 +762,8 @@ struct TaskOptions {
         overlapLines = OIP_IBPA_DEFAULT_LINEOVERLAP;
     double ibcThreshold = OIP_IBCV_DEF_THRESHOLD;
     bool keepLeading = false;
+    int fitMode = OIP_FIT_REFERENCE;
+    bool fp16acc = false;
 };
 
 inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const std::string &rrc1, const std::string &rrc2,
@@ -701,25 +784,15 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         throw std::invalid_argument("PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)");
     const size_t npx = (size_t)W * L;
     DevBuf<uint16_t> p1(npx), p2(npx), p2s(npx);
-    {
-        std::unique_ptr<char[]> h((char *)IMO::LoadRawImage(pan1, 0, 0, s1));
-        p1.upload((uint16_t *)h.get(), npx);
-        ck(oip_sync(ctx));
-        h.reset((char *)IMO::LoadRawImage(pan2, 0, 0, s2));
-        p2.upload((uint16_t *)h.get(), npx);
-        ck(oip_sync(ctx));
-    }
+    p1.load_file(pan1, npx);
+    p2.load_file(pan2, npx);
     // CalcSttParameters on the raw strips (App. B-1), same filter and mean as stitcher.h:181-198
     std::vector<double> r(3 * (size_t)o.sections);
     ck(oip_stt_correlate(ctx, p1.p, p2.p, W, L, 0, L, o.sections, o.sectionLines, o.overlapCols, o.edgeCols, r.data()));
     double dx = 0, dy = 0, resp = 0;
     int valid = 0;
-    for (int i = 0; i < o.sections; ++i) {
-        const bool ok = r[3 * i + 2] >= o.sttThreshold && (o.sttMaxDeltaY <= 0.0 || std::abs(r[3 * i + 1]) <= o.sttMaxDeltaY);
-        if (ok) { dx += r[3 * i]; dy += r[3 * i + 1]; resp += r[3 * i + 2]; ++valid; }
-    }
-    if (valid == 0) throw std::runtime_error("No valid delta value found for stitching parameter calculating");
-    dx /= valid; dy /= valid; resp /= valid;
+    if (oip_stt_mean(r.data(), o.sections, o.sttThreshold, o.sttMaxDeltaY, &dx, &dy, &resp, &valid) != OIP_OK)
+        throw std::runtime_error("No valid delta value found for stitching parameter calculating");
     OLOG("Total %d valid delta value pairs found, everage value:", valid);
     OLOG("    dx: %.5f, dy: %.5f, r: %.5f", dx, dy, resp);
     // DoRRC (both strips, in place) + PreStitch of PAN2
@@ -732,7 +805,8 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
             ck(oip_sync(ctx));
         }
     }
-    ck(oip_remap_shift_bicubic_u16(ctx, p2.p, 0, L, p2s.p, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
+    ck((o.fp16acc ? oip_remap_shift_bicubic_u16_f16acc : oip_remap_shift_bicubic_u16)(ctx, p2.p, 0, L, p2s.p, 0, L, W, L, dx, dy,
+                                                                                     OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
     p2.release();
     // ---- step 2: stitched PAN product
     {
@@ -744,7 +818,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
         st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
-        write_tiff_u16(outPAN, h.get(), 2 * (W - fold), L, 1, false);
+        write_tiff_u16(outPAN, h.get(), 2 * (W - fold), L, 1, false, tiff_compression(TIFF_NONE));
     }
     // ---- step 3: inter-band alignment per CCD, PAN taken from the device
     DevBuf<uint16_t> aligned[2];
@@ -752,6 +826,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
     for (int c = 0; c < 2; ++c) {
         PreProcessor pp(c ? pan2 : pan1, c ? mss2 : mss1, "", c ? rrcMss2 : rrcMss1, W);
         pp.UseDevicePAN(c ? p2s.p : p1.p);
+        pp.SetFitMode(o.fitMode);
         pp.LoadMSS();
         pp.DoRRC4MSS(true);
         pp.CalcInterBandCorrelation(o.slices, o.ibcSections, o.ibcThreshold, false);
@@ -772,11 +847,11 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         OLOG("Write stitched image to file '%s' ...", outMSS.c_str());
         const int ow = 2 * (Wb - fold);
         if (!o.useGDAL && nout < 4000000000ull) {
-            write_tiff_u16(outMSS, h.get(), ow, arows[0], MSS_BANDS, true);          // as cv::imwrite of the stitched Mat
+            write_tiff_u16(outMSS, h.get(), ow, arows[0], MSS_BANDS, true, tiff_compression(TIFF_LZW));          // as cv::imwrite of the stitched Mat
         } else {
             int order[4];
             for (int b = 0; b < 4; ++b) order[b] = o.bandMap ? o.bandMap[b] - 1 : b;  // band b <- Mat channel map[b]-1
-            write_tiff_u16_mapped(outMSS, h.get(), ow, arows[0], order);
+            write_tiff_u16_mapped(outMSS, h.get(), ow, arows[0], order, tiff_compression(TIFF_LZW));
         }
     }
     OLOG("Fused task done in %.3f seconds.", total.tick());

@@ -24,6 +24,7 @@ struct oip_prof_pending {
 };
 
 struct oip_fft_state;   // fft.hip
+struct oip_stage_state; // staging.hip
 
 // cv::resize coefficient tables (resize.cpp builds the same xofs/alpha/yofs/beta on the host)
 struct OipResizeTab {
@@ -67,11 +68,10 @@ struct oip_ctx {
     void *d_work = nullptr;
     size_t work_bytes = 0;
 
-    // pinned staging for oip_rrc_u16_host
-    void *h_stage[2] = {nullptr, nullptr};
+    // raster I/O staging (staging.hip): pinned ring + staging streams, and the two device blocks of oip_rrc_u16_host
+    oip_stage_state *stage = nullptr;
     void *d_stage[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
-    hipStream_t stage_stream[2] = {nullptr, nullptr};
 
     oip_fft_state *fft = nullptr;
     std::vector<OipResizeTab> resize_tabs;
@@ -90,6 +90,7 @@ void oip_prof_end(oip_ctx *ctx, int pending);
 int oip_workspace(oip_ctx *ctx, size_t bytes, void **out);   // grow-only workspace
 int oip_small(oip_ctx *ctx, size_t bytes);                   // make d_small / h_small hold at least `bytes`
 void oip_fft_destroy(oip_ctx *ctx);
+void oip_stage_destroy(oip_ctx *ctx);
 
 #define OIP_HIP(ctx, call)                                                              \
     do {                                                                                \

@@ -8,8 +8,8 @@
 //   oip task ...                fused flow of DOC/sample-task.sh, see run_task()
 //   oip -v | --version          prints 1.1
 // plus --width N (pixels per PAN line; the reference hard-codes 12288, oipshared.h:28).
-// `auxsep` is outside this build.  TIFF output and (uncompressed) TIFF input go through oip_tiff.hpp;
-// LZW-compressed inputs such as cv::imwrite's are refused, not decoded.
+// `auxsep` is outside this build.  TIFF input and output go through oip_tiff.hpp (uncompressed and LZW, with
+// or without the horizontal predictor).  Two options are not the reference's: --fit and --fp16-accumulate.
 //
 // Exit codes as the reference: usage_error -> "USAGE ERROR" + 254; any std::exception -> 2; unknown
 // -> 1; help/version -> 255 (CLI11's Success + 255, main.cpp:262-263); argument errors -> CLI11's
@@ -97,18 +97,30 @@ void existing_file(const Parsed &p, const std::string &k)
         throw cli_error(105, k + ": File does not exist: " + p.val.at(k));
 }
 
+// --fit reference|lstsq (not in the reference): which solver fits the shift polynomials.  `reference` (default)
+// restates NumCpp's Poly1d::fit operation by operation (preproc.h:535-536) so the maps are the reference's;
+// `lstsq` solves the same least-squares problem by Householder QR on a scaled abscissa.
+int fit_mode(const Parsed &p)
+{
+    const std::string f = p.str("--fit", "reference");
+    if (f == "reference") return OIP_FIT_REFERENCE;
+    if (f == "lstsq") return OIP_FIT_LSTSQ;
+    throw cli_error(105, "--fit: reference or lstsq expected");
+}
+
 void usage()
 {
     puts("Optical Satellite Image Pre-Processing/Processing Utility (MI355X build)\n"
          "Usage: oip [OPTIONS] [SUBCOMMAND]\n\n"
          "Options:\n"
-         "  -h,--help  -v,--version  --width N\n"
+         "  -h,--help  -v,--version  --width N  --tiff-compress reference|none|lzw\n"
          "  --pan FILE --mss FILE [--do-rrc4pan --rrc-pan FILE --write-rrcpan/--no-rrcpan] [--no-rrc4mss]\n"
          "  --rrc-msb1 FILE --rrc-msb2 FILE --rrc-msb3 FILE --rrc-msb4 FILE\n"
-         "  --slices N --ibc-sections N --ibc-threshold X --line-offset N --lines-section N --overlap-lines N -k,--keep-leading\n\n"
+         "  --slices N --ibc-sections N --ibc-threshold X --line-offset N --lines-section N --overlap-lines N -k,--keep-leading\n"
+         "  --fit reference|lstsq   (polynomial fit: the reference's NumCpp formulation [default] or QR least squares)\n\n"
          "Subcommands:\n"
          "  prestitch  --pan1 FILE --pan2 FILE [--rrc1 FILE --rrc2 FILE -s N -l N --stitch-overlap N\n"
-         "             --stt-threshold X --stt-maxdeltay X -e N -r,--rrc/--no-rrc -c,--only-calculate]\n"
+         "             --stt-threshold X --stt-maxdeltay X -e N -r,--rrc/--no-rrc -c,--only-calculate --fp16-accumulate]\n"
          "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE] [-g,--GDAL -m,--band-map a,b,c,d]\n"
          "  task       prestitch + stitch + default action x2 + stitch in one process (intermediates stay on the GPU):\n"
          "             --pan1 --pan2 --rrc1 --rrc2 --mss1 --mss2 --rrc-mss{1,2}-b{1..4} FILE --fold-cols-pan N --fold-cols-mss N\n"
@@ -120,7 +132,7 @@ int run_prestitch(const std::vector<std::string> &args, int width)
     Spec sp;
     sp.valued = {"--pan1", "--pan2", "--rrc1", "--rrc2", "--sections", "--section-lines", "--stitch-overlap", "--stt-threshold",
                  "--stt-maxdeltay", "--edge-cols", "--width"};
-    sp.flags = {"--rrc", "--no-rrc", "--only-calculate"};
+    sp.flags = {"--rrc", "--no-rrc", "--only-calculate", "--fp16-accumulate"};
     sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-r", "--rrc"}, {"-c", "--only-calculate"}};
     Parsed p = parse(sp, args);
     require(p, "--pan1");
@@ -140,7 +152,7 @@ int run_prestitch(const std::vector<std::string> &args, int width)
     stt.CalcSttParameters(thr, maxdy, edgeCols);
     if (!onlyCalc) {
         if (doRRC) stt.DoRRC();
-        stt.PreStitch();
+        stt.PreStitch(p.flag.count("--fp16-accumulate") != 0);      // not in the reference: BASELINE config 5's resampling variant
     }
     return 0;
 }
@@ -175,7 +187,7 @@ int run_default(const std::vector<std::string> &args, int width)
 {
     Spec sp;
     sp.valued = {"--pan", "--mss", "--rrc-pan", "--rrc-msb1", "--rrc-msb2", "--rrc-msb3", "--rrc-msb4", "--slices", "--ibc-sections",
-                 "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width"};
+                 "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width", "--fit"};
     sp.flags = {"--do-rrc4pan", "--write-rrcpan", "--no-rrcpan", "--no-rrc4mss", "--keep-leading"};
     sp.alias = {{"-k", "--keep-leading"}};
     Parsed p = parse(sp, args);
@@ -194,6 +206,7 @@ int run_default(const std::vector<std::string> &args, int width)
         throw usage_error("RRC parameter file of all MSS Bands needed");
     // main.cpp:301-316
     PreProcessor pp(p.str("--pan"), p.str("--mss"), p.str("--rrc-pan"), msb, width);
+    pp.SetFitMode(fit_mode(p));
     pp.LoadPAN();
     pp.LoadMSS();
     if (doRRC4PAN) {
@@ -213,10 +226,10 @@ int run_task(const std::vector<std::string> &args, int width)
     Spec sp;
     sp.valued = {"--pan1", "--pan2", "--rrc1", "--rrc2", "--mss1", "--mss2", "--out-pan", "--out-mss", "--fold-cols-pan", "--fold-cols-mss",
                  "--sections", "--section-lines", "--stitch-overlap", "--stt-threshold", "--stt-maxdeltay", "--edge-cols", "--band-map",
-                 "--slices", "--ibc-sections", "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width"};
+                 "--slices", "--ibc-sections", "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width", "--fit"};
     for (int c = 1; c <= 2; ++c)
         for (int b = 1; b <= MSS_BANDS; ++b) sp.valued.insert("--rrc-mss" + std::to_string(c) + "-b" + std::to_string(b));
-    sp.flags = {"--GDAL", "--keep-leading"};
+    sp.flags = {"--GDAL", "--keep-leading", "--fp16-accumulate"};
     sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-g", "--GDAL"}, {"-m", "--band-map"}, {"-k", "--keep-leading"}};
     Parsed p = parse(sp, args);
     std::string msb[2][MSS_BANDS];
@@ -259,6 +272,8 @@ int run_task(const std::vector<std::string> &args, int width)
     o.lineOffset = p.integer("--line-offset", 0);
     o.overlapLines = p.integer("--overlap-lines", o.overlapLines);
     o.keepLeading = p.flag.count("--keep-leading") != 0;
+    o.fitMode = fit_mode(p);
+    o.fp16acc = p.flag.count("--fp16-accumulate") != 0;
     for (auto k : {"--out-pan", "--out-mss"})
         if (to_lower(std::filesystem::path(p.str(k)).extension().string()) != ".tiff") throw std::invalid_argument("Output file should be a tiff image");
     RunFusedTask(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), p.str("--mss1"), p.str("--mss2"), msb[0], msb[1],
@@ -279,6 +294,18 @@ int main(int argc, const char *argv[])
             for (auto &a : args) {
                 if (a == "-h" || a == "--help") { usage(); return 255; }
                 if (a == "-v" || a == "--version") { puts("1.1"); return 255; }
+            }
+            // --tiff-compress reference|none|lzw (not in the reference; anywhere on the line)
+            for (size_t i = 0; i < args.size(); ++i) {
+                std::string v;
+                if (args[i] == "--tiff-compress" && i + 1 < args.size()) { v = args[i + 1]; args.erase(args.begin() + i, args.begin() + i + 2); }
+                else if (args[i].rfind("--tiff-compress=", 0) == 0) { v = args[i].substr(16); args.erase(args.begin() + i); }
+                else continue;
+                if (v == "reference") tiff_policy() = -1;
+                else if (v == "none") tiff_policy() = TIFF_NONE;
+                else if (v == "lzw") tiff_policy() = TIFF_LZW;
+                else throw cli_error(105, "--tiff-compress: reference, none or lzw expected");
+                break;
             }
             if (!args.empty() && args[0] == "prestitch") return run_prestitch({args.begin() + 1, args.end()}, width);
             if (!args.empty() && args[0] == "stitch") return run_stitch({args.begin() + 1, args.end()}, width);

@@ -1,37 +1,202 @@
-// oip_tiff.hpp -- dependency-free writer for uncompressed 16-bit TIFF / BigTIFF.
+// oip_tiff.hpp -- dependency-free codec for the 16-bit TIFF / BigTIFF files on either side of the hot path.
 //
-// SURVEY 8f rank 1.  The reference writes its results through two libraries that are not
-// available here: the stitched PAN strip as a 1-band GTiff via GDAL (imageop.h:316-328,
-// GDT_UInt16, default creation options = uncompressed, one strip per row block) and the aligned
-// MSS image via cv::imwrite(".TIFF") of a CV_16UC4 Mat (preproc.h:167-185).  This writer produces
-// files every TIFF reader opens (little endian, baseline tags, contiguous strips; BigTIFF when the
-// file would pass 4 GiB, as GDAL does with BIGTIFF=IF_NEEDED) -- not byte-identical files: OpenCV
-// additionally LZW-compresses, which no consumer depends on.
+// SURVEY 8f ranks 1 and 2.  The reference writes and reads its TIFFs through two libraries that are not
+// available here:
+//   * cv::imwrite(".TIFF") of a CV_16UC4 Mat (preproc.h:167-185; StitchTiff, imageop.h:390-402): OpenCV's TIFF
+//     encoder defaults to LZW with the horizontal predictor, and converts BGRA -> RGBA on the way out;
+//   * GDAL GTiff: stitched PAN as a 1-band file with default creation options (imageop.h:316-328: no
+//     compression), stitched MSS with COMPRESS=LZW PREDICTOR=2 (imageop.h:460-567);
+//   * cv::imread of those files (imageop.h:380-388).
+// This codec writes and reads little-endian baseline strips, chunky samples, unsigned 16 bit, classic TIFF or
+// BigTIFF (when the file would pass 4 GiB, as GDAL does with BIGTIFF=IF_NEEDED), uncompressed (259 = 1) or LZW
+// (259 = 5) with predictor 1 or 2 (317) -- so the files the reference itself produces can be consumed and the
+// files written here open in cv::imread / GDAL.  Pixel payloads match the reference's; file bytes need not
+// (strip sizes and tag order are the libraries' own).  Strips are encoded / decoded on a few threads.
 //
-// Channel order: OpenCV's TIFF encoder converts BGRA -> RGBA on write (and imread converts back),
-// so a 4-channel Mat (c0,c1,c2,c3) is stored as samples (c2,c1,c0,c3).  `opencv_order` reproduces
-// that, so files written here round-trip through cv::imread exactly like the reference's.
+// LZW as TIFF 6.0 section 13 specifies it and libtiff implements it: MSB-first codes of 9..12 bits, ClearCode
+// 256, EndOfInformation 257, first free code 258, every strip starts with ClearCode; the encoder widens the
+// code after assigning entry 511 / 1023 / 2047 (the decoder, whose table lags by one entry, widens when ITS
+// next free code is 511 / 1023 / 2047 -- TIFF's "early change") and emits ClearCode when entry 4093 is assigned.
+// Predictor 2 on 16-bit samples: each sample minus the same channel of the previous pixel, modulo 2^16.
+//
+// Channel order: OpenCV stores a 4-channel Mat (c0,c1,c2,c3) as samples (c2,c1,c0,c3); `opencv_order`
+// reproduces that, so files written here round-trip through cv::imread exactly like the reference's.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace OIPGPU {
 
+enum TiffCompression { TIFF_NONE = 1, TIFF_LZW = 5 };
+
+namespace tiffdetail {
+
+inline int worker_count()
+{
+    int n = (int)std::thread::hardware_concurrency() / 2;
+    return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+// run fn(i) for i in [0, n) on a few threads
+template <typename F> inline void parallel_for(size_t n, F fn)
+{
+    const int nt = (int)std::min<size_t>(n, (size_t)worker_count());
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> th;
+    std::vector<std::string> errs(nt);
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            try { for (size_t i = t; i < n; i += nt) fn(i); }
+            catch (const std::exception &e) { errs[t] = e.what(); }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
+}
+
+struct BitWriter {
+    std::vector<uint8_t> &out;
+    uint64_t acc = 0;
+    int nbits = 0;
+    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
+    void put(unsigned code, int width)
+    {
+        acc = (acc << width) | code;
+        nbits += width;
+        while (nbits >= 8) { out.push_back((uint8_t)(acc >> (nbits - 8))); nbits -= 8; }
+    }
+    void flush() { if (nbits > 0) { out.push_back((uint8_t)(acc << (8 - nbits))); nbits = 0; } }
+};
+
+inline void lzw_encode(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+{
+    constexpr int kHash = 1 << 14;                 // open addressing, 4x the table
+    std::vector<int32_t> hkey(kHash, -1);          // (prefix << 8) | byte
+    std::vector<uint16_t> hcode(kHash);
+    out.clear();
+    out.reserve(n / 2 + 64);
+    BitWriter bw(out);
+    int width = 9, next = 258;
+    bw.put(256, width);
+    if (n == 0) { bw.put(257, width); bw.flush(); return; }
+    int ent = src[0];
+    for (size_t i = 1; i < n; ++i) {
+        const int c = src[i];
+        const int32_t key = (ent << 8) | c;
+        unsigned h = ((unsigned)key * 2654435761u) >> 18;
+        bool found = false;
+        while (hkey[h] != -1) {
+            if (hkey[h] == key) { ent = hcode[h]; found = true; break; }
+            h = (h + 1) & (kHash - 1);
+        }
+        if (found) continue;
+        bw.put((unsigned)ent, width);
+        ent = c;
+        hkey[h] = key;
+        hcode[h] = (uint16_t)next++;
+        if (next == 4094) {                        // table full: clear (libtiff: free_ent == CODE_MAX - 1)
+            bw.put(256, width);
+            std::fill(hkey.begin(), hkey.end(), -1);
+            width = 9;
+            next = 258;
+        } else if (next == (1 << width) && width < 12) {
+            ++width;
+        }
+    }
+    bw.put((unsigned)ent, width);
+    ++next;                                        // libtiff's LZWPostEncode: the last code counts as an entry too
+    if (next == 4094) { bw.put(256, width); width = 9; }
+    else if (next == (1 << width) && width < 12) ++width;
+    bw.put(257, width);
+    bw.flush();
+}
+
+// returns the number of bytes produced (at most cap); throws on a corrupt stream
+inline size_t lzw_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
+{
+    uint16_t prefix[4096];
+    uint8_t suffix[4096], first[4096];
+    uint16_t length[4096];
+    for (int i = 0; i < 256; ++i) { prefix[i] = 0xFFFF; suffix[i] = (uint8_t)i; first[i] = (uint8_t)i; length[i] = 1; }
+    int width = 9, next = 258, old = -1;
+    uint64_t acc = 0;
+    int nbits = 0;
+    size_t pos = 0, produced = 0;
+    for (;;) {
+        while (nbits < width) {
+            if (pos >= n) return produced;          // stream ends without EOI: tolerated, as libtiff does
+            acc = (acc << 8) | src[pos++];
+            nbits += 8;
+        }
+        const int code = (int)((acc >> (nbits - width)) & ((1u << width) - 1));
+        nbits -= width;
+        if (code == 257) break;
+        if (code == 256) { width = 9; next = 258; old = -1; continue; }
+        if (old < 0) {
+            if (code >= 256) throw std::runtime_error("corrupt LZW stream (bad first code)");
+            if (produced < cap) dst[produced] = (uint8_t)code;
+            ++produced;
+            old = code;
+            continue;
+        }
+        int emit = code;
+        if (code >= next) {
+            if (code != next) throw std::runtime_error("corrupt LZW stream (code beyond the table)");
+            // KwKwK: old string + its first byte
+            prefix[next] = (uint16_t)old; suffix[next] = first[old]; first[next] = first[old]; length[next] = (uint16_t)(length[old] + 1);
+            emit = next;
+        } else {
+            prefix[next] = (uint16_t)old; suffix[next] = first[code]; first[next] = first[old]; length[next] = (uint16_t)(length[old] + 1);
+        }
+        const size_t len = length[emit];
+        if (produced + len <= cap) {
+            uint8_t *p = dst + produced + len;
+            for (int c = emit; c != 0xFFFF; c = prefix[c]) *--p = suffix[c];
+        } else {
+            // tail of a strip that decodes to more than expected: keep what fits
+            std::vector<uint8_t> tmp(len);
+            uint8_t *p = tmp.data() + len;
+            for (int c = emit; c != 0xFFFF; c = prefix[c]) *--p = suffix[c];
+            if (produced < cap) memcpy(dst + produced, tmp.data(), cap - produced);
+        }
+        produced += len;
+        if (next < 4096) ++next;
+        if (next >= (1 << width) - 1 && width < 12) ++width;       // early change
+        old = code;
+        if (produced >= cap && pos >= n) break;
+    }
+    return produced;
+}
+
+inline void predictor2_encode(uint16_t *row, size_t width, int spp)
+{
+    for (size_t i = width * spp - 1; i >= (size_t)spp; --i) row[i] = (uint16_t)(row[i] - row[i - spp]);
+}
+inline void predictor2_decode(uint16_t *row, size_t width, int spp)
+{
+    for (size_t i = spp; i < width * spp; ++i) row[i] = (uint16_t)(row[i] + row[i - spp]);
+}
+
+}  // namespace tiffdetail
+
 class TiffWriterU16 {
 public:
-    // rows are appended top to bottom with write_rows(); close() writes the directory
-    TiffWriterU16(const std::string &path, int width, long height, int spp, bool opencv_order)
-        : mW(width), mH(height), mSpp(spp), mSwap(opencv_order && spp == 4)
+    // rows are appended top to bottom with write_rows(); close() writes the directory.
+    // compression: TIFF_NONE, or TIFF_LZW (always with predictor 2, what cv::imwrite and the reference's GDAL call use)
+    TiffWriterU16(const std::string &path, int width, long height, int spp, bool opencv_order, int compression = TIFF_NONE)
+        : mW(width), mH(height), mSpp(spp), mSwap(opencv_order && spp == 4), mComp(compression)
     {
         if (width <= 0 || height <= 0 || (spp != 1 && spp != 4)) throw std::invalid_argument("TiffWriterU16: bad geometry");
+        if (compression != TIFF_NONE && compression != TIFF_LZW) throw std::invalid_argument("TiffWriterU16: unsupported compression");
         mRowBytes = (size_t)width * spp * 2;
         const size_t data = mRowBytes * (size_t)height;
-        mBig = data + (size_t)height * 16 / 64 + 4096 > 0xFFFFF000ull;      // classic TIFF offsets are 32 bit
+        mBig = data + (size_t)height * 16 / 64 + 4096 > 0xFFFFF000ull;      // classic TIFF offsets are 32 bit (LZW output is smaller; BigTIFF is always valid)
         mRowsPerStrip = (long)((8u << 20) / mRowBytes);
         if (mRowsPerStrip < 1) mRowsPerStrip = 1;
         if (mRowsPerStrip > height) mRowsPerStrip = height;
@@ -50,36 +215,62 @@ public:
     void write_rows(const uint16_t *rows, long count)
     {
         if (mRowsDone + count > mH) throw std::logic_error("TiffWriterU16: too many rows");
-        std::vector<uint16_t> tmp;
-        for (long r = 0; r < count; ++r) {
-            if (mRowsDone % mRowsPerStrip == 0) { mStripOff.push_back(mPos); mStripLen.push_back(0); }
-            const uint16_t *src = rows + (size_t)r * mW * mSpp;
-            if (mSwap) {
-                tmp.resize((size_t)mW * 4);
-                for (int x = 0; x < mW; ++x) {
-                    tmp[4 * x + 0] = src[4 * x + 2];
-                    tmp[4 * x + 1] = src[4 * x + 1];
-                    tmp[4 * x + 2] = src[4 * x + 0];
-                    tmp[4 * x + 3] = src[4 * x + 3];
-                }
-                src = tmp.data();
+        if (mComp == TIFF_NONE) {
+            std::vector<uint16_t> tmp;
+            for (long r = 0; r < count; ++r) {
+                if (mRowsDone % mRowsPerStrip == 0) { mStripOff.push_back(mPos); mStripLen.push_back(0); }
+                const uint16_t *src = rows + (size_t)r * mW * mSpp;
+                if (mSwap) { tmp.resize((size_t)mW * 4); swap_row(src, tmp.data()); src = tmp.data(); }
+                put(src, mRowBytes);
+                mStripLen.back() += mRowBytes;
+                mPos += mRowBytes;
+                ++mRowsDone;
             }
-            put(src, mRowBytes);
-            mStripLen.back() += mRowBytes;
-            mPos += mRowBytes;
-            ++mRowsDone;
+            return;
         }
+        // compressed: rows gather into whole strips, strips are encoded on a few threads, then written in order
+        const size_t rw = (size_t)mW * mSpp;
+        mPending.insert(mPending.end(), rows, rows + (size_t)count * rw);
+        mRowsDone += count;
+        const long have = (long)(mPending.size() / rw);
+        long nstrips = have / mRowsPerStrip;
+        if (mRowsDone == mH && have % mRowsPerStrip) ++nstrips;           // the last, short strip
+        if (nstrips == 0) return;
+        std::vector<std::vector<uint8_t>> enc((size_t)nstrips);
+        tiffdetail::parallel_for((size_t)nstrips, [&](size_t k) {
+            const long r0 = (long)k * mRowsPerStrip;
+            const long n = std::min<long>(mRowsPerStrip, have - r0);
+            std::vector<uint16_t> buf((size_t)n * rw);
+            for (long r = 0; r < n; ++r) {
+                const uint16_t *src = mPending.data() + (size_t)(r0 + r) * rw;
+                uint16_t *d = buf.data() + (size_t)r * rw;
+                if (mSwap) swap_row(src, d); else memcpy(d, src, rw * 2);
+                tiffdetail::predictor2_encode(d, (size_t)mW, mSpp);
+            }
+            tiffdetail::lzw_encode((const uint8_t *)buf.data(), buf.size() * 2, enc[k]);
+        });
+        long used = 0;
+        for (long k = 0; k < nstrips; ++k) {
+            if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
+            mStripOff.push_back(mPos);
+            mStripLen.push_back(enc[k].size());
+            put(enc[k].data(), enc[k].size());
+            mPos += enc[k].size();
+            used += std::min<long>(mRowsPerStrip, have - k * mRowsPerStrip);
+        }
+        mPending.erase(mPending.begin(), mPending.begin() + (size_t)used * rw);
     }
 
     void close()
     {
         if (!mF) return;
-        if (mRowsDone != mH) { fclose(mF); mF = nullptr; throw std::logic_error("TiffWriterU16: rows missing"); }
+        if (mRowsDone != mH || !mPending.empty()) { fclose(mF); mF = nullptr; throw std::logic_error("TiffWriterU16: rows missing"); }
         if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
         // out-of-line arrays first
         const uint64_t nstrips = mStripOff.size();
         uint64_t offStripOff = 0, offStripLen = 0, offBits = 0, offFmt = 0;
         const size_t osz = mBig ? 8 : 4, inl = mBig ? 8 : 4;
+        if (!mBig && mPos + nstrips * 8 + 4096 > 0xFFFFFFFFull) { fclose(mF); mF = nullptr; throw std::runtime_error("TiffWriterU16: classic TIFF overflow"); }
         if (nstrips * osz > inl) {
             offStripOff = mPos; for (uint64_t v : mStripOff) putv(v, osz);
             offStripLen = mPos; for (uint64_t v : mStripLen) putv(v, osz);
@@ -98,13 +289,14 @@ public:
         tags.push_back({256, LONG, 1, (uint64_t)mW, false});
         tags.push_back({257, LONG, 1, (uint64_t)mH, false});
         tags.push_back({258, SHORT, (uint64_t)mSpp, offBits ? offBits : inline_shorts(mSpp, 16), offBits != 0});
-        tags.push_back({259, SHORT, 1, 1, false});                                        // no compression
+        tags.push_back({259, SHORT, 1, (uint64_t)mComp, false});
         tags.push_back({262, SHORT, 1, (uint64_t)(mSpp == 4 ? 2 : 1), false});            // RGB / BlackIsZero
         tags.push_back({273, otype, nstrips, offStripOff ? offStripOff : mStripOff[0], offStripOff != 0});
         tags.push_back({277, SHORT, 1, (uint64_t)mSpp, false});
         tags.push_back({278, LONG, 1, (uint64_t)mRowsPerStrip, false});
         tags.push_back({279, otype, nstrips, offStripLen ? offStripLen : mStripLen[0], offStripLen != 0});
         tags.push_back({284, SHORT, 1, 1, false});                                        // chunky
+        if (mComp == TIFF_LZW) tags.push_back({317, SHORT, 1, 2, false});                 // horizontal predictor
         if (mSpp == 4) tags.push_back({338, SHORT, 1, 2, false});                         // unassociated alpha
         tags.push_back({339, SHORT, (uint64_t)mSpp, offFmt ? offFmt : inline_shorts(mSpp, 1), offFmt != 0});
         if (mBig) {
@@ -128,6 +320,15 @@ public:
     bool bigtiff() const { return mBig; }
 
 private:
+    void swap_row(const uint16_t *src, uint16_t *dst) const
+    {
+        for (int x = 0; x < mW; ++x) {
+            dst[4 * x + 0] = src[4 * x + 2];
+            dst[4 * x + 1] = src[4 * x + 1];
+            dst[4 * x + 2] = src[4 * x + 0];
+            dst[4 * x + 3] = src[4 * x + 3];
+        }
+    }
     void put(const void *p, size_t n)
     {
         if (fwrite(p, 1, n, mF) != n) throw std::runtime_error("TiffWriterU16: write failed");
@@ -145,34 +346,46 @@ private:
     long mH;
     int mSpp;
     bool mSwap, mBig = false;
+    int mComp;
     size_t mRowBytes = 0;
     long mRowsPerStrip = 1, mRowsDone = 0;
     uint64_t mPos = 0;
     std::vector<uint64_t> mStripOff, mStripLen;
+    std::vector<uint16_t> mPending;
 };
 
-// Reader for what the writer above produces (and any other little-endian, uncompressed, chunky
-// 16-bit strip TIFF / BigTIFF).  Compressed files -- e.g. cv::imwrite's default LZW -- are refused
-// with a clear message rather than decoded.  Samples are returned in file order.
+// Reader for little-endian, chunky, unsigned 16-bit strip TIFF / BigTIFF, uncompressed or LZW (predictor 1 or
+// 2): what the writer above, cv::imwrite and GDAL's GTiff driver (INTERLEAVE=PIXEL, untiled) produce.  Samples
+// are returned in file order.  Every header field is checked before it sizes an allocation or a read.
 inline void read_tiff_u16(const std::string &path, int *width, long *height, int *spp, std::vector<uint16_t> *out)
 {
-    FILE *f = fopen(path.c_str(), "rb");
+    struct FileGuard {
+        FILE *f;
+        ~FileGuard() { if (f) fclose(f); }
+    } g{fopen(path.c_str(), "rb")};
+    FILE *f = g.f;
     if (!f) throw std::runtime_error("cannot open file [" + path + "]");
-    auto fail = [&](const std::string &m) { fclose(f); throw std::runtime_error("read TIFF [" + path + "]: " + m); };
-    auto rd = [&](uint64_t off, void *p, size_t n) { if (fseeko(f, (off_t)off, SEEK_SET) || fread(p, 1, n, f) != n) fail("truncated file"); };
+    auto fail = [&](const std::string &m) -> void { throw std::runtime_error("read TIFF [" + path + "]: " + m); };
+    if (fseeko(f, 0, SEEK_END)) fail("seek failed");
+    const uint64_t fsize = (uint64_t)ftello(f);
+    auto rd = [&](uint64_t off, void *p, size_t n) {
+        if (off > fsize || n > fsize - off) fail("truncated file");
+        if (fseeko(f, (off_t)off, SEEK_SET) || fread(p, 1, n, f) != n) fail("truncated file");
+    };
     unsigned char h[16];
     rd(0, h, 8);
     if (h[0] != 'I' || h[1] != 'I') fail("only little-endian TIFF is supported");
     const bool big = h[2] == 43;
-    if (h[2] != 42 && !big) fail("not a TIFF file");
+    if ((h[2] != 42 && !big) || h[3] != 0) fail("not a TIFF file");
     uint64_t ifd;
     if (big) { rd(8, h, 8); memcpy(&ifd, h, 8); } else { uint32_t v; memcpy(&v, h + 4, 4); ifd = v; }
     uint64_t n = 0;
     if (big) rd(ifd, &n, 8); else { uint16_t v; rd(ifd, &v, 2); n = v; }
+    if (n == 0 || n > 4096) fail("implausible directory");
     const uint64_t ent = ifd + (big ? 8 : 2);
     const size_t esz = big ? 20 : 12, osz = big ? 8 : 4;
     auto tsize = [](int t) { return t == 3 ? 2 : (t == 4 ? 4 : (t == 16 ? 8 : 0)); };
-    uint64_t W = 0, H = 0, comp = 1, planar = 1, S = 1, bits = 0, fmt = 1;
+    uint64_t W = 0, H = 0, comp = 1, planar = 1, S = 1, bits = 0, fmt = 1, pred = 1, rps = 0;
     std::vector<uint64_t> offs, lens;
     for (uint64_t i = 0; i < n; ++i) {
         unsigned char e[20];
@@ -182,7 +395,8 @@ inline void read_tiff_u16(const std::string &path, int *width, long *height, int
         uint64_t cnt = 0;
         memcpy(&cnt, e + 4, osz);
         const int ts = tsize(type);
-        if (!ts) continue;
+        if (!ts || cnt == 0) continue;                                          // unknown type / empty tag: not ours
+        if (cnt > fsize / (uint64_t)ts) fail("tag larger than the file");
         std::vector<unsigned char> raw((size_t)cnt * ts);
         if (cnt * ts <= osz) memcpy(raw.data(), e + 4 + osz, (size_t)cnt * ts);
         else { uint64_t o = 0; memcpy(&o, e + 4 + osz, osz); rd(o, raw.data(), raw.size()); }
@@ -194,45 +408,89 @@ inline void read_tiff_u16(const std::string &path, int *width, long *height, int
             case 259: comp = val(0); break;
             case 273: offs.resize(cnt); for (uint64_t k = 0; k < cnt; ++k) offs[k] = val(k); break;
             case 277: S = val(0); break;
+            case 278: rps = val(0); break;
             case 279: lens.resize(cnt); for (uint64_t k = 0; k < cnt; ++k) lens[k] = val(k); break;
             case 284: planar = val(0); break;
+            case 317: pred = val(0); break;
             case 339: fmt = val(0); break;
+            case 322: case 323: case 324: case 325: fail("tiled TIFF is not supported (strips only)"); break;
             default: break;
         }
     }
-    if (comp != 1) fail("compressed TIFF input (compression " + std::to_string(comp) + ") is not supported by this build; re-save uncompressed");
+    if (comp != TIFF_NONE && comp != TIFF_LZW) fail("compression " + std::to_string(comp) + " is not supported (none and LZW are)");
+    if (pred != 1 && pred != 2) fail("predictor " + std::to_string(pred) + " is not supported");
     if (bits != 16 || fmt != 1 || planar != 1) fail("only chunky unsigned 16-bit samples are supported");
-    if (!W || !H || offs.empty() || offs.size() != lens.size()) fail("missing geometry or strip tags");
-    out->resize((size_t)W * H * S);
-    size_t pos = 0;
-    for (size_t k = 0; k < offs.size(); ++k) {
-        if (pos + lens[k] > out->size() * 2) fail("strip sizes exceed the image");
-        rd(offs[k], (char *)out->data() + pos, (size_t)lens[k]);
-        pos += (size_t)lens[k];
+    if (!W || !H || W > 0x7FFFFFFFull || H > 0x7FFFFFFFull || S == 0 || S > 16) fail("missing or implausible geometry");
+    if (offs.empty() || offs.size() != lens.size()) fail("missing strip tags");
+    const uint64_t row_bytes = W * S * 2;
+    if (H > (~(uint64_t)0) / row_bytes || row_bytes * H > ((uint64_t)1 << 46)) fail("implausible image size");
+    if (rps == 0 || rps > H) rps = H;
+    const uint64_t nstrips = (H + rps - 1) / rps;
+    if (offs.size() != nstrips) fail("strip count does not match RowsPerStrip");
+    for (size_t k = 0; k < offs.size(); ++k)
+        if (offs[k] > fsize || lens[k] > fsize - offs[k]) fail("strip outside the file");
+    if (comp == TIFF_NONE) {
+        uint64_t total = 0;
+        for (uint64_t l : lens) { if (l > row_bytes * H - total) fail("strip sizes exceed the image"); total += l; }
+        if (total != row_bytes * H) fail("strip sizes do not cover the image");
     }
-    if (pos != out->size() * 2) fail("strip sizes do not cover the image");
-    fclose(f);
+    out->resize((size_t)(W * H * S));
+    unsigned char *dstb = reinterpret_cast<unsigned char *>(out->data());
+    if (comp == TIFF_NONE) {
+        size_t pos = 0;
+        for (size_t k = 0; k < offs.size(); ++k) {
+            rd(offs[k], dstb + pos, (size_t)lens[k]);
+            pos += (size_t)lens[k];
+        }
+    } else {
+        // read the compressed strips in batches, decode them on a few threads
+        const size_t batch = 64;
+        for (size_t k0 = 0; k0 < offs.size(); k0 += batch) {
+            const size_t kn = std::min(batch, offs.size() - k0);
+            std::vector<std::vector<unsigned char>> raw(kn);
+            for (size_t j = 0; j < kn; ++j) { raw[j].resize((size_t)lens[k0 + j]); rd(offs[k0 + j], raw[j].data(), raw[j].size()); }
+            tiffdetail::parallel_for(kn, [&](size_t j) {
+                const uint64_t k = k0 + j;
+                const uint64_t r0 = k * rps, nr = std::min<uint64_t>(rps, H - r0);
+                const size_t want = (size_t)(nr * row_bytes);
+                const size_t got = tiffdetail::lzw_decode(raw[j].data(), raw[j].size(), dstb + (size_t)(r0 * row_bytes), want);
+                if (got != want) throw std::runtime_error("read TIFF [" + path + "]: strip " + std::to_string(k) + " decodes to " +
+                                                          std::to_string(got) + " bytes, " + std::to_string(want) + " expected");
+            });
+        }
+    }
+    if (pred == 2) {
+        uint16_t *px = out->data();
+        tiffdetail::parallel_for((size_t)H, [&](size_t r) { tiffdetail::predictor2_decode(px + r * (size_t)(W * S), (size_t)W, (int)S); });
+    }
     *width = (int)W; *height = (long)H; *spp = (int)S;
 }
 
 // like the writer class, but with an explicit sample order: out sample i = in sample order[i]
-inline void write_tiff_u16_mapped(const std::string &path, const uint16_t *data, int width, long height, const int order[4])
+inline void write_tiff_u16_mapped(const std::string &path, const uint16_t *data, int width, long height, const int order[4],
+                                  int compression = TIFF_NONE)
 {
-    TiffWriterU16 w(path, width, height, 4, false);
-    std::vector<uint16_t> row((size_t)width * 4);
-    for (long r = 0; r < height; ++r) {
-        const uint16_t *src = data + (size_t)r * width * 4;
-        for (int x = 0; x < width; ++x)
-            for (int c = 0; c < 4; ++c) row[4 * (size_t)x + c] = src[4 * (size_t)x + order[c]];
-        w.write_rows(row.data(), 1);
+    TiffWriterU16 w(path, width, height, 4, false, compression);
+    const long chunk = std::max<long>(1, (long)(((size_t)32 << 20) / ((size_t)width * 8)));
+    std::vector<uint16_t> rows((size_t)chunk * width * 4);
+    for (long r0 = 0; r0 < height; r0 += chunk) {
+        const long n = std::min(chunk, height - r0);
+        for (long r = 0; r < n; ++r) {
+            const uint16_t *src = data + (size_t)(r0 + r) * width * 4;
+            uint16_t *dst = rows.data() + (size_t)r * width * 4;
+            for (int x = 0; x < width; ++x)
+                for (int c = 0; c < 4; ++c) dst[4 * (size_t)x + c] = src[4 * (size_t)x + order[c]];
+        }
+        w.write_rows(rows.data(), n);
     }
     w.close();
 }
 
-inline void write_tiff_u16(const std::string &path, const uint16_t *data, int width, long height, int spp, bool opencv_order)
+inline void write_tiff_u16(const std::string &path, const uint16_t *data, int width, long height, int spp, bool opencv_order,
+                           int compression = TIFF_NONE)
 {
-    TiffWriterU16 w(path, width, height, spp, opencv_order);
-    const long chunk = 4096;
+    TiffWriterU16 w(path, width, height, spp, opencv_order, compression);
+    const long chunk = std::max<long>(1, (long)(((size_t)64 << 20) / ((size_t)width * spp * 2)));
     for (long r = 0; r < height; r += chunk)
         w.write_rows(data + (size_t)r * width * spp, height - r < chunk ? height - r : chunk);
     w.close();

@@ -23,7 +23,6 @@
 // overflow case needs a select (negative overflow and NaN already give low half 0).
 #include "oip_internal.h"
 
-#include <thread>
 #include <vector>
 
 namespace {
@@ -329,86 +328,4 @@ extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16
     return OIP_OK;
 }
 
-// Host-buffer form of InplaceRRC: the caller's heap buffer is corrected in place through
-// two pinned staging blocks and two device blocks on two streams, so the H2D copy of block
-// i+1, the kernel of block i and the D2H copy of block i-1 overlap.
-// The staging copies between the caller's pageable raster and the pinned buffers are what bounds the
-// host-buffer form (one thread moves about 10 GB/s; the link moves 50): split them over a few threads.
-static void staged_copy(void *dst, const void *src, size_t bytes)
-{
-    static const int nthreads = [] {
-        const char *e = getenv("OIP_HOST_COPY_THREADS");
-        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        return n < 1 ? 1 : (n > 8 ? 8 : n);
-    }();
-    if (nthreads == 1 || bytes < ((size_t)8 << 20)) { memcpy(dst, src, bytes); return; }
-    const size_t part = (bytes / nthreads + 4095) & ~(size_t)4095;
-    std::vector<std::thread> th;
-    for (int i = 1; i < nthreads; ++i) {
-        const size_t off = (size_t)i * part;
-        if (off >= bytes) break;
-        const size_t n = bytes - off < part ? bytes - off : part;
-        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, n); });
-    }
-    memcpy(dst, src, part < bytes ? part : bytes);
-    for (auto &t : th) t.join();
-}
-
-extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb_host)
-{
-    OIP_CHECK_CTX(ctx);
-    if (w <= 0 || h < 0 || !buff || !kb_host) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16_host: bad argument");
-    if (h == 0) return OIP_OK;
-    OIP_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t row_bytes = (size_t)w * 2;
-    size_t block_bytes = (size_t)64 << 20;
-    long rows_per_chunk = (long)(block_bytes / row_bytes);
-    if (rows_per_chunk < 1) rows_per_chunk = 1;
-    if (rows_per_chunk > h) rows_per_chunk = h;
-    block_bytes = (size_t)rows_per_chunk * row_bytes;
-    if (ctx->stage_bytes < block_bytes) {
-        for (int i = 0; i < 2; ++i) {
-            if (ctx->h_stage[i]) OIP_HIP(ctx, hipHostFree(ctx->h_stage[i]));
-            if (ctx->d_stage[i]) OIP_HIP(ctx, hipFree(ctx->d_stage[i]));
-            ctx->h_stage[i] = ctx->d_stage[i] = nullptr;
-            OIP_HIP(ctx, hipHostMalloc(&ctx->h_stage[i], block_bytes, hipHostMallocDefault));
-            OIP_HIP(ctx, hipMalloc(&ctx->d_stage[i], block_bytes));
-            if (!ctx->stage_stream[i]) OIP_HIP(ctx, hipStreamCreateWithFlags(&ctx->stage_stream[i], hipStreamNonBlocking));
-        }
-        ctx->stage_bytes = block_bytes;
-    }
-    double *d_kb = nullptr;
-    OIP_HIP(ctx, hipMalloc((void **)&d_kb, (size_t)w * 16));
-    OIP_HIP(ctx, hipMemcpy(d_kb, kb_host, (size_t)w * 16, hipMemcpyHostToDevice));
-    hipStream_t saved = ctx->stream;
-    int rc = OIP_OK;
-    long nchunks = (h + rows_per_chunk - 1) / rows_per_chunk;
-    // chunk c uses slot c&1; before reusing a slot, drain it back into the caller's buffer
-    for (long c = 0; c < nchunks + 2 && rc == OIP_OK; ++c) {
-        int slot = (int)(c & 1);
-        if (c >= 2) {
-            long pc = c - 2;
-            long r0 = pc * rows_per_chunk;
-            long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
-            if (hipStreamSynchronize(ctx->stage_stream[slot]) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "stage sync failed"); break; }
-            staged_copy(buff + r0 * (long)w, ctx->h_stage[slot], (size_t)n * row_bytes);
-        }
-        if (c < nchunks) {
-            long r0 = c * rows_per_chunk;
-            long n = (h - r0 < rows_per_chunk) ? h - r0 : rows_per_chunk;
-            staged_copy(ctx->h_stage[slot], buff + r0 * (long)w, (size_t)n * row_bytes);
-            hipStream_t st = ctx->stage_stream[slot];
-            if (hipMemcpyAsync(ctx->d_stage[slot], ctx->h_stage[slot], (size_t)n * row_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "H2D failed"); break; }
-            ctx->stream = st;
-            rc = oip_rrc_u16(ctx, (uint16_t *)ctx->d_stage[slot], (uint16_t *)ctx->d_stage[slot], w, n, d_kb);
-            ctx->stream = saved;
-            if (rc != OIP_OK) break;
-            if (hipMemcpyAsync(ctx->h_stage[slot], ctx->d_stage[slot], (size_t)n * row_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H failed"); break; }
-        }
-    }
-    ctx->stream = saved;
-    hipStreamSynchronize(ctx->stage_stream[0]);
-    hipStreamSynchronize(ctx->stage_stream[1]);
-    hipFree(d_kb);
-    return rc;
-}
+// oip_rrc_u16_host (the host-buffer form of this seam) lives in staging.hip with the rest of the raster I/O staging

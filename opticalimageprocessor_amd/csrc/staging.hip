@@ -1,0 +1,427 @@
+// staging.hip -- raster I/O staging between files / pageable host buffers and HBM.
+//
+// Replaces the staging half of ImageOperations: ReadFileContent (imageop.h:52-82: one heap buffer
+// filled by 8 MiB fread calls), LoadRawImage (:110-127), WriteBufferToFile (:84-97) and the per-section
+// fseek/fread/fwrite of Stitcher::PreStitch (stitcher.h:103-120).  The reference moves every raster
+// through one pageable heap buffer, serially with the arithmetic; here a raster travels in blocks
+// through a ring of pinned buffers on a stream of its own:
+//     file --fread--> pinned slot --DMA--> HBM        (the next block is being read while this one flies)
+//     HBM --DMA--> pinned slot --fwrite--> file
+//     pageable buffer --pool memcpy--> pinned slot --DMA--> HBM   (and back)
+// so disk, host copies, PCIe and the kernels of the context's compute stream overlap.  Staging calls
+// use only the staging stream and ring: they may run on a second host thread while the first one
+// drives kernels through the same context (two staging calls must not overlap each other).  A call
+// returns a TICKET; oip_stage_wait(ctx, ticket) makes the compute stream wait -- on the device, not the
+// host -- for the transfers up to that ticket, and oip_stage_sync(ctx) blocks the host until they are done.
+#include "oip_internal.h"
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+// ---- a small persistent pool for the pageable <-> pinned copies ---------------------------------
+// (one thread moves ~10 GB/s, the link ~55: the copies, not the link, bound a pageable host buffer)
+class CopyPool {
+public:
+    static CopyPool &get()
+    {
+        static CopyPool p;
+        return p;
+    }
+    int threads() const { return (int)mWorkers.size() + 1; }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        const int n = threads();
+        if (n == 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
+        const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+        {
+            std::unique_lock<std::mutex> lk(mMu);
+            mDst = (char *)dst; mSrc = (const char *)src; mBytes = bytes; mPart = part;
+            mPending = (int)mWorkers.size();
+            ++mGen;
+        }
+        mCv.notify_all();
+        memcpy(dst, src, part < bytes ? part : bytes);                 // the caller takes piece 0
+        std::unique_lock<std::mutex> lk(mMu);
+        mDone.wait(lk, [&] { return mPending == 0; });
+    }
+
+private:
+    CopyPool()
+    {
+        const char *e = getenv("OIP_HOST_COPY_THREADS");
+        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        n = n < 1 ? 1 : (n > 16 ? 16 : n);
+        for (int i = 1; i < n; ++i) mWorkers.emplace_back([this, i] { work(i); });
+    }
+    ~CopyPool()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mMu);
+            mStop = true;
+            ++mGen;
+        }
+        mCv.notify_all();
+        for (auto &t : mWorkers) t.join();
+    }
+    void work(int idx)
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mMu);
+            mCv.wait(lk, [&] { return mGen != seen; });
+            seen = mGen;
+            if (mStop) return;
+            char *d = mDst; const char *s = mSrc; const size_t bytes = mBytes, part = mPart;
+            lk.unlock();
+            const size_t off = (size_t)idx * part;
+            if (off < bytes) memcpy(d + off, s + off, bytes - off < part ? bytes - off : part);
+            lk.lock();
+            if (--mPending == 0) mDone.notify_one();
+        }
+    }
+    std::vector<std::thread> mWorkers;
+    std::mutex mMu;
+    std::condition_variable mCv, mDone;
+    unsigned long mGen = 0;
+    int mPending = 0;
+    bool mStop = false;
+    char *mDst = nullptr;
+    const char *mSrc = nullptr;
+    size_t mBytes = 0, mPart = 0;
+};
+
+constexpr int kSlots = 4;
+constexpr size_t kSlotBytes = (size_t)32 << 20;
+constexpr int kTicketRing = 64;
+
+}  // namespace
+
+// the staging state lives behind the context (opaque to the other translation units)
+struct oip_stage_state {
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // second lane of oip_rrc_u16_host (up and down transfers of neighbouring blocks overlap)
+    void *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t slot_free[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // recorded after the DMA that last used the slot
+    bool slot_used[kSlots] = {false, false, false, false};
+    int next = 0;
+    hipEvent_t ticket_ev[kTicketRing];
+    hipEvent_t compute_ev = nullptr;        // marks the compute stream's position for downloads
+    std::atomic<long> ticket{0};
+    // LUT cache of oip_rrc_u16_host
+    double *d_kb = nullptr;
+    std::vector<double> kb_host;
+};
+
+static int stage_init(oip_ctx *ctx)
+{
+    if (ctx->stage) return OIP_OK;
+    OIP_HIP(ctx, hipSetDevice(ctx->device));
+    oip_stage_state *s = new oip_stage_state();
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
+    for (int i = 0; i < kSlots; ++i) {
+        if (hipHostMalloc(&s->slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s->slot_free[i], hipEventDisableTiming) != hipSuccess) {
+            delete s;
+            return oip_fail(ctx, OIP_E_NOMEM, "pinned staging ring (%d x %zu MiB) failed", kSlots, kSlotBytes >> 20);
+        }
+    }
+    for (int i = 0; i < kTicketRing; ++i)
+        if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    ctx->stage = s;
+    return OIP_OK;
+}
+
+void oip_stage_destroy(oip_ctx *ctx)
+{
+    oip_stage_state *s = ctx->stage;
+    if (!s) return;
+    if (s->stream) hipStreamSynchronize(s->stream);
+    if (s->stream2) { hipStreamSynchronize(s->stream2); hipStreamDestroy(s->stream2); }
+    for (int i = 0; i < kSlots; ++i) { if (s->slot[i]) hipHostFree(s->slot[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
+    for (int i = 0; i < kTicketRing; ++i) hipEventDestroy(s->ticket_ev[i]);
+    if (s->compute_ev) hipEventDestroy(s->compute_ev);
+    if (s->d_kb) hipFree(s->d_kb);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    ctx->stage = nullptr;
+}
+
+// next ring slot, once the DMA that last read or wrote it has finished
+static int slot_acquire(oip_ctx *ctx, oip_stage_state *s, int *out)
+{
+    const int i = s->next;
+    s->next = (s->next + 1) % kSlots;
+    if (s->slot_used[i]) OIP_HIP(ctx, hipEventSynchronize(s->slot_free[i]));
+    *out = i;
+    return OIP_OK;
+}
+
+static long ticket_issue(oip_ctx *ctx, oip_stage_state *s)
+{
+    const long t = s->ticket.load() + 1;
+    hipEventRecord(s->ticket_ev[t % kTicketRing], s->stream);
+    s->ticket.store(t);
+    return t;
+}
+
+// uploads must see what the compute stream wrote before (and vice versa for downloads): the staging stream
+// waits for the compute stream's work enqueued so far
+static int order_after_compute(oip_ctx *ctx, oip_stage_state *s)
+{
+    hipEvent_t e = s->compute_ev;
+    OIP_HIP(ctx, hipEventRecord(e, ctx->stream));
+    OIP_HIP(ctx, hipStreamWaitEvent(s->stream, e, 0));
+    return OIP_OK;
+}
+
+extern "C" int oip_stage_wait(oip_ctx *ctx, long ticket)
+{
+    if (!ctx) return OIP_E_INVALID;
+    oip_stage_state *s = ctx->stage;
+    if (!s || ticket <= 0) return OIP_OK;
+    const long now = s->ticket.load();
+    if (ticket > now) return oip_fail(ctx, OIP_E_INVALID, "oip_stage_wait: ticket %ld not issued yet", ticket);
+    // an old ticket whose event was recycled is implied by any later one on the same stream
+    const long use = now - ticket >= kTicketRing - 2 ? now : ticket;
+    OIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ticket_ev[use % kTicketRing], 0));
+    return OIP_OK;
+}
+
+extern "C" int oip_stage_sync(oip_ctx *ctx)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (ctx->stage) OIP_HIP(ctx, hipStreamSynchronize(ctx->stage->stream));
+    return OIP_OK;
+}
+
+extern "C" int oip_stage_threads(void) { return CopyPool::get().threads(); }
+
+// ---- file <-> device -------------------------------------------------------------------------------
+extern "C" int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t offset, size_t bytes, void *d_dst,
+                                       size_t *bytes_read, long *ticket)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!path || (!d_dst && bytes)) return oip_fail(ctx, OIP_E_INVALID, "oip_read_file_to_device: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    FILE *f = fopen(path, "rb");
+    if (!f) return oip_fail(ctx, OIP_E_INVALID, "cannot open file [%s]: %d", path, errno);      // imageop.h:55-57
+    if (bytes == 0) {                                                                            // all available (imageop.h:59-63)
+        if (fseeko(f, 0, SEEK_END)) { fclose(f); return oip_fail(ctx, OIP_E_INVALID, "ReadFileContent(): seek2end failed"); }
+        const off_t end = ftello(f);
+        bytes = (size_t)end > offset ? (size_t)end - offset : 0;
+    }
+    if (fseeko(f, (off_t)offset, SEEK_SET)) { fclose(f); return oip_fail(ctx, OIP_E_INVALID, "ReadFileContent(): rewind failed"); }
+    size_t done = 0;
+    while (done < bytes) {
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) { fclose(f); return rc; }
+        const size_t want = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
+        size_t got = 0;
+        while (got < want) {                                                                     // imageop.h:69-79, 8 MiB units
+            const size_t unit = want - got < ((size_t)8 << 20) ? want - got : ((size_t)8 << 20);
+            const size_t rn = fread((char *)s->slot[i] + got, 1, unit, f);
+            got += rn;
+            if (rn == 0) break;
+        }
+        if (got) {
+            if (hipMemcpyAsync((char *)d_dst + done, s->slot[i], got, hipMemcpyHostToDevice, s->stream) != hipSuccess) {
+                fclose(f);
+                return oip_fail(ctx, OIP_E_DEVICE, "H2D of a staged block failed");
+            }
+            hipEventRecord(s->slot_free[i], s->stream);
+            s->slot_used[i] = true;
+        }
+        done += got;
+        if (got < want) break;                                                                   // short file
+    }
+    fclose(f);
+    if (bytes_read) *bytes_read = done;
+    const long t = ticket_issue(ctx, s);
+    if (ticket) *ticket = t;
+    else OIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ticket_ev[t % kTicketRing], 0));        // no ticket wanted: order the compute stream now
+    return OIP_OK;
+}
+
+extern "C" int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!path || (!d_src && bytes)) return oip_fail(ctx, OIP_E_INVALID, "oip_write_device_to_file: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    FILE *f = fopen(path, append ? "ab" : "wb");
+    if (!f) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);      // imageop.h:86-88
+    if ((rc = order_after_compute(ctx, s))) { fclose(f); return rc; }
+    // block k's DMA is in flight while block k-1 is written
+    int prev = -1;
+    size_t prev_bytes = 0, done = 0;
+    auto flush = [&](int i, size_t n) -> int {
+        if (hipEventSynchronize(s->slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        size_t w = 0;
+        while (w < n) {                                                                          // imageop.h:88-95, 8 MiB units
+            const size_t unit = n - w < ((size_t)8 << 20) ? n - w : ((size_t)8 << 20);
+            const size_t wb = fwrite((const char *)s->slot[i] + w, 1, unit, f);
+            if (wb == 0) return oip_fail(ctx, OIP_E_RUNTIME, "write file failed: %d", errno);
+            w += wb;
+        }
+        return OIP_OK;
+    };
+    while (done < bytes) {
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) break;
+        const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
+        if (hipMemcpyAsync(s->slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream) != hipSuccess) {
+            rc = oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+            break;
+        }
+        hipEventRecord(s->slot_free[i], s->stream);
+        s->slot_used[i] = true;
+        if (prev >= 0 && (rc = flush(prev, prev_bytes))) break;
+        prev = i; prev_bytes = n;
+        done += n;
+    }
+    if (rc == OIP_OK && prev >= 0) rc = flush(prev, prev_bytes);
+    if (fclose(f) != 0 && rc == OIP_OK) rc = oip_fail(ctx, OIP_E_RUNTIME, "close file [%s] failed: %d", path, errno);
+    return rc;
+}
+
+// ---- pageable host buffer <-> device ---------------------------------------------------------------
+extern "C" int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes, long *ticket)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if ((!d_dst || !host) && bytes) return oip_fail(ctx, OIP_E_INVALID, "oip_upload_staged: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    size_t done = 0;
+    while (done < bytes) {
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) return rc;
+        const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
+        CopyPool::get().copy(s->slot[i], (const char *)host + done, n);
+        OIP_HIP(ctx, hipMemcpyAsync((char *)d_dst + done, s->slot[i], n, hipMemcpyHostToDevice, s->stream));
+        hipEventRecord(s->slot_free[i], s->stream);
+        s->slot_used[i] = true;
+        done += n;
+    }
+    const long t = ticket_issue(ctx, s);
+    if (ticket) *ticket = t;
+    else OIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ticket_ev[t % kTicketRing], 0));
+    return OIP_OK;
+}
+
+extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if ((!d_src || !host) && bytes) return oip_fail(ctx, OIP_E_INVALID, "oip_download_staged: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    if ((rc = order_after_compute(ctx, s))) return rc;
+    int prev = -1;
+    size_t prev_bytes = 0, prev_off = 0, done = 0;
+    auto drain = [&](int i, size_t off, size_t n) -> int {
+        if (hipEventSynchronize(s->slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        CopyPool::get().copy((char *)host + off, s->slot[i], n);
+        return OIP_OK;
+    };
+    while (done < bytes) {
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) return rc;
+        const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
+        OIP_HIP(ctx, hipMemcpyAsync(s->slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream));
+        hipEventRecord(s->slot_free[i], s->stream);
+        s->slot_used[i] = true;
+        if (prev >= 0 && (rc = drain(prev, prev_off, prev_bytes))) return rc;
+        prev = i; prev_off = done; prev_bytes = n;
+        done += n;
+    }
+    if (prev >= 0) rc = drain(prev, prev_off, prev_bytes);
+    return rc;
+}
+
+// ---- IMO::InplaceRRC on the reference's heap buffer (imageop.h:129-138 as DoRRC4RAW calls it, :194-228) -----------
+// In place on a pageable raster: block k+1 goes up, block k is corrected and block k-1 comes down at the same time;
+// the LUT is uploaded once per distinct table (cached), the host copies run on the persistent pool.
+extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb_host)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || h < 0 || !buff || !kb_host) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16_host: bad argument");
+    if (h == 0) return OIP_OK;
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    OIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->kb_host.size() != (size_t)w * 2 || memcmp(s->kb_host.data(), kb_host, sizeof(double) * 2 * w) != 0) {
+        OIP_HIP(ctx, hipStreamSynchronize(s->stream));
+        if (s->d_kb) OIP_HIP(ctx, hipFree(s->d_kb));
+        s->d_kb = nullptr;
+        OIP_HIP(ctx, hipMalloc((void **)&s->d_kb, (size_t)w * 16));
+        OIP_HIP(ctx, hipMemcpy(s->d_kb, kb_host, (size_t)w * 16, hipMemcpyHostToDevice));
+        s->kb_host.assign(kb_host, kb_host + (size_t)w * 2);
+    }
+    const size_t row_bytes = (size_t)w * 2;
+    long rows = (long)(kSlotBytes / row_bytes);
+    if (rows < 1) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_rrc_u16_host: a line exceeds the staging block");
+    if (rows > h) rows = h;
+    const size_t block = (size_t)rows * row_bytes;
+    // device blocks: two, inside the context's staging allocations
+    if (ctx->stage_bytes < block) {
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->d_stage[i]) OIP_HIP(ctx, hipFree(ctx->d_stage[i]));
+            ctx->d_stage[i] = nullptr;
+            OIP_HIP(ctx, hipMalloc(&ctx->d_stage[i], block));
+        }
+        ctx->stage_bytes = block;
+    }
+    hipStream_t saved = ctx->stream;
+    const long nchunks = (h + rows - 1) / rows;
+    // per chunk: pinned slot up -> device block (slot c & 1) -> kernel -> same pinned slot down; the ring has four
+    // pinned slots, so the host copies of chunk c+1 (in) and c-1 (out) run while chunk c is on the device
+    int slot_of[3] = {-1, -1, -1};
+    long chunk_of[3] = {-1, -1, -1};
+    auto drain = [&](int k) -> int {          // bring chunk chunk_of[k] home
+        if (chunk_of[k] < 0) return OIP_OK;
+        const long c = chunk_of[k];
+        const long r0 = c * rows, n = h - r0 < rows ? h - r0 : rows;
+        if (hipEventSynchronize(s->slot_free[slot_of[k]]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "staged RRC block failed");
+        CopyPool::get().copy(buff + r0 * (long)w, s->slot[slot_of[k]], (size_t)n * row_bytes);
+        chunk_of[k] = -1;
+        return OIP_OK;
+    };
+    for (long c = 0; c < nchunks && rc == OIP_OK; ++c) {
+        const int k = (int)(c % 3);
+        if ((rc = drain(k))) break;                                   // chunk c-3 (its slot is about to be reused)
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) break;
+        const long r0 = c * rows, n = h - r0 < rows ? h - r0 : rows;
+        const size_t nb = (size_t)n * row_bytes;
+        CopyPool::get().copy(s->slot[i], buff + r0 * (long)w, nb);
+        void *d = ctx->d_stage[c & 1];
+        hipStream_t st = (c & 1) ? s->stream2 : s->stream;          // device block and stream alternate: neighbours overlap
+        if (hipMemcpyAsync(d, s->slot[i], nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "H2D failed"); break; }
+        ctx->stream = st;
+        rc = oip_rrc_u16(ctx, (uint16_t *)d, (uint16_t *)d, w, n, s->d_kb);
+        ctx->stream = saved;
+        if (rc != OIP_OK) break;
+        if (hipMemcpyAsync(s->slot[i], d, nb, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H failed"); break; }
+        hipEventRecord(s->slot_free[i], st);
+        s->slot_used[i] = true;
+        slot_of[k] = i; chunk_of[k] = c;
+        // bring home the chunk before this one while this one is on the device
+        if (c >= 1 && (rc = drain((int)((c - 1) % 3)))) break;
+    }
+    ctx->stream = saved;
+    for (int k = 0; k < 3 && rc == OIP_OK; ++k) rc = drain(k);
+    if (rc != OIP_OK) { hipStreamSynchronize(s->stream); hipStreamSynchronize(s->stream2); }
+    return rc;
+}

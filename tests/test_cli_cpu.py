@@ -57,27 +57,48 @@ def test_runtime_errors_exit_2(files):
     assert r.returncode == 2 and "PAN file size does not match MSS file size" in r.stdout
 
 
-def test_tiff_writer_roundtrip(tmp_path):
-    """csrc/oip_tiff.hpp through a tiny driver: classic TIFF, 1 and 4 samples, odd sizes, many strips"""
-    import numpy as np
-    import _tiff
+def _tiff_tool(tmp_path):
+    """tiny driver around csrc/oip_tiff.hpp: `t write OUT W H SPP COMP` (deterministic content) and
+    `t read IN RAWOUT [REWRITE COMP]`"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "t.cpp"
-    src.write_text('#include "oip_tiff.hpp"\n#include <cstdlib>\n#include <vector>\nint main(int c, char** v){int w=atoi(v[2]);long h=atol(v[3]);int s=atoi(v[4]);'
-                   'std::vector<uint16_t> d((size_t)w*h*s);for(size_t i=0;i<d.size();++i)d[i]=(uint16_t)(i*2654435761u>>7);'
-                   'OIPGPU::write_tiff_u16(v[1],d.data(),w,h,s,s==4);return 0;}\n')
+    src.write_text('#include "oip_tiff.hpp"\n#include <cstdlib>\n#include <cstring>\n#include <vector>\n'
+                   'int main(int c, char** v){try{if(!strcmp(v[1],"write")){int w=atoi(v[3]);long h=atol(v[4]);int s=atoi(v[5]);int comp=atoi(v[6]);'
+                   'std::vector<uint16_t> d((size_t)w*h*s);for(size_t i=0;i<d.size();++i)d[i]=(uint16_t)((i*2654435761u>>7)&(comp==5?0x0fff:0xffff));'
+                   'OIPGPU::write_tiff_u16(v[2],d.data(),w,h,s,s==4,comp);return 0;}'
+                   'int w,s;long h;std::vector<uint16_t> d;OIPGPU::read_tiff_u16(v[2],&w,&h,&s,&d);'
+                   'if(c>5){OIPGPU::write_tiff_u16(v[4],d.data(),w,h,s,false,atoi(v[5]));}'
+                   'FILE*f=fopen(v[3],"wb");fwrite(d.data(),2,d.size(),f);fclose(f);printf("%d %ld %d\\n",w,h,s);return 0;}'
+                   'catch(std::exception&e){printf("ERR %s\\n",e.what());return 3;}}\n')
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)],
+                   check=True)
+    return exe
+
+
+@pytest.mark.parametrize("comp", [1, 5])
+def test_tiff_writer_roundtrip(tmp_path, comp):
+    """csrc/oip_tiff.hpp writer: classic TIFF, 1 and 4 samples, odd sizes, many strips; uncompressed and LZW with the
+    horizontal predictor (what cv::imwrite and the reference's GDAL call produce).  Checked by the independent
+    Python decoder of tests/_tiff.py and, for 1-band files, by Pillow (libtiff)."""
+    import numpy as np
+    import _tiff
+    exe = _tiff_tool(tmp_path)
     for w, h, spp in [(7, 5, 1), (1001, 333, 4), (3000, 3000, 1), (7500, 700, 4)]:
+        if comp == 5 and w * h * spp > 300_000:
+            h = max(1, 300_000 // (w * spp))                # the Python LZW decoder is slow
         out = tmp_path / ("o_%d_%d_%d.tiff" % (w, h, spp))
-        subprocess.run([str(exe), str(out), str(w), str(h), str(spp)], check=True)
+        subprocess.run([str(exe), "write", str(out), str(w), str(h), str(spp), str(comp)], check=True)
         img, tags, big = _tiff.read_tiff_u16(str(out))
+        assert tags[259] == [comp] and tags.get(317, [1]) == ([2] if comp == 5 else [1])
         n = w * h * spp
-        want = ((np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)) >> 7).astype(np.uint16)
+        want = (((np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)) >> 7) & (0x0fff if comp == 5 else 0xffff)).astype(np.uint16)
         want = want.reshape(h, w, spp) if spp > 1 else want.reshape(h, w)
         if spp == 4:
             want = want[:, :, [2, 1, 0, 3]]
         assert not big and np.array_equal(img, want), (w, h, spp)
+        if comp == 5 and n > 100000:
+            assert os.path.getsize(out) < n * 2                     # it did compress the 12-bit data
         if spp == 1:
             from PIL import Image
             with Image.open(str(out)) as im:
@@ -85,44 +106,77 @@ def test_tiff_writer_roundtrip(tmp_path):
 
 
 def test_tiff_reader(tmp_path):
-    """oip_tiff.hpp reader: its own files, a foreign uncompressed file, and a refused LZW file"""
+    """oip_tiff.hpp reader: its own files (both compressions), foreign uncompressed files, LZW files written by Pillow
+    (libtiff; predictor 1 and 2) and by the independent Python encoder (4 samples, predictor 2, one row per strip
+    like cv::imwrite writes wide images); malformed headers fail cleanly."""
     import numpy as np
     import _tiff
     from PIL import Image
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = tmp_path / "r.cpp"
-    src.write_text('#include "oip_tiff.hpp"\n#include <cstdlib>\n#include <vector>\nint main(int c, char** v){int w,s;long h;std::vector<uint16_t> d;'
-                   'try{OIPGPU::read_tiff_u16(v[1],&w,&h,&s,&d);}catch(std::exception&e){printf("ERR %s\\n",e.what());return 3;}'
-                   'if(c>3){OIPGPU::write_tiff_u16(v[3],d.data(),w,h,s,false);}'
-                   'FILE*f=fopen(v[2],"wb");fwrite(d.data(),2,d.size(),f);fclose(f);printf("%d %ld %d\\n",w,h,s);return 0;}\n')
-    exe = tmp_path / "r"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    exe = _tiff_tool(tmp_path)
     rng = np.random.default_rng(3)
     for shape in [(5, 7), (333, 1001, 4), (900, 7500, 4)]:
         a = rng.integers(0, 65536, shape).astype(np.uint16)
         p = tmp_path / "in.tiff"
         _tiff.write_tiff_u16(str(p), a)
-        r = subprocess.run([str(exe), str(p), str(tmp_path / "o.raw"), str(tmp_path / "rt.tiff")], capture_output=True, text=True)
+        for comp in (1, 5):
+            r = subprocess.run([str(exe), "read", str(p), str(tmp_path / "o.raw"), str(tmp_path / "rt.tiff"), str(comp)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout
+            w, h, s = map(int, r.stdout.split())
+            assert (h, w) == shape[:2] and s == (shape[2] if len(shape) == 3 else 1)
+            assert np.array_equal(np.fromfile(tmp_path / "o.raw", np.uint16).reshape(shape), a)
+            # written again by the C++ writer (many strips for the large case) and read back by the C++ reader
+            r = subprocess.run([str(exe), "read", str(tmp_path / "rt.tiff"), str(tmp_path / "o2.raw")], capture_output=True, text=True)
+            assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o2.raw", np.uint16).reshape(shape), a)
+            if comp == 1 or a.size < 200000:
+                back, _, _ = _tiff.read_tiff_u16(str(tmp_path / "rt.tiff"))
+                assert np.array_equal(back.reshape(shape), a)
+    # Pillow (libtiff) writes 16-bit gray: uncompressed, LZW, LZW + horizontal predictor
+    g = (rng.integers(0, 4096, (240, 500)) + np.arange(500) * 3).astype(np.uint16)
+    for name, kw in (("pil.tiff", {}), ("lzw.tiff", {"compression": "tiff_lzw"}),
+                     ("lzwp.tiff", {"compression": "tiff_lzw", "tiffinfo": {317: 2}})):
+        Image.fromarray(g).save(str(tmp_path / name), **kw)
+        r = subprocess.run([str(exe), "read", str(tmp_path / name), str(tmp_path / "o3.raw")], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stdout)
+        assert np.array_equal(np.fromfile(tmp_path / "o3.raw", np.uint16).reshape(g.shape), g), name
+    # what cv::imwrite produces for an ALIGNED image: 4 samples, LZW, predictor 2, a handful of rows per strip
+    a4 = (rng.integers(0, 4096, (37, 411, 4)) + np.arange(411)[None, :, None]).astype(np.uint16)
+    for pred, rps in ((2, 1), (2, 5), (1, 37)):
+        _tiff.write_tiff_u16(str(tmp_path / "cv.tiff"), a4, lzw=True, predictor=pred, rows_per_strip=rps)
+        r = subprocess.run([str(exe), "read", str(tmp_path / "cv.tiff"), str(tmp_path / "o4.raw")], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout
-        w, h, s = map(int, r.stdout.split())
-        assert (h, w) == shape[:2] and s == (shape[2] if len(shape) == 3 else 1)
-        assert np.array_equal(np.fromfile(tmp_path / "o.raw", np.uint16).reshape(shape), a)
-        # written again by the C++ writer (many strips for the large case) and read back by both readers
-        back, _, _ = _tiff.read_tiff_u16(str(tmp_path / "rt.tiff"))
-        assert np.array_equal(back.reshape(shape), a)
-        r = subprocess.run([str(exe), str(tmp_path / "rt.tiff"), str(tmp_path / "o2.raw")], capture_output=True, text=True)
-        assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o2.raw", np.uint16).reshape(shape), a)
-    # Pillow writes 16-bit gray; uncompressed is accepted, LZW is refused with a clear message
-    g = rng.integers(0, 65536, (40, 50)).astype(np.uint16)
-    Image.fromarray(g).save(str(tmp_path / "pil.tiff"))
-    r = subprocess.run([str(exe), str(tmp_path / "pil.tiff"), str(tmp_path / "o3.raw")], capture_output=True, text=True)
-    assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o3.raw", np.uint16).reshape(40, 50), g)
-    Image.fromarray(g).save(str(tmp_path / "lzw.tiff"), compression="tiff_lzw")
-    r = subprocess.run([str(exe), str(tmp_path / "lzw.tiff"), str(tmp_path / "o4.raw")], capture_output=True, text=True)
-    assert r.returncode == 3 and "compressed TIFF input" in r.stdout
+        assert np.array_equal(np.fromfile(tmp_path / "o4.raw", np.uint16).reshape(a4.shape), a4), (pred, rps)
+    # long runs force the 12-bit table to fill and clear several times
+    flat = np.zeros((24, 4096), np.uint16); flat[::7] = 4095; flat[:, ::501] = 17
+    _tiff.write_tiff_u16(str(tmp_path / "runs.tiff"), flat, lzw=True, predictor=1, rows_per_strip=24)
+    r = subprocess.run([str(exe), "read", str(tmp_path / "runs.tiff"), str(tmp_path / "o5.raw"), str(tmp_path / "runs2.tiff"), "5"], capture_output=True, text=True)
+    assert r.returncode == 0 and np.array_equal(np.fromfile(tmp_path / "o5.raw", np.uint16).reshape(flat.shape), flat)
+    with Image.open(str(tmp_path / "runs2.tiff")) as im:           # the C++ LZW stream through libtiff
+        assert np.array_equal(np.asarray(im), flat)
+    # malformed input: clean failures, no crash
     (tmp_path / "bad.tiff").write_bytes(b"not a tiff at all")
-    r = subprocess.run([str(exe), str(tmp_path / "bad.tiff"), str(tmp_path / "o5.raw")], capture_output=True, text=True)
-    assert r.returncode == 3
+    good = (tmp_path / "pil.tiff").read_bytes()
+    import struct
+    ifd = struct.unpack_from("<I", good, 4)[0]
+    nent = struct.unpack_from("<H", good, ifd)[0]
+
+    def patched(tag, field_off, fmt, value):
+        b = bytearray(good)
+        for i in range(nent):
+            o = ifd + 2 + 12 * i
+            if struct.unpack_from("<H", b, o)[0] == tag:
+                struct.pack_into(fmt, b, o + field_off, value)
+        return bytes(b)
+
+    cases = {"bad.tiff": b"not a tiff at all",
+             "hugecount.tiff": patched(279, 4, "<I", 0xFFFFFFFF),         # StripByteCounts count
+             "hugelen.tiff": patched(279, 8, "<I", 0xFFFFFFF0),           # a strip longer than the file
+             "hugew.tiff": patched(256, 8, "<I", 0xFFFFFFFF),             # width that overflows the image size
+             "zerocount.tiff": patched(273, 4, "<I", 0),                  # tag with count 0
+             "trunc.tiff": good[: len(good) // 2]}
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        r = subprocess.run([str(exe), "read", str(tmp_path / name), str(tmp_path / "o6.raw")], capture_output=True, text=True)
+        assert r.returncode == 3 and r.stdout.startswith("ERR"), (name, r.returncode, r.stdout)
 
 
 def test_task_subcommand_argument_errors(files):

@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--fp16-accumulate", action="store_true",
                     help="prestitch: the fp16-accumulate resampling variant (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive pass from pageable host buffers")
     return ap.parse_args()
 
 
@@ -184,6 +185,75 @@ def cpu_baseline(W, L, slices, sections):
         "rrc_reference_1thread_Mpix_s": rrc_mpix_1t,
         "rrc_all_cores_Mpix_s": rrc_mpix_mt, "rrc_all_cores": cores,
     }
+
+
+def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, threshold, reps=3):
+    """PCIe-inclusive pass of the default action on one GPU: the raw rasters start in PAGEABLE host memory (the
+    reference's heap buffers, imageop.h:52-82) and the aligned image ends in pageable host memory; file I/O is not
+    included.  Uploads run on a second host thread through the staging ring (oip_upload_staged), MSS first, then the
+    PAN strip in line blocks; each block is corrected as it lands, and a correlation section is computed as soon as its
+    lines are resident -- so H2D, the RRC kernels and the FFT correlation overlap; the fit, the align kernel and the
+    staged download of the aligned image follow.  Results are the bits of the HBM-resident step (same unit pairs)."""
+    import queue
+    import threading
+    import torch
+    import opticalimageprocessor_amd as oip
+    W, pb, mb = plan.W, plan.pb, plan.mb
+    host_pan = np.empty((pb, W), np.uint16); host_mss = np.empty((mb, W), np.uint16)
+    ctx.download_staged(host_pan, raw_pan); ctx.download_staged(host_mss, raw_mss)
+    host_out = np.empty(tuple(out.shape), np.uint16)
+    nblk = 16
+    edges = [pb * i // nblk // 4 * 4 for i in range(nblk + 1)]
+    times = []
+    for rep in range(reps):
+        raw_pan.zero_(); raw_mss.zero_(); out.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q = queue.Queue()
+
+        def uploader():
+            q.put(("mss", ctx.upload_staged(raw_mss, host_mss, want_ticket=True)))
+            for i in range(nblk):
+                a, b = edges[i], edges[i + 1]
+                q.put((i, ctx.upload_staged(raw_pan, host_pan[a:b], want_ticket=True, byte_offset=a * W * 2)))
+        th = threading.Thread(target=uploader)
+        th.start()
+        _, t = q.get()
+        ctx.stage_wait(t)
+        ctx.mss_split_rrc_u16(raw_mss, bufs.planes.data_ptr() + 2 * bufs.own_planes_offset(), bufs.plane_stride, W, mb, d_kb_mss)
+        shifts = np.full((4, plan.n_units, 4), np.nan)
+        for u in range(plan.n_units):
+            shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2
+        next_sec = 0
+        for i in range(nblk):
+            _, t = q.get()
+            ctx.stage_wait(t)
+            a, b = edges[i], edges[i + 1]
+            ctx.rrc_u16(raw_pan.data_ptr() + a * W * 2, bufs.pan.data_ptr() + a * W * 2, W, b - a, d_kb_pan)
+            while next_sec < plan.sections and plan.section(next_sec)[1] <= b:
+                units = range(next_sec * plan.slices, (next_sec + 1) * plan.slices)
+                wins = [bufs.unit_windows(u) for u in units]
+                res = ctx.interband_correlate_units([w[0].data_ptr() for w in wins], [w[0].stride(0) for w in wins],
+                                                    [[x.data_ptr() for x in w[1]] for w in wins], [w[1][0].stride(0) for w in wins],
+                                                    plan.base_rows, plan.base_cols)
+                for j, u in enumerate(units):
+                    shifts[:, u, :3] = res[j]
+                next_sec += 1
+        th.join()
+        cx, cy = oip.filter_and_fit(shifts, threshold, 5)
+        o0, o1 = plan.align_out_rows(0)
+        ctx.align_mss_bicubic_u16x4(bufs.planes.data_ptr() + 2 * bufs.own_planes_offset(), bufs.plane_stride, out, W // 4, plan.Lm, cx, cy,
+                                    plan.lps, plan.line_offset, plan.overlap, plan.keep, plan.min_lines)
+        ctx.download_staged(host_out, out)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    pix = 1.25 * W * pb
+    return {"value": pix / best / 1e6, "unit": "Mpix/s", "ms_per_pass": best * 1e3, "passes": reps,
+            "bytes_up": int(host_pan.nbytes + host_mss.nbytes), "bytes_down": int(host_out.nbytes),
+            "host_copy_threads": oip.load_library().oip_stage_threads(),
+            "what": "pageable host rasters -> pinned staging ring -> H2D (PAN in %d line blocks, on a second thread) || RRC per "
+                    "block || correlation per section as its lines land -> fit -> align -> staged D2H of the aligned image into "
+                    "pageable memory; file I/O excluded; best of %d" % (nblk, reps)}, (cx, cy)
 
 
 def main():
@@ -399,6 +469,15 @@ def main():
             pass        # CPU baseline for this workload: see DESIGN.md (oracle remap is measured in the tests)
         elif world == 1 and not args.no_cpu_baseline and args.workload in ("default", "weak5n"):
             line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
+        if world == 1 and args.workload == "default" and not args.no_end_to_end:
+            e2e, (ecx, ecy) = end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, threshold)
+            e2e["same_fit_as_resident_step"] = bool(np.array_equal(ecx, info["cx"]) and np.array_equal(ecy, info["cy"]))
+            # the host-buffer form of the RRC seam alone (IMO::InplaceRRC on DoRRC4RAW's heap buffer), in place
+            hb = np.random.default_rng(2).integers(64, 4096, (32768, W), dtype=np.uint16)
+            ctx.rrc_u16_host(hb[:2048], kb_pan)
+            t1 = time.perf_counter(); ctx.rrc_u16_host(hb, kb_pan); dt = time.perf_counter() - t1
+            e2e["rrc_host_buffer_Gpix_s"] = hb.size / dt / 1e9
+            line["end_to_end"] = e2e
         elif world == 1 and not args.no_cpu_baseline:
             import oracle
             img = np.random.default_rng(1).integers(64, 4096, (4096, W), dtype=np.uint16)

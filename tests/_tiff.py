@@ -83,7 +83,12 @@ def lzw_encode(data: bytes) -> bytes:
     return bytes(out)
 
 
-def read_tiff_u16(path):
+def read_tags(path):
+    """directory only (no pixel decoding)"""
+    return read_tiff_u16(path, tags_only=True)[1]
+
+
+def read_tiff_u16(path, tags_only=False):
     with open(path, "rb") as f:
         buf = f.read()
     assert buf[:2] == b"II"
@@ -110,6 +115,8 @@ def read_tiff_u16(path):
         if cnt * tsize[typ] > osz:
             voff = struct.unpack_from(ofmt, buf, voff)[0]
         tags[tid] = [struct.unpack_from(tfmt[typ], buf, voff + k * tsize[typ])[0] for k in range(cnt)]
+    if tags_only:
+        return None, tags, big
     w, h, spp = tags[256][0], tags[257][0], tags.get(277, [1])[0]
     assert tags[258] == [16] * spp and tags[259][0] in (1, 5) and tags.get(284, [1]) == [1] and tags.get(339, [1] * spp) == [1] * spp
     strips = [buf[o:o + c] for o, c in zip(tags[273], tags[279])]

@@ -30,7 +30,9 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     import opticalimageprocessor_amd as oip
     W, L, OV = 1024, 33024, 64
     d = str(tmp_path)
-    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"))
+    # the strip-sized TIFF products are written uncompressed here so that the independent Python reader can check their
+    # pixels (its LZW decoder is slow); the reference's LZW products are exercised at the end of this test
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_TIFF_COMPRESS="none")
     pan1, pan2 = _synth.ccd_pair(L, W, OV, (3, -2), seed=5)
     kb1, kb2 = _synth.lut(W, 1), _synth.lut(W, 2)
     pan1.tofile(os.path.join(d, "S_PAN-1.RAW")); pan2.tofile(os.path.join(d, "S_PAN-2.RAW"))
@@ -100,8 +102,6 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     assert "%d lines valid" % nvalid in r.stdout
 
     # ---- step 4: stitch two aligned 4-channel TIFFs (imageop.h:365-457; -g/-m: :460-567)
-    import shutil
-    shutil.copy(os.path.join(d, "T_MSS.ALIGNED.TIFF"), os.path.join(d, "T2_MSS.ALIGNED.TIFF"))
     rolled = np.roll(tif, 7, axis=0)                         # a second, different image in file order
     _tiff.write_tiff_u16(os.path.join(d, "T2_MSS.ALIGNED.TIFF"), rolled)
     r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "--fold-cols", "12",
@@ -120,6 +120,21 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "-g", "-m", "3,2,9,4",
                         "--fold-cols", "12", "-o", "x.TIFF"], cwd=d, env=env, capture_output=True, text=True)
     assert r.returncode == 105
+    # ---- the reference's own product format: LZW + horizontal predictor (cv::imwrite, GDAL COMPRESS=LZW PREDICTOR=2).
+    # The same stitch with the default policy writes LZW; feeding LZW files back in gives the same pixels.
+    env_ref = dict(env)
+    del env_ref["OIP_TIFF_COMPRESS"]
+    r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T2_MSS.ALIGNED.TIFF", "--fold-cols", "12",
+                        "-o", "stitched-MSS-lzw.TIFF"], cwd=d, env=env_ref, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tg = _tiff.read_tags(os.path.join(d, "stitched-MSS-lzw.TIFF"))
+    assert tg[259] == [5] and tg[317] == [2] and _tiff.read_tags(os.path.join(d, "stitched-MSS.TIFF"))[259] == [1]
+    small = os.path.join(d, "lzw-a.TIFF")
+    r = subprocess.run([OIP, "stitch", "--image1", "stitched-MSS-lzw.TIFF", "--image2", "stitched-MSS-lzw.TIFF", "--fold-cols", "2",
+                        "--tiff-compress", "none", "-o", "lzw-a.TIFF"], cwd=d, env=env_ref, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    twice, _, _ = _tiff.read_tiff_u16(small)
+    assert np.array_equal(twice, np.concatenate([out[:, :out.shape[1] - 1], out[:, 1:]], axis=1))
 
 
 def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
@@ -157,11 +172,14 @@ def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
     # ---- the reference's flow: five commands, six intermediate files
     t0 = time.time()
     run(["prestitch", "--width", str(W), "--pan1", "A_PAN-1.RAW", "--pan2", "A_PAN-2.RAW", "--rrc1", "P1.csv", "--rrc2", "P2.csv"] + stt)
-    run(["stitch", "--width", str(W), "--image1", "A_PAN-1.RRC.RAW", "--image2", "A_PAN-2.RRC.PRESTT.RAW", "--fold-cols", "40", "-o", "ref-PAN.TIFF"])
+    # (the ALIGNED.TIFF intermediates carry the reference's LZW + predictor encoding and are read back by `stitch`; the final
+    # products are written uncompressed so that the independent Python reader can compare them quickly)
+    plain = ["--tiff-compress", "none"]
+    run(["stitch", "--width", str(W), "--image1", "A_PAN-1.RRC.RAW", "--image2", "A_PAN-2.RRC.PRESTT.RAW", "--fold-cols", "40", "-o", "ref-PAN.TIFF"] + plain)
     for c, s1 in ((1, "A_PAN-1.RRC.RAW"), (2, "A_PAN-2.RRC.PRESTT.RAW")):
         run(["--width", str(W), "--pan", s1, "--mss", "A_MSS-%d.RAW" % c] + ibc + sum([["--rrc-msb%d" % (b + 1), "M%dB%d.csv" % (c, b + 1)] for b in range(4)], []))
-    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-o", "ref-MSS.TIFF"])
-    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-g", "-m", "3,2,1,4", "-o", "ref-MSS-g.TIFF"])
+    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-o", "ref-MSS.TIFF"] + plain)
+    run(["stitch", "--image1", "A_MSS-1.ALIGNED.TIFF", "--image2", "A_MSS-2.ALIGNED.TIFF", "--fold-cols", "12", "-g", "-m", "3,2,1,4", "-o", "ref-MSS-g.TIFF"] + plain)
     t_ref = time.time() - t0
 
     # ---- the fused task
@@ -171,9 +189,9 @@ def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
         for b in range(4):
             task += ["--rrc-mss%d-b%d" % (c, b + 1), "M%dB%d.csv" % (c, b + 1)]
     t0 = time.time()
-    run(task + ["--out-pan", "fused-PAN.TIFF", "--out-mss", "fused-MSS.TIFF"])
+    run(task + ["--out-pan", "fused-PAN.TIFF", "--out-mss", "fused-MSS.TIFF"] + plain)
     t_fused = time.time() - t0
-    run(task + ["--out-pan", "fused-PAN2.TIFF", "--out-mss", "fused-MSS-g.TIFF", "-g", "-m", "3,2,1,4"])
+    run(task + ["--out-pan", "fused-PAN2.TIFF", "--out-mss", "fused-MSS-g.TIFF", "-g", "-m", "3,2,1,4"] + plain)
     for a, b in (("ref-PAN.TIFF", "fused-PAN.TIFF"), ("ref-MSS.TIFF", "fused-MSS.TIFF"), ("ref-MSS-g.TIFF", "fused-MSS-g.TIFF")):
         ia, ta, _ = _tiff.read_tiff_u16(os.path.join(d, a))
         ib, tb, _ = _tiff.read_tiff_u16(os.path.join(d, b))

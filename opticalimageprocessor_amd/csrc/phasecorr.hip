@@ -885,7 +885,7 @@ struct RowStage {
 };
 RowStage row_stage(const OipFft2dPlan *pl)
 {
-    static const char *env = getenv("OIP_FUSED_ROWS");
+    const char *env = getenv("OIP_FUSED_ROWS");          // read per call: a test switches it between two correlations
     int level = env ? atoi(env) : 2;
     RowStage rs{nullptr, 0};
     if (level <= 0 || pl->xf.size() != 1) return rs;

@@ -77,8 +77,13 @@ def _cross_power_ccs(F1: np.ndarray, F2: np.ndarray, M: int, N: int) -> np.ndarr
     return C
 
 
-def phase_correlate(a: np.ndarray, b: np.ndarray):
-    """cv::phaseCorrelate(src1, src2, noArray(), &response) -> ((dx, dy), response)."""
+def phase_correlate(a: np.ndarray, b: np.ndarray, fft: str = "f64"):
+    """cv::phaseCorrelate(src1, src2, noArray(), &response) -> ((dx, dy), response).
+
+    fft="f64": the transforms run in float64 (numpy) and are rounded to float32 storage -- the tightest statement of
+    the algorithm.  fft="f32": scipy.fft on float32 arrays, single precision throughout like OpenCV's own dft() -- a
+    second, independent float32 implementation next to the GPU's: the spread between the two float32 results and the
+    float64 one is what "any correct float32 FFT" costs, and the tests report GPU-vs-f32 and f32-vs-f64 side by side."""
     a = np.asarray(a, np.float32)
     b = np.asarray(b, np.float32)
     assert a.shape == b.shape and a.ndim == 2
@@ -89,10 +94,20 @@ def phase_correlate(a: np.ndarray, b: np.ndarray):
         pb = np.zeros((M, N), np.float32); pb[:rows, :cols] = b
     else:
         pa, pb = a, b
-    F1 = np.fft.rfft2(pa.astype(np.float64))
-    F2 = np.fft.rfft2(pb.astype(np.float64))
-    C = _cross_power_ccs(F1, F2, M, N)
-    c = (np.fft.irfft2(C.astype(np.complex128), s=(M, N)) * (M * N)).astype(np.float32)
+    if fft == "f32":
+        import scipy.fft as sfft
+        F1 = sfft.rfft2(np.ascontiguousarray(pa, np.float32))
+        F2 = sfft.rfft2(np.ascontiguousarray(pb, np.float32))
+        assert F1.dtype == np.complex64
+        C = _cross_power_ccs(F1, F2, M, N)
+        c = sfft.irfft2(C.astype(np.complex64), s=(M, N))
+        assert c.dtype == np.float32
+        c = (c * np.float32(M * N)).astype(np.float32)
+    else:
+        F1 = np.fft.rfft2(pa.astype(np.float64))
+        F2 = np.fft.rfft2(pb.astype(np.float64))
+        C = _cross_power_ccs(F1, F2, M, N)
+        c = (np.fft.irfft2(C.astype(np.complex128), s=(M, N)) * (M * N)).astype(np.float32)
     c = np.roll(c, (M >> 1, N >> 1), axis=(0, 1))            # fftShift
     peak = int(np.argmax(c))                                 # minMaxLoc: first maximum
     py, px = divmod(peak, N)
@@ -141,7 +156,7 @@ def calc_stt_parameters(pan1: np.ndarray, pan2: np.ndarray, sections=10, lines_p
     return table, (sdx / valid, sdy / valid, sr / valid)
 
 
-def calc_interband_correlation(pan: np.ndarray, bands, slices=10, sections=5, corr_lines=16000):
+def calc_interband_correlation(pan: np.ndarray, bands, slices=10, sections=5, corr_lines=16000, fft="f64"):
     """PreProcessor::CalcInterBandCorrelation, preproc.h:224-329.  Returns shifts[b][sec*slices+i]
     = (dx, dy, rs, cx)."""
     Lp, W = pan.shape
@@ -164,7 +179,7 @@ def calc_interband_correlation(pan: np.ndarray, bands, slices=10, sections=5, co
                 br0 = band_gap + sec * (band_rows + band_gap)
                 bs = window_u16_to_f32(bands[b], br0, i * band_cols, band_rows, band_cols)
                 up = resize_cubic(bs, base_cols, base_rows)
-                (dx, dy), rs = phase_correlate(base, up)
+                (dx, dy), rs = phase_correlate(base, up, fft)
                 out[b, sec * slices + i] = (dx, dy, rs, i * base_cols + base_cols // 2)
     return out
 

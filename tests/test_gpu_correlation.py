@@ -205,3 +205,92 @@ def test_vertical_upsampling_kernels_agree(ctx):
         os.environ.pop("OIP_V_GENERIC", None)
     b = ctx.interband_correlate(*args)
     assert np.array_equal(a, b)
+
+
+# ---- parity evidence that can be had without OpenCV (PARITY UNPINNED stays) ---------------
+def _straddling_scene(seed=21):
+    """PAN + four bands whose slices carry increasing noise: the unit responses spread over 0.0 .. 1.0, eight to
+    eleven of sixteen per band above the reference's 0.4 threshold (IBCV_DEF_THRESHOLD), none within 0.01 of it."""
+    Lp, W, slices, sections, corr = 3200, 2560, 8, 2, 1600
+    pan, bands = _synth.pan_mss(Lp, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=seed)
+    rng = np.random.default_rng(seed)
+    bw = W // 4 // slices
+    amps = [0, 60, 140, 240, 360, 500, 650, 800]
+    out = []
+    for b in range(4):
+        a = bands[b].astype(np.float64)
+        for i in range(slices):
+            a[:, i * bw:(i + 1) * bw] += rng.normal(0, amps[(i + 3 * b) % 8], (a.shape[0], bw))
+        out.append(np.clip(np.rint(a), 0, 65535).astype(np.uint16))
+    return pan, out, (Lp, W, slices, sections, corr)
+
+
+def test_gpu_against_float32_and_float64_oracles(ctx, oracle_mod):
+    """Three implementations of the same algorithm on the same units: the GPU (f32, own mixed-radix FFT), the oracle
+    with a float32 FFT (scipy.fft, single precision throughout like cv::dft) and the oracle with a float64 FFT.  The
+    deltas are printed side by side: the GPU must sit as close to either oracle as the two oracles sit to each other,
+    up to a small factor -- i.e. the tolerance brackets 'any float32 FFT', not a GPU defect."""
+    from oracle import phasecorr as pc
+    pan, bands, (Lp, W, slices, sections, corr) = _straddling_scene()
+    w64 = pc.calc_interband_correlation(pan, bands, slices, sections, corr)
+    w32 = pc.calc_interband_correlation(pan, bands, slices, sections, corr, fft="f32")
+    planes = _cuda(np.stack(bands, 0))
+    got = ctx.interband_correlate(_cuda(pan), Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, sections, corr)
+    ok = w64[..., 2] >= 0.1                      # units with a usable peak (see the note in the test above)
+    d = lambda a, b: (np.abs(a[..., :2] - b[..., :2])[ok].max(), np.abs(a[..., 2] - b[..., 2]).max())
+    g32, g64, o = d(got, w32), d(got, w64), d(w32, w64)
+    print("\nshift / response deltas:  GPU vs f32 oracle %.2e px / %.2e   GPU vs f64 oracle %.2e px / %.2e   "
+          "f32 oracle vs f64 oracle %.2e px / %.2e" % (g32 + g64 + o))
+    assert g32[0] < SHIFT_TOL and g64[0] < SHIFT_TOL and g32[1] < 5 * RESP_TOL and g64[1] < 5 * RESP_TOL
+    # the GPU is not an outlier among float32 implementations: within 20x of the spread between the two oracles,
+    # or under 1e-4 px / 1e-4 absolutely
+    assert g64[0] < max(20 * o[0], 1e-4) and g64[1] < max(20 * o[1], 1e-4), (g64, o)
+
+
+def test_valid_set_straddling_the_reference_threshold(ctx, oracle_mod):
+    """The reference keeps a unit when its response reaches 0.4 (preproc.h:492-512).  On a scene whose responses
+    straddle that threshold the GPU and the oracle must keep the SAME units, and the polynomials fitted to the two
+    kept sets must give maps that agree to 1/64 px over the whole line (half a 1/32-px phase step)."""
+    import opticalimageprocessor_amd as oip
+    from oracle import phasecorr as pc
+    pan, bands, (Lp, W, slices, sections, corr) = _straddling_scene()
+    want = pc.calc_interband_correlation(pan, bands, slices, sections, corr)
+    assert np.abs(want[..., 2] - 0.4).min() > 5e-3              # the scene itself keeps clear of the threshold
+    planes = _cuda(np.stack(bands, 0))
+    got = ctx.interband_correlate(_cuda(pan), Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, sections, corr)
+    thr = 0.4
+    vg, vw = got[..., 2] >= thr, want[..., 2] >= thr
+    assert np.array_equal(vg, vw)
+    assert 5 <= vw.sum(1).min() and vw.sum(1).max() < slices * sections      # some kept, some dropped, in every band
+    cx, cy = oip.filter_and_fit(got, thr, 5)
+    wcx, wcy = pc.filter_and_fit(want, thr, 5)
+    xs = np.arange(0, W, 4, dtype=np.float64)
+    worst = 0.0
+    for b in range(4):
+        worst = max(worst, np.abs((cx[b, 0] + cx[b, 1] * xs) - (wcx[b, 0] + wcx[b, 1] * xs)).max() / 4,
+                    np.abs((cy[b, 0] + cy[b, 1] * xs + cy[b, 2] * xs * xs) - (wcy[b, 0] + wcy[b, 1] * xs + wcy[b, 2] * xs * xs)).max() / 4)
+    print("\nlargest map difference over the line: %.2e MSS px" % worst)
+    assert worst < 1.0 / 64
+
+
+def test_fast_cross_power_is_bounded_against_the_exact_bin(ctx):
+    """The fused row stage forms interior cross-power bins with the hardware reciprocal and square root
+    (cross_power_bin_fast); OIP_FUSED_ROWS=1 runs the same correlations through cross_power_bin (correctly rounded
+    double divisions, the reference's operation order).  Same spectra, same inverse transforms: the difference in
+    shift and response is what the approximation costs."""
+    import os
+    pan, bands, (Lp, W, slices, sections, corr) = _straddling_scene(22)
+    planes = _cuda(np.stack(bands, 0))
+    dpan = _cuda(pan)
+    fast = ctx.interband_correlate(dpan, Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, sections, corr)
+    os.environ["OIP_FUSED_ROWS"] = "1"
+    try:
+        exact = ctx.interband_correlate(dpan, Lp, 0, Lp, planes, bands[0].size, 0, Lp // 4, W, slices, sections, corr)
+    finally:
+        del os.environ["OIP_FUSED_ROWS"]
+    ok = exact[..., 2] >= 0.1
+    ds = np.abs(fast[..., :2] - exact[..., :2])[ok].max()
+    dr = np.abs(fast[..., 2] - exact[..., 2]).max()
+    print("\ncross_power_bin_fast vs cross_power_bin: %.2e px, %.2e response" % (ds, dr))
+    assert ds < 2e-4 and dr < 2e-5
+    assert (fast[..., :3] != exact[..., :3]).any()          # the two paths really differ

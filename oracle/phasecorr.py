@@ -290,3 +290,18 @@ def polyfit(x, y, deg, method="numcpp"):
         for i in range(j + 1):
             p[i] += cj * comb(j, i) * (-mu) ** (j - i) / sc ** j
     return p
+
+
+# ---- timing helpers for bench.py's cpu_baseline leg (each call is one worker's share of a parallel sample) ----------
+def bench_unit_band(seed: int, rows: int, cols: int, repeat: int = 1) -> float:
+    """seconds for `repeat` (window conversion + x4 cubic up-sampling + phaseCorrelate) of one band of one unit"""
+    import time
+    rng = np.random.default_rng(seed)
+    pan = rng.integers(64, 4096, (rows, cols), dtype=np.uint16)
+    band = rng.integers(64, 4096, (rows // 4, cols // 4), dtype=np.uint16)
+    t = time.perf_counter()
+    for _ in range(repeat):
+        a = window_u16_to_f32(pan, 0, 0, rows, cols)
+        b = resize_cubic(window_u16_to_f32(band, 0, 0, rows // 4, cols // 4), cols, rows)
+        phase_correlate(a, b)
+    return time.perf_counter() - t

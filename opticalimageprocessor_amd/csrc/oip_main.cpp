@@ -19,6 +19,7 @@
 #include <set>
 
 #include "oip_host.hpp"
+#include "oip_multigpu.hpp"
 
 using namespace OIPGPU;
 
@@ -122,6 +123,8 @@ void usage()
          "  prestitch  --pan1 FILE --pan2 FILE [--rrc1 FILE --rrc2 FILE -s N -l N --stitch-overlap N\n"
          "             --stt-threshold X --stt-maxdeltay X -e N -r,--rrc/--no-rrc -c,--only-calculate --fp16-accumulate]\n"
          "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE] [-g,--GDAL -m,--band-map a,b,c,d]\n"
+         "  --gpus N   (default action and prestitch) scan-line blocks over the N GPUs of the node, RCCL exchanges\n"
+         "  plan       strip|ccd --width W --lines L --gpus N ...: print the multi-GPU row plan as JSON\n"
          "  task       prestitch + stitch + default action x2 + stitch in one process (intermediates stay on the GPU):\n"
          "             --pan1 --pan2 --rrc1 --rrc2 --mss1 --mss2 --rrc-mss{1,2}-b{1..4} FILE --fold-cols-pan N --fold-cols-mss N\n"
          "             --out-pan FILE.TIFF --out-mss FILE.TIFF [prestitch, default-action and stitch options]");
@@ -131,7 +134,7 @@ int run_prestitch(const std::vector<std::string> &args, int width)
 {
     Spec sp;
     sp.valued = {"--pan1", "--pan2", "--rrc1", "--rrc2", "--sections", "--section-lines", "--stitch-overlap", "--stt-threshold",
-                 "--stt-maxdeltay", "--edge-cols", "--width"};
+                 "--stt-maxdeltay", "--edge-cols", "--width", "--gpus"};
     sp.flags = {"--rrc", "--no-rrc", "--only-calculate", "--fp16-accumulate"};
     sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-r", "--rrc"}, {"-c", "--only-calculate"}};
     Parsed p = parse(sp, args);
@@ -147,6 +150,16 @@ int run_prestitch(const std::vector<std::string> &args, int width)
     const double thr = p.real("--stt-threshold", OIP_STT_DEF_PHCTHRHLD), maxdy = p.real("--stt-maxdeltay", 0.0);
     const bool doRRC = !p.flag.count("--no-rrc");
     const bool onlyCalc = p.flag.count("--only-calculate") != 0;
+    const int gpus = p.integer("--gpus", 1);
+    if (gpus < 1 || gpus > 64) throw cli_error(105, "--gpus: GPU count expected");
+    if (p.has("--gpus")) {                        // scan-line blocks over the GPUs of the node (oip_multigpu.hpp); --gpus 1 included
+        MultiGpuPrestitchOptions mo;
+        mo.width = width; mo.gpus = gpus; mo.sections = sections; mo.sectionLines = sectionLines; mo.overlapCols = overlapCols;
+        mo.edgeCols = edgeCols; mo.threshold = thr; mo.maxDeltaY = maxdy; mo.doRRC = doRRC; mo.onlyCalc = onlyCalc;
+        mo.fp16acc = p.flag.count("--fp16-accumulate") != 0;
+        RunPrestitchMultiGpu(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), mo);
+        return 0;
+    }
     // main.cpp:270-286
     Stitcher stt(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), sections, sectionLines, overlapCols, width);
     stt.CalcSttParameters(thr, maxdy, edgeCols);
@@ -187,7 +200,7 @@ int run_default(const std::vector<std::string> &args, int width)
 {
     Spec sp;
     sp.valued = {"--pan", "--mss", "--rrc-pan", "--rrc-msb1", "--rrc-msb2", "--rrc-msb3", "--rrc-msb4", "--slices", "--ibc-sections",
-                 "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width", "--fit"};
+                 "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width", "--fit", "--gpus"};
     sp.flags = {"--do-rrc4pan", "--write-rrcpan", "--no-rrcpan", "--no-rrc4mss", "--keep-leading"};
     sp.alias = {{"-k", "--keep-leading"}};
     Parsed p = parse(sp, args);
@@ -204,6 +217,20 @@ int run_default(const std::vector<std::string> &args, int width)
     std::string msb[MSS_BANDS] = {p.str("--rrc-msb1"), p.str("--rrc-msb2"), p.str("--rrc-msb3"), p.str("--rrc-msb4")};
     if (doRRC4MSS && (msb[0].empty() || msb[1].empty() || msb[2].empty() || msb[3].empty()))
         throw usage_error("RRC parameter file of all MSS Bands needed");
+    if (p.has("--gpus")) {                        // scan-line blocks over the GPUs of the node (oip_multigpu.hpp); --gpus 1 included
+        MultiGpuDefaultOptions mo;
+        mo.width = width; mo.gpus = p.integer("--gpus", 1);
+        if (mo.gpus < 1 || mo.gpus > 64) throw cli_error(105, "--gpus: GPU count expected");
+        if (p.flag.count("--write-rrcpan")) throw cli_error(105, "--write-rrcpan is not available with --gpus");
+        require(p, "--pan");
+        require(p, "--mss");
+        mo.doRRC4PAN = doRRC4PAN; mo.doRRC4MSS = doRRC4MSS; mo.keepLeading = p.flag.count("--keep-leading") != 0;
+        mo.slices = p.integer("--slices", OIP_IBCV_DEF_SLICES); mo.sections = p.integer("--ibc-sections", OIP_IBCV_DEF_SECTIONS);
+        mo.linesSection = p.integer("--lines-section", OIP_IBPA_DEFAULT_BATCHLINES); mo.lineOffset = p.integer("--line-offset", 0);
+        mo.overlapLines = p.integer("--overlap-lines", OIP_IBPA_DEFAULT_LINEOVERLAP); mo.fitMode = fit_mode(p); mo.threshold = thr;
+        RunDefaultActionMultiGpu(p.str("--pan"), p.str("--mss"), p.str("--rrc-pan"), msb, mo);
+        return 0;
+    }
     // main.cpp:301-316
     PreProcessor pp(p.str("--pan"), p.str("--mss"), p.str("--rrc-pan"), msb, width);
     pp.SetFitMode(fit_mode(p));
@@ -217,6 +244,38 @@ int run_default(const std::vector<std::string> &args, int width)
     pp.CalcInterBandCorrelation(p.integer("--slices", OIP_IBCV_DEF_SLICES), p.integer("--ibc-sections", OIP_IBCV_DEF_SECTIONS), thr);
     pp.DoInterBandAlignment(p.integer("--lines-section", OIP_IBPA_DEFAULT_BATCHLINES), p.integer("--line-offset", 0),
                             p.integer("--overlap-lines", OIP_IBPA_DEFAULT_LINEOVERLAP), p.flag.count("--keep-leading") != 0);
+    return 0;
+}
+
+// oip plan strip|ccd ...: prints the multi-GPU row plan as JSON (no device is touched) -- what each rank computes,
+// which window pieces and halo lines move.  tests/test_cli_cpu.py compares it with dist.py's plan.
+int run_plan(const std::vector<std::string> &args)
+{
+    if (args.empty() || (args[0] != "strip" && args[0] != "ccd")) throw cli_error(105, "plan: strip or ccd expected");
+    Spec sp;
+    sp.valued = {"--width", "--lines", "--gpus", "--slices", "--ibc-sections", "--corr-lines", "--lines-section", "--line-offset", "--overlap-lines",
+                 "--min-lines", "--halo-cap", "--cy", "--sections", "--section-lines", "--stitch-overlap", "--edge-cols", "--dy", "--section-rows"};
+    sp.flags = {"--keep-leading"};
+    Parsed p = parse(sp, {args.begin() + 1, args.end()});
+    const int W = p.integer("--width", OIP_PIXELS_PER_LINE), gpus = p.integer("--gpus", 1);
+    const long L = (long)p.real("--lines", 0);
+    if (args[0] == "strip") {
+        StripPlanC plan(W, L, gpus, p.integer("--slices", OIP_IBCV_DEF_SLICES), p.integer("--ibc-sections", OIP_IBCV_DEF_SECTIONS),
+                        p.integer("--corr-lines", OIP_CORRELATION_LINES), p.integer("--lines-section", OIP_IBPA_DEFAULT_BATCHLINES),
+                        p.integer("--line-offset", 0), p.integer("--overlap-lines", OIP_IBPA_DEFAULT_LINEOVERLAP), p.flag.count("--keep-leading") != 0,
+                        p.integer("--min-lines", OIP_IBPA_MIN_PROCESSLINES), p.integer("--halo-cap", 64));
+        double cy[12] = {0};
+        const std::string c = p.str("--cy", "0,0,0");
+        double a = 0, b = 0, d = 0;
+        if (sscanf(c.c_str(), "%lf,%lf,%lf", &a, &b, &d) != 3) throw cli_error(105, "--cy: three coefficients expected");
+        for (int k = 0; k < 4; ++k) { cy[3 * k] = a; cy[3 * k + 1] = b; cy[3 * k + 2] = d; }
+        PrintStripPlan(plan, cy);
+    } else {
+        CcdPlanC plan(W, L, gpus, p.integer("--sections", OIP_STT_DEF_SECTIONS), p.integer("--section-lines", OIP_STT_DEF_SECLINES),
+                      p.integer("--stitch-overlap", OIP_STT_DEF_OVERLAPPX), p.integer("--edge-cols", 0),
+                      p.integer("--section-rows", OIP_REMAP_SECTION_ROWS));
+        PrintCcdPlan(plan, p.real("--dy", 0.0));
+    }
     return 0;
 }
 
@@ -310,6 +369,7 @@ int main(int argc, const char *argv[])
             if (!args.empty() && args[0] == "prestitch") return run_prestitch({args.begin() + 1, args.end()}, width);
             if (!args.empty() && args[0] == "stitch") return run_stitch({args.begin() + 1, args.end()}, width);
             if (!args.empty() && args[0] == "task") return run_task({args.begin() + 1, args.end()}, width);
+            if (!args.empty() && args[0] == "plan") return run_plan({args.begin() + 1, args.end()});
             if (!args.empty() && args[0] == "auxsep")
                 throw std::invalid_argument("auxsep (down-link de-framing) is outside this build: run the reference's auxsep, then this tool");
             if (args.empty()) { usage(); return 0; }

@@ -222,3 +222,52 @@ def test_weak_scaling_plan_keeps_per_rank_work_fixed(world):
     rows = [plan.align_out_rows(r) for r in range(world)]
     assert rows[0][0] == 0 and rows[-1][1] == plan.out_rows
     assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+
+
+# ---- the C++ multi-GPU host (csrc/oip_multigpu.hpp, `oip --gpus N`) plans exactly like dist.py -----------------------
+OIP = os.path.join(ROOT, "opticalimageprocessor_amd", "lib", "oip")
+
+
+def _plan_json(args):
+    import json
+    import subprocess
+    r = subprocess.run([OIP, "plan"] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads(r.stdout)
+
+
+@pytest.mark.parametrize("W,L,world,slices,sections", [(30000, 524288, 8, 10, 5), (30000, 800000, 8, 10, 5), (30000, 200000, 2, 10, 5),
+                                                       (12288, 262144, 4, 10, 5), (640, 4800, 2, 8, 3), (30000, 400000, 4, 10, 20)])
+def test_cpp_strip_plan_equals_python_plan(W, L, world, slices, sections):
+    import opticalimageprocessor_amd as oip
+    from opticalimageprocessor_amd.dist import StripPlan
+    corr = 16000 if L >= 100000 else 1200
+    lps, ovl, minl = (20000, 520, 1500) if L >= 100000 else (700, 60, 100)
+    plan = StripPlan(W, L, world, slices, sections, corr, lps, 0, ovl, False, minl)
+    cy = np.tile([-1.3, 2e-5, -3e-10], (4, 1))
+    got = _plan_json(["strip", "--width", W, "--lines", L, "--gpus", world, "--slices", slices, "--ibc-sections", sections, "--corr-lines", corr,
+                      "--lines-section", lps, "--overlap-lines", ovl, "--min-lines", minl, "--cy=-1.3,2e-5,-3e-10"])
+    assert got["assign"] == plan.assign
+    kinds = {"pan": 0, "mss": 1}
+    want = [[p.src, p.dst, kinds[p.kind], p.unit, p.row0, p.rows, p.col0, p.cols, p.dst_row] for p in plan.correlation_pieces()]
+    assert got["pieces"] == want
+    assert got["align_rows"] == [list(plan.align_out_rows(r)) for r in range(world)]
+    tr, _ = plan.align_transfers(lambda a, n: oip.align_mss_src_range(a, n, plan.Lm, cy, W // 4, lps, 0, ovl, False, minl))
+    assert got["align_transfers"] == [[t.src, t.dst, t.row0, t.rows] for t in tr]
+
+
+@pytest.mark.parametrize("W,L,world,sections,lps,ov,dy", [(30000, 262144, 8, 10, 16000, 200, -1.62), (30000, 262144, 8, 10, 16000, 200, 2.4),
+                                                          (12288, 400000, 4, 10, 16000, 200, 0.3), (30000, 200000, 2, 10, 16000, 200, -0.2)])
+def test_cpp_ccd_plan_equals_python_plan(W, L, world, sections, lps, ov, dy):
+    import opticalimageprocessor_amd as oip
+    from opticalimageprocessor_amd.dist import CcdPlan
+    plan = CcdPlan(W, L, world, sections, lps, ov, 0)
+    got = _plan_json(["ccd", "--width", W, "--lines", L, "--gpus", world, "--sections", sections, "--section-lines", lps, "--stitch-overlap", ov,
+                      "--dy=%r" % dy])
+    assert got["assign"] == plan.assign
+    kinds = {"pan1": 0, "pan2": 1}
+    want = [[p.src, p.dst, kinds[p.kind], p.unit, p.row0, p.rows, p.col0, p.cols, p.dst_row] for p in plan.correlation_pieces()]
+    assert got["pieces"] == want
+    tr, need = plan.remap_transfers(lambda a, n: oip.remap_shift_src_range(a, n, L, dy, 30000))
+    assert got["remap_transfers"] == [[t.src, t.dst, t.row0, t.rows] for t in tr]
+    assert got["need"] == [list(x) for x in need]

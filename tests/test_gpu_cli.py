@@ -202,3 +202,42 @@ def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
     # argument errors keep the CLI's codes
     r = subprocess.run([OIP, "task", "--pan1", "A_PAN-1.RAW"], cwd=d, env=env, capture_output=True, text=True)
     assert r.returncode == 106
+
+
+def test_multigpu_host_on_one_gpu_equals_the_plain_cli(tmp_path):
+    """`oip --gpus N` / `oip prestitch --gpus N` (csrc/oip_multigpu.hpp: one context, host thread and RCCL communicator per
+    GPU, block-offset file reads, grouped ncclSend/ncclRecv, ncclAllGather).  This box has one GPU, so N = 1 is what can
+    run here: the whole RCCL host path with a single rank must reproduce the plain CLI's product files byte for byte.
+    (The N > 1 plan is checked against dist.py's in tests/test_dist_cpu.py, dist.py itself on gloo.)"""
+    import shutil
+    W, L, OV = 1024, 33024, 64
+    base = str(tmp_path)
+    pan1, pan2 = _synth.ccd_pair(L, W, OV, (3, -2), seed=15)
+    pan, bands = _synth.pan_mss(L, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=16)
+    dirs = {}
+    for name in ("plain", "node"):
+        d = os.path.join(base, name)
+        os.makedirs(d)
+        dirs[name] = d
+        pan1.tofile(os.path.join(d, "S_PAN-1.RAW")); pan2.tofile(os.path.join(d, "S_PAN-2.RAW"))
+        pan.tofile(os.path.join(d, "T_PAN.RAW")); np.concatenate(bands, axis=1).tofile(os.path.join(d, "T_MSS.RAW"))
+        _csv(os.path.join(d, "PAN-1.csv"), _synth.lut(W, 1)); _csv(os.path.join(d, "PAN-2.csv"), _synth.lut(W, 2))
+        for b in range(4):
+            _csv(os.path.join(d, "MSS.B%d.csv" % (b + 1)), _synth.lut(W // 4, 20 + b))
+    for name, extra in (("plain", []), ("node", ["--gpus", "1"])):
+        d = dirs[name]
+        env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_TIFF_COMPRESS="none")
+        r = subprocess.run([OIP, "prestitch", "--width", str(W), "--pan1", "S_PAN-1.RAW", "--pan2", "S_PAN-2.RAW", "--rrc1", "PAN-1.csv",
+                            "--rrc2", "PAN-2.csv", "-s", "3", "-l", "1600", "--stitch-overlap", str(OV), "--stt-threshold", "0.05"] + extra,
+                           cwd=d, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--slices", "8", "--ibc-sections", "1",
+                "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"] + extra
+        for b in range(4):
+            args += ["--rrc-msb%d" % (b + 1), "MSS.B%d.csv" % (b + 1)]
+        r = subprocess.run(args, cwd=d, env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for f in ("S_PAN-1.RRC.RAW", "S_PAN-2.RRC.RAW", "S_PAN-2.RRC.PRESTT.RAW", "T_MSS.ALIGNED.TIFF"):
+        a = open(os.path.join(dirs["plain"], f), "rb").read()
+        b = open(os.path.join(dirs["node"], f), "rb").read()
+        assert len(a) > 1000 and a == b, f

@@ -970,22 +970,75 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));       // per-iteration opaque copy: no loop-invariant stage addressing in registers
         expand(o1, tid);
+        const int o1n = o1 + gridDim.y;
+        const bool more = o1n < p.O1;
+        const long base = (long)o2 * p.o2_stride + (long)o1 * p.o1_stride + lane0;
+        if (F == 128 && NT == 256 && !(p.dbg & 8)) {
+            // The element a thread has just built, zz[i], is point (tid >> 4) + 16 i of lane v: the eight inputs of ITS
+            // radix-8 butterfly of the first stage.  So the first stage runs on the registers and only its result goes
+            // to LDS; the third stage's outputs are multiplied by the inter-pass twiddles and stored from registers
+            // (a wave covers four 128-byte row segments per store instruction): two LDS round trips instead of four.
+            const int qq = tid >> 4;
+            bf8(zz);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) buf[(qq * 8 + m) * Vp + v] = zz[m];
+            __syncthreads();
+            if (more) fetch(o1n, tid);               // in flight during the two remaining stages and the stores
+            __builtin_amdgcn_sched_barrier(0);
+            float2 y[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int b = qq + 16 * i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {            // radix 4, Ns = 8
+                const int b = qq + 16 * i, k = b & 7;
+                const float2 w1 = tw[k * 4];
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                y[i][1] = cmul(y[i][1], w1);
+                y[i][2] = cmul(y[i][2], w2);
+                y[i][3] = cmul(y[i][3], w3);
+                bf4(y[i]);
+                const int j0 = (b - k) * 4 + k;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) buf[(j0 + 8 * m) * Vp + v] = y[i][m];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {            // radix 4, Ns = 32: outputs n = b + 32 m
+                const int b = qq + 16 * i;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
+                const float2 w1 = tw[b];
+                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                y[i][1] = cmul(y[i][1], w1);
+                y[i][2] = cmul(y[i][2], w2);
+                y[i][3] = cmul(y[i][3], w3);
+                bf4(y[i]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int n = b + 32 * m;
+                    if (v < nv) data[base + (long)n * p.nstride + v] = cmul(y[i][m], twj[n]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int n = (tid >> VS) + i * (NT >> VS);
             buf[n * Vp + (tid & (V - 1))] = zz[i];
         }
         __syncthreads();
-        const int o1n = o1 + gridDim.y;
-        const bool more = o1n < p.O1;
         if (more) fetch(o1n, tid);               // in flight during the transform and the stores below
         __builtin_amdgcn_sched_barrier(0);
         Stages<F, VS, Vp, NT, 1, Rs...>::run(buf, tw, tid);
-        const long base = (long)o2 * p.o2_stride + (long)o1 * p.o1_stride + lane0;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int n = (tid >> VS) + i * (NT >> VS);
             if (v < nv) data[base + (long)n * p.nstride + v] = cmul(buf[n * Vp + (tid & (V - 1))], twj[n]);
+        }
         }
         if (!more) break;
         __syncthreads();                    // buf and twj are free for the next tile

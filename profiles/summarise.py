@@ -24,15 +24,21 @@ def bench_name(kernel):
     m = re.search(r"fft_first_pass_up_kernel<(\d+)", kernel)
     if m:
         return "fft_pass_ct_kernel_F%d_pack" % int(m.group(1))       # the library profiles it under the pass's name
+    if "fft_col128_peak_kernel" in kernel:
+        return "fft_pass_ct_kernel_F128_peak"                         # the register-staged peak pass, profiled under the pass's name
+    if "align_mss8_kernel" in kernel:
+        return "align_mss_kernel"
     if "resize_cubic_v_x4_kernel" in kernel:
         return "resize_cubic_v_kernel"                                # profiled under the generic kernel's name
     m = re.search(r"([A-Za-z_0-9]+_kernel)\b", kernel)
     return m.group(1) if m else kernel
 
 
-h = os.path.join(out, "host_rrc.json")
-if os.path.exists(h) and os.path.getsize(h):
-    shutil.copy(h, os.path.join(prof, "%s_host_rrc.json" % tag))
+for extra, dst in (("host_rrc.json", "%s_host_rrc.json"), ("staging_probe.txt", "%s_staging_probe.txt"),
+                   ("bench_prestitch_f16.json", "%s_bench_prestitch_f16.json")):
+    h = os.path.join(out, extra)
+    if os.path.exists(h) and os.path.getsize(h):
+        shutil.copy(h, os.path.join(prof, dst % tag))
 raw, traffic = {}, {}
 for w in ("default", "prestitch", "rrc"):
     b = os.path.join(out, "bench_%s.json" % w)
@@ -49,11 +55,13 @@ for w in ("default", "prestitch", "rrc"):
                     continue
                 name = bench_name(row["Kernel_Name"])
                 grid = int(row.get("Grid_Size", 0) or 0)
-                if name.endswith("_peak") and grid <= 50 * 256:
+                if name.endswith("_peak") and grid <= 50 * 256 and "fft_col128_peak_kernel" not in row["Kernel_Name"]:
                     name = "fft_window_F" + name.split("_F")[1].split("_")[0]          # 25-tile window launches
                 per[name][c].append(float(row["Counter_Value"]))
     raw[w], traffic[w] = {}, {}
     for name, d in per.items():
+        if not re.fullmatch(r"[A-Za-z_0-9]+", name) or name.startswith("__amd") or name in ("reduce_kernel", "vectorized_elementwise_kernel", "distribution_elementwise_grid_stride_kernel"):
+            continue                                                  # torch's own kernels (synthetic data generation)
         f = d.get("FETCH_SIZE", [])
         wr = d.get("WRITE_SIZE", [])
         if not f or not wr:

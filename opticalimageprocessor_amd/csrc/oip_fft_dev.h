@@ -120,12 +120,81 @@ __device__ __forceinline__ void bf8(float2 *x)
     x[3] = csub(e[3], o3);
     x[7] = cadd(e[3], o3);
 }
+// ---- composite butterflies: R = A * B points in registers -----------------------------------------------------
+// x[n], n = n1 + A n2  ->  X[B k1 + k2]:  B-point transforms over n2 for each n1, the twiddles w_R^(n1 k2)
+// (compile-time constants), A-point transforms over n1 for each k2; the result is put back in natural order
+// (all indices are compile-time: the final permutation is a renaming of registers).  A stage built on these
+// moves a point through LDS once where two radix-A / radix-B stages move it twice.
+__device__ __forceinline__ float2 cmul_const(float2 a, float cr, float ci)
+{
+    OIP_FFT_FMA
+    return make_float2(a.x * cr - a.y * ci, a.x * ci + a.y * cr);
+}
+template <int A, int B> struct CompositeTw;
+template <> struct CompositeTw<5, 5> {
+    static __device__ __forceinline__ float2 w(int t)
+    {
+        constexpr float re[25] = {1.0f, 0.968583161f, 0.87630668f, 0.728968627f, 0.535826795f, 0.309016994f, 0.0627905195f, -0.187381315f, -0.425779292f, -0.63742399f, -0.809016994f, -0.929776486f, -0.992114701f, -0.992114701f, -0.929776486f, -0.809016994f, -0.63742399f, -0.425779292f, -0.187381315f, 0.0627905195f, 0.309016994f, 0.535826795f, 0.728968627f, 0.87630668f, 0.968583161f};
+        constexpr float im[25] = {-0.0f, -0.248689887f, -0.481753674f, -0.684547106f, -0.844327926f, -0.951056516f, -0.998026728f, -0.982287251f, -0.904827052f, -0.770513243f, -0.587785252f, -0.368124553f, -0.125333234f, 0.125333234f, 0.368124553f, 0.587785252f, 0.770513243f, 0.904827052f, 0.982287251f, 0.998026728f, 0.951056516f, 0.844327926f, 0.684547106f, 0.481753674f, 0.248689887f};
+        return make_float2(re[t], im[t]);
+    }
+};
+template <> struct CompositeTw<3, 5> {
+    static __device__ __forceinline__ float2 w(int t)
+    {
+        constexpr float re[15] = {1.0f, 0.913545458f, 0.669130606f, 0.309016994f, -0.104528463f, -0.5f, -0.809016994f, -0.978147601f, -0.978147601f, -0.809016994f, -0.5f, -0.104528463f, 0.309016994f, 0.669130606f, 0.913545458f};
+        constexpr float im[15] = {-0.0f, -0.406736643f, -0.743144825f, -0.951056516f, -0.994521895f, -0.866025404f, -0.587785252f, -0.207911691f, 0.207911691f, 0.587785252f, 0.866025404f, 0.994521895f, 0.951056516f, 0.743144825f, 0.406736643f};
+        return make_float2(re[t], im[t]);
+    }
+};
+template <int A, int B> __device__ __forceinline__ void butterfly_leaf(float2 *x);
+template <int A, int B> __device__ __forceinline__ void bf_composite(float2 *x)
+{
+    constexpr int R = A * B;
+    // B-point transforms over n2, for each n1
+#pragma unroll
+    for (int n1 = 0; n1 < A; ++n1) {
+        float2 t[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) t[n2] = x[n1 + A * n2];
+        butterfly_leaf<B, 0>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) {
+            float2 v = t[k2];
+            if (n1 * k2 != 0) { const float2 c = CompositeTw<A, B>::w(n1 * k2); v = cmul_const(v, c.x, c.y); }
+            x[n1 + A * k2] = v;
+        }
+    }
+    // A-point transforms over n1, for each k2; X[B k1 + k2] lands at position k1 + A k2
+    float2 y[R];
+#pragma unroll
+    for (int k2 = 0; k2 < B; ++k2) {
+        float2 u[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) u[n1] = x[n1 + A * k2];
+        butterfly_leaf<A, 0>(u);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) y[B * k1 + k2] = u[k1];
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) x[m] = y[m];
+}
+template <int A, int B> __device__ __forceinline__ void butterfly_leaf(float2 *x)
+{
+    if (A == 2) bf2(x);
+    else if (A == 3) bf3(x);
+    else if (A == 4) bf4(x);
+    else if (A == 5) bf5(x);
+    else bf8(x);
+}
 template <int R> __device__ __forceinline__ void butterfly(float2 *x)
 {
     if (R == 2) bf2(x);
     else if (R == 3) bf3(x);
     else if (R == 4) bf4(x);
     else if (R == 5) bf5(x);
+    else if (R == 15) bf_composite<3, 5>(x);
+    else if (R == 25) bf_composite<5, 5>(x);
     else bf8(x);
 }
 
@@ -332,6 +401,101 @@ template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesPipe<F
         }
         if (NA == 1) __syncthreads();
         StagesPipe<F, NT, NA, Ns * R, Rest...>::run(buf, tw, tid);
+    }
+};
+
+// One Stockham stage over ALL NA two-line buffers at once: an item is one butterfly of one line of one buffer, items are
+// dealt over the whole block (with radix-25 / radix-15 butterflies one buffer alone would keep a third of the block
+// busy); load everything, barrier, combine and store, barrier.  Twiddle powers w^m come from w^1 by products, grouped
+// as w^(n1) (w^A)^(n2) for composite radices so the chain stays four deep.
+template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
+    static constexpr int NB = F / R;
+    static constexpr int ITEMS = NA * 2 * NB;
+    static constexpr int PER = (ITEMS + NT - 1) / NT;
+    static constexpr int TWSTEP = F / (Ns * R);
+    static constexpr int A = R == 15 ? 3 : (R == 25 ? 5 : 1);       // composite split R = A * B (1: plain radix)
+    static __device__ __forceinline__ void decode(int item, int *base, int *b)
+    {
+        const int a = item / (2 * NB), rem = item - a * (2 * NB);
+        *b = rem >> 1;
+        *base = a * 2 * F + (rem & 1);                                // element offset of (buffer a, line), point 0
+    }
+    static __device__ __forceinline__ void load(const float2 *__restrict__ buf, float2 (&x)[PER][R], int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = tid + i * NT;
+            if (ITEMS % NT == 0 || item < ITEMS) {
+                int base, b;
+                decode(item, &base, &b);
+#pragma unroll
+                for (int m = 0; m < R; ++m) x[i][m] = buf[base + 2 * (b + m * NB)];
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(float2 *__restrict__ buf, const float2 *__restrict__ tw, float2 (&x)[PER][R], int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int item = tid + i * NT;
+            if (ITEMS % NT == 0 || item < ITEMS) {
+                int base, b;
+                decode(item, &base, &b);
+                const int k = b % Ns;
+                if (Ns > 1) {
+                    const float2 w1 = tw[k * TWSTEP];
+                    if (A == 1) {
+                        float2 w = w1;
+#pragma unroll
+                        for (int m = 1; m < R; ++m) {
+                            x[i][m] = cmul(x[i][m], w);
+                            if (m + 1 < R) w = cmul(w, w1);
+                        }
+                    } else {
+                        constexpr int B = R / A;
+                        float2 wn1[A];                                  // w^n1, n1 < A
+                        wn1[0] = make_float2(1.f, 0.f);
+                        wn1[1] = w1;
+#pragma unroll
+                        for (int n1 = 2; n1 < A; ++n1) wn1[n1] = cmul(wn1[n1 - 1], w1);
+                        float2 wa = cmul(wn1[A - 1], w1);               // w^A
+                        float2 wan = wa;                                // (w^A)^n2
+#pragma unroll
+                        for (int n1 = 1; n1 < A; ++n1) x[i][n1] = cmul(x[i][n1], wn1[n1]);
+#pragma unroll
+                        for (int n2 = 1; n2 < B; ++n2) {
+                            x[i][A * n2] = cmul(x[i][A * n2], wan);
+#pragma unroll
+                            for (int n1 = 1; n1 < A; ++n1) x[i][n1 + A * n2] = cmul(x[i][n1 + A * n2], cmul(wn1[n1], wan));
+                            if (n2 + 1 < B) wan = cmul(wan, wa);
+                        }
+                    }
+                }
+                butterfly<R>(x[i]);
+                const int j0 = (b - k) * R + k;
+#pragma unroll
+                for (int m = 0; m < R; ++m) buf[base + 2 * (j0 + m * Ns)] = x[i][m];
+            }
+        }
+    }
+};
+template <int F, int NT, int NA, int Ns, int... Rs> struct StagesAll;
+template <int F, int NT, int NA, int Ns> struct StagesAll<F, NT, NA, Ns> {
+    static __device__ __forceinline__ void run(float2 *, const float2 *, int) {}
+};
+template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesAll<F, NT, NA, Ns, R, Rest...> {
+    // entry: every writer of the buffers is behind a barrier; exit: likewise
+    static __device__ __forceinline__ void run(float2 *buf, const float2 *tw, int tid)
+    {
+        using Ops = StageAllOps<F, NT, NA, Ns, R>;
+        {
+            float2 x[Ops::PER][R];
+            Ops::load(buf, x, tid);
+            __syncthreads();
+            Ops::store(buf, tw, x, tid);
+        }
+        __syncthreads();
+        StagesAll<F, NT, NA, Ns * R, Rest...>::run(buf, tw, tid);
     }
 };
 

@@ -556,6 +556,167 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
     }
 }
 
+// The same row stage with a three-stage factorisation (3000 = 25 * 15 * 8: composite butterflies in registers,
+// oip_fft_dev.h) and every stage dealt over all buffers at once: a point crosses LDS three times per transform instead
+// of five, a stage costs two barriers for all buffers instead of one per buffer.  Single-line items keep LDS accesses
+// 8 bytes wide and conflict-free (the first stage stores at a 25-point stride: 100 dwords, odd multiple of 4).
+template <int F, int NT, int NARR, int NOUT, int... Rs>
+__global__ __launch_bounds__(NT) void corr_rows3_kernel(FusedJob fj, int M, int P, const int *__restrict__ ypos,
+                                                       const float2 *__restrict__ twF)
+{
+    constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
+    constexpr int N = F;
+    constexpr int NIT = (N + NT - 1) / NT;
+    __shared__ __align__(16) float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
+    __shared__ float2 tw[TWN];
+    const int dbg = fj.dbg;
+    const int half = M / 2;
+    int ky = blockIdx.x;
+    if (ky > half) return;
+    for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
+    // Lines move 16 bytes (two points) per lane: half the vector-memory and LDS instructions of 8-byte
+    // accesses -- their operand traffic shares the SIMD-to-LDS path with the stages' ds_writes.
+    static_assert(N % 2 == 0, "two points per lane");
+    constexpr int NIT2 = (N / 2 + NT - 1) / NT;
+    float4 la[NARR][NIT2], lb[NARR][NIT2];
+    float4 *buf4 = reinterpret_cast<float4 *>(buf);
+    // rows of the line pair whose loads are in la/lb (n1, n2) and of the pair in LDS (s1, s2)
+    // (row positions come from a per-plan table: decoding them with the digit loop cost ~300 scalar
+    // instructions and four dependent scalar loads per iteration, on every wave at the same time)
+    long n1 = (long)ypos[ky] * P, n2 = (long)ypos[ky ? M - ky : 0] * P;
+    auto fetch = [&](int tid) {
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) {
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                // lanes past the end of the line re-read its last pair (never committed): a select on
+                // the loaded value would need the load to have completed -- a wait inside the prefetch
+                int q = tid + it * NT;
+                q = q < N / 2 ? q : N / 2 - 1;
+                la[a][it] = *reinterpret_cast<const float4 *>(fj.z[a] + n1 + 2 * q);
+                lb[a][it] = *reinterpret_cast<const float4 *>(fj.z[a] + n2 + 2 * q);
+            }
+        }
+    };
+    auto commit = [&](int tid) {
+#pragma unroll
+        for (int a = 0; a < NARR; ++a) {
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < N / 2) {
+                    // [point][line] interleave: (2q, line 0), (2q, line 1), (2q+1, line 0), (2q+1, line 1):
+                    // two 16-byte writes 32 bytes apart per lane (2-way bank conflict; four 8-byte writes
+                    // would be 4-way).  The repacking moves sit here, after the loads have landed.
+                    buf4[a * F + 2 * q] = make_float4(la[a][it].x, la[a][it].y, lb[a][it].x, lb[a][it].y);
+                    buf4[a * F + 2 * q + 1] = make_float4(la[a][it].z, la[a][it].w, lb[a][it].z, lb[a][it].w);
+                }
+            }
+        }
+    };
+    fetch(threadIdx.x);
+    commit(threadIdx.x);
+    long s1 = n1, s2 = n2;
+    __syncthreads();
+    for (; ky <= half; ky += gridDim.x) {
+        // opaque per iteration: keeps the stage address arithmetic from being hoisted out of this
+        // loop, where it would occupy registers for the whole kernel
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const bool pair = s1 != s2;
+        // The lines of the NEXT pair are requested first and committed at the bottom of this same
+        // iteration: the registers holding them then never cross the loop's back edge.  (Carried across
+        // it, the register allocator gave the loop-header values other registers than the loads'
+        // destinations and copied right after the loads -- waiting for them at the point of issue.)
+        const int kn = ky + gridDim.x;
+        const bool more = kn <= half;
+        if (more && !(dbg & 8)) {
+            n1 = (long)ypos[kn] * P;
+            n2 = (long)ypos[M - kn] * P;
+            fetch(tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 1)) oipfft::StagesAll<F, NT, NARR, 1, Rs...>::run(buf, tw, tid);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int kx = tid + it * NT;
+            if (kx >= N || (dbg & 2)) continue;
+            const int nkx = kx ? N - kx : 0;
+            const bool edge_col = (kx == 0) || (2 * kx == N);
+            const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+            // The two job shapes are fixed (xpower_stage checks them on the host), so which spectrum and
+            // slot feeds which correlation is known here -- no run-time selects:
+            //   1 spectrum : Y0 = C(z0.re, z0.im)
+            //   3 spectra  : A = z0.re against z0.im, z1.re | z1.im, z2.(re or im: fj.pb[3])
+            const float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
+            const float2 A = spec_of(0, zk0, zm0);
+            float2 y0, y0m, y1 = make_float2(0.f, 0.f), y1m = make_float2(0.f, 0.f);
+            {
+                const float2 C = cross_power_bin_fast(A, spec_of(1, zk0, zm0), real_bin, edge_col);
+                y0 = C;
+                y0m = make_float2(C.x, -C.y);
+            }
+            if (NARR == 3) {
+                const float2 zk1 = buf[2 * F + 2 * kx], zm1 = buf[2 * F + 2 * nkx + 1];
+                const float2 zk2 = buf[4 * F + 2 * kx], zm2 = buf[4 * F + 2 * nkx + 1];
+                float2 C = cross_power_bin_fast(A, spec_of(0, zk1, zm1), real_bin, edge_col);
+                y0.x -= C.y; y0.y += C.x; y0m.x += C.y; y0m.y += C.x;                        // + i C, + i conj(C)
+                C = cross_power_bin_fast(A, spec_of(1, zk1, zm1), real_bin, edge_col);
+                y1 = C;
+                y1m = make_float2(C.x, -C.y);
+                const float2 B3 = fj.pb[3] ? spec_of(1, zk2, zm2) : spec_of(0, zk2, zm2);
+                C = cross_power_bin_fast(A, B3, real_bin, edge_col);
+                y1.x -= C.y; y1.y += C.x; y1m.x += C.y; y1m.y += C.x;
+            }
+            // inverse = conj(forward(conj(.)))
+            buf[2 * kx] = make_float2(y0.x, -y0.y);
+            buf[2 * nkx + 1] = pair ? make_float2(y0m.x, -y0m.y) : make_float2(0.f, 0.f);
+            if (NOUT == 2) {
+                buf[2 * F + 2 * kx] = make_float2(y1.x, -y1.y);
+                buf[2 * F + 2 * nkx + 1] = pair ? make_float2(y1m.x, -y1m.y) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        if (!(dbg & 4)) oipfft::StagesAll<F, NT, NOUT, 1, Rs...>::run(buf, tw, tid);
+        // Results leave LDS through registers so that the next pair can be committed before the stores
+        // are issued.
+        float4 ya[NOUT][NIT2], yb[NOUT][NIT2];      // line ky / line -ky, two points each
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < N / 2) {
+                    const float4 u = buf4[o * F + 2 * q], v = buf4[o * F + 2 * q + 1];
+                    ya[o][it] = make_float4(u.x, -u.y, v.x, -v.y);
+                    yb[o][it] = make_float4(u.z, -u.w, v.z, -v.w);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) commit(tid);
+        __builtin_amdgcn_sched_barrier(0);
+        const long o1 = s1, o2 = s2;
+        s1 = n1; s2 = n2;
+        if (!(dbg & 16)) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float2 *out = fj.out[o];
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int q = tid + it * NT;
+                    if (q < N / 2) {
+                        *reinterpret_cast<float4 *>(out + o1 + 2 * q) = ya[o][it];
+                        if (pair) *reinterpret_cast<float4 *>(out + o2 + 2 * q) = yb[o][it];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 struct FusedRow {
     int F, threads, fwd_threads;
     void (*fwd1)(FusedJob, int, int, const int *, const float2 *);        // one spectrum -> one output
@@ -948,6 +1109,13 @@ int xpower_stage(oip_ctx *ctx, const OipFft2dPlan *pl, const RowStage &rs, const
         long grid = (long)ctx->cu_count * per_cu;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
         OipProfScope prof(ctx, "corr_rows_kernel");
+        const char *env3 = getenv("OIP_ROWS3");                         // experiment knob: 0 = the five-stage kernel
+        if (three && rs.k->F == 3000 && !(env3 && atoi(env3) == 0)) {
+            long g3 = ctx->cu_count;
+            if (g3 > pl->M / 2 + 1) g3 = pl->M / 2 + 1;
+            hipLaunchKernelGGL((corr_rows3_kernel<3000, 768, 3, 2, 25, 15, 8>), dim3((unsigned)g3), dim3(768), 0, ctx->stream, fj, pl->M, pl->P,
+                               pl->d_ypos, twF);
+        } else
         hipLaunchKernelGGL(one ? rs.k->fwd1 : rs.k->fwd3, dim3((unsigned)grid), dim3(rs.k->fwd_threads), 0, ctx->stream, fj, pl->M,
                            pl->P, pl->d_ypos, twF);
     } else {

@@ -560,6 +560,8 @@ __global__ __launch_bounds__(NT) void corr_rows_kernel(FusedJob fj, int M, int P
 // oip_fft_dev.h) and every stage dealt over all buffers at once: a point crosses LDS three times per transform instead
 // of five, a stage costs two barriers for all buffers instead of one per buffer.  Single-line items keep LDS accesses
 // 8 bytes wide and conflict-free (the first stage stores at a 25-point stride: 100 dwords, odd multiple of 4).
+// Measured per launch: 0.80 -> 0.76 ms at 3000 points.  The 1250-point geometry (25 * 25 * 2) was measured too and is
+// slower this way (0.46 vs 0.33 ms: eight rounds of radix-2 items), so it keeps the five-stage kernel.
 template <int F, int NT, int NARR, int NOUT, int... Rs>
 __global__ __launch_bounds__(NT) void corr_rows3_kernel(FusedJob fj, int M, int P, const int *__restrict__ ypos,
                                                        const float2 *__restrict__ twF)

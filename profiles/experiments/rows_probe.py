@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import opticalimageprocessor_amd as oip
 
-W, L = 30000, 16000
+W, L = int(os.environ.get("PROBE_W", "30000")), 16000
 ctx = oip.Context(0)
 s = torch.cuda.Stream()
 torch.cuda.set_stream(s)

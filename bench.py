@@ -78,12 +78,17 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         # whole row stage (forward rows + cross-power + inverse rows): every spectrum of the job read
         # once, every output written once -- 3 in + 2 out for a PAN-vs-4-bands unit, 1 + 1 for a CCD pair
         "corr_rows_kernel": 8.0 * MN * rows_arrays,
+        # row stage of a pair of units with the horizontal up-sampling on the band spectra: PAN_A + i PAN_B and four
+        # quarter-width band arrays in, four outputs
+        "corr_rows_up_kernel": 8.0 * MN * 6.0,
+        # column passes of one quarter-width band array (two vertically up-sampled f32 images in)
+        "fft_pass_ct_kernel_F128_pack_quarter": 8.0 * MN / 4.0 + 2 * 4.0 * win / 4.0,
+        "fft_pass_ct_kernel_F125_quarter": 16.0 * MN / 4.0,
         # vertical half of the x4 up-sampling, the eight bands of a pair of units per launch: u16 band
         # window in (win/16 px), f32 rows x4 out (win/4 px)
         "resize_cubic_v_kernel": 8 * (4.0 * win / 4.0 + 2.0 * win / 16.0),
-        # first forward pass of a pair of units (5 launches): PAN windows as u16 (2 launches x 2 B), eight
-        # vertically up-sampled bands (8 x win/4 x 4 B), one complex array written per launch
-        "fft_pass_ct_kernel_F128_pack": 8.0 * MN + (2 * 2.0 * win + 8 * 4.0 * win / 4.0) / 5.0,
+        # first forward pass of the two PAN windows of a pair of units (u16 in, one complex array out)
+        "fft_pass_ct_kernel_F128_pack": 8.0 * MN + 2 * 2.0 * win,
         # last inverse pass: reads the array, keeps only per-tile maxima
         "fft_pass_ct_kernel_F128_peak": 8.0 * MN,
         "resize_cubic_kernel": 4.0 * win + 2.0 * win / 16.0,  # u16 window in, x4 f32 out

@@ -1328,9 +1328,9 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     }
     long blocks = blocks_override > 0 ? blocks_override : pass_blocks(p);
     if (blocks <= 0 || blocks > 0x7fffffffL) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft pass grid too large");
-    char pname[48];
-    snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d%s" : "fft_pass_kernel_F%d%s"), p.F,
-             io.load_kind == 1 ? "_pack" : (io.store_kind == 1 ? "_peak" : ""));
+    char pname[64];
+    snprintf(pname, sizeof pname, blocks_override > 0 ? "fft_window_F%d" : (p.fast >= 0 ? "fft_pass_ct_kernel_F%d%s%s" : "fft_pass_kernel_F%d%s%s"), p.F,
+             io.load_kind == 1 ? "_pack" : (io.store_kind == 1 ? "_peak" : ""), blocks_override > 0 || !ctx->prof_tag ? "" : ctx->prof_tag);
     OipProfScope prof(ctx, pname);
     { const char *e = getenv("OIP_PACK_DBG"); p.dbg = e ? atoi(e) : 0; }
     dim3 grid3((unsigned)blocks);

@@ -36,6 +36,8 @@ struct OipResizeTab {
     float *d_alpha;     // dw x 4
     int *d_yofs;
     float *d_beta;      // dh x 4
+    void *d_xspec;      // float2 [5][dw]: the horizontal up-sampling as an operator on spectra (built on first use)
+    int xspec_state;    // 0 not tried, 1 built, -1 the geometry has no such form
 };
 
 // OpenCV imgwarp.cpp interpolateCubic, f32, evaluated on the host exactly as OpenCV does
@@ -82,6 +84,7 @@ struct oip_ctx {
     std::vector<oip_prof_entry> prof;
     std::vector<oip_prof_pending> prof_pending;
     hipEvent_t prof_chain = nullptr;    // end event of the previous scope while nothing else has been enqueued since
+    const char *prof_tag = nullptr;     // appended to the FFT pass names (the quarter-width band transforms report apart)
 };
 
 int oip_fail(oip_ctx *ctx, int code, const char *fmt, ...);

@@ -719,6 +719,272 @@ __global__ __launch_bounds__(NT) void corr_rows3_kernel(FusedJob fj, int M, int 
     }
 }
 
+// ---- row stage with the x4 cubic up-sampling of the bands applied to their spectra -------------------------------
+//
+// cv::resize(INTER_CUBIC) by exactly 4 is linear: along one axis, out = R s with R = C + E, where C is the circulant
+// operator "zero-stuff by 4, convolve with the 16-tap kernel h" and E holds what edge replication changes -- it is
+// non-zero in the columns of the source samples {0, 1, n-2, n-1} only (the taps that leave the image are clamped to
+// sample 0 or n-1 instead of wrapping to n-2, n-1, 0, 1).  So the N = 4n point transform of an up-sampled line is
+//     DFT_N(R s)[k] = H[k] DFT_n(s)[k mod n] + sum_j G_j[k] s[J_j],       H = DFT_N(h), G_j = DFT_N(E[:, J_j])
+// -- a 750-point transform, one complex multiply and four multiply-adds per bin instead of a 3000-point transform of
+// the up-sampled line, and the four band images of a unit need no full-size column passes at all: their columns are
+// transformed at the width of the band window (16000 x 750, a quarter of the array).  The identity is exact; what
+// changes against transforming the up-sampled image is the rounding (the f32 rounding of every up-sampled pixel is
+// replaced by the rounding of H, G and the products), 1e-6 px on the shifts -- the size of the difference between
+// any two float FFTs (tests/test_gpu_correlation.py compares both routes and the oracle, which up-samples first).
+// The vertical taps are still applied in the image domain (resize_cubic_v), with cv::resize's own arithmetic.
+//
+// One launch serves a pair of units: zp = PAN_A + i PAN_B (full width), four narrow arrays (bands 0|1 and 2|3 of unit
+// A, then of unit B) and four outputs Y = C(PAN, band 2a) + i C(PAN, band 2a+1).  LDS holds the PAN line pair, one
+// more full-width buffer and the eight narrow lines (144 KB): after the forward transforms the PAN spectra of the
+// thread's bins move to registers, and the outputs are formed, inverse-transformed and stored two at a time in the two
+// full-width buffers.  A thread owns the same bins kx of every line pair (and their mirrors in line -ky): its H and G
+// values come from the L2-resident table every round.
+struct UpRowsJob {
+    const float2 *zp;       // pitch P
+    const float2 *zn;       // four narrow arrays, zn_stride elements apart, pitch Pn
+    long zn_stride;
+    int Pn;
+    float2 *out[4];
+    const float2 *xtab;     // [5][N]: H, G_0 .. G_3
+    int nout;               // 4, or 2 for a single unit (arrays 2 and 3 are not read)
+    int dbg;                // experiment mask like FusedJob::dbg
+};
+
+// conj(a) b, acc + a b, acc + conj(a) b on packed-f32 instructions (two each; operand selection as in oipfft::cmul).
+// The spectral operator is part of the transform: multiply-adds fuse (see oip_fft_dev.h).
+__device__ __forceinline__ float2 cmulj(float2 a, float2 b)
+{
+    oipfft::oip_v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)), "v"(t));
+    return oipfft::to_f2(r);
+}
+__device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 acc)
+{
+    oipfft::oip_v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)), "v"(oipfft::to_v(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)), "v"(t));
+    return oipfft::to_f2(r);
+}
+__device__ __forceinline__ float2 cfmaj(float2 a, float2 b, float2 acc)
+{
+    oipfft::oip_v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)), "v"(oipfft::to_v(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(oipfft::to_v(a)), "v"(oipfft::to_v(b)), "v"(t));
+    return oipfft::to_f2(r);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, int P, const int *__restrict__ ypos,
+                                                          const float2 *__restrict__ twF, const float2 *__restrict__ twS)
+{
+    constexpr int F = 3000, S = F / 4;
+    constexpr int TWF = oipfft::TwTable<F, 25, 15, 8>::value(), TWS = oipfft::TwTable<S, 25, 15, 2>::value();
+    constexpr int NB = (F + NT - 1) / NT;                           // bins kx = tid + NT * it of line ky per thread
+    __shared__ __align__(16) float2 buf[2 * 2 * F + 4 * 2 * S];    // PAN / output 0 | output 1 | narrow arrays; [point][line]
+    __shared__ float2 tw[TWF], tws[TWS];
+    __shared__ float2 edge[4][2][4];                               // [array][line][j]: narrow line samples 0, 1, S-2, S-1
+    __shared__ float2 edgeA[2][2];                                 // PAN spectra (unit A, unit B) at kx = 0 and N/2
+    float2 *bufN = buf + 4 * F;
+    float4 *buf4 = reinterpret_cast<float4 *>(buf), *buf4N = reinterpret_cast<float4 *>(bufN);
+    const int dbg = fj.dbg;
+    const int half = M / 2;
+    int ky = blockIdx.x;
+    if (ky > half) return;
+    for (int i = threadIdx.x; i < TWF; i += NT) tw[i] = twF[i];
+    for (int i = threadIdx.x; i < TWS; i += NT) tws[i] = twS[i];
+    constexpr int NIT2 = (F / 2 + NT - 1) / NT;
+    constexpr int NQ = 4 * (S / 2);                 // 16-byte pieces of one line of the four narrow arrays
+    constexpr int NITN = (NQ + NT - 1) / NT;
+    float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
+    long n1 = ypos[ky], n2 = ypos[ky ? M - ky : 0];     // rows (the pitches differ between zp and zn)
+    auto fetch = [&](int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it) {
+            int q = tid + it * NT;
+            q = q < F / 2 ? q : F / 2 - 1;
+            la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
+            lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < NITN; ++it) {
+            int q = tid + it * NT;
+            q = q < NQ ? q : NQ - 1;
+            const int a = q / (S / 2), i = q - a * (S / 2);
+            const float2 *z = fj.zn + a * fj.zn_stride + 2 * i;
+            na[it] = *reinterpret_cast<const float4 *>(z + n1 * fj.Pn);
+            nb[it] = *reinterpret_cast<const float4 *>(z + n2 * fj.Pn);
+        }
+    };
+    auto commit = [&](int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it) {
+            const int q = tid + it * NT;
+            if (q < F / 2) {
+                buf4[2 * q] = make_float4(la[it].x, la[it].y, lb[it].x, lb[it].y);
+                buf4[2 * q + 1] = make_float4(la[it].z, la[it].w, lb[it].z, lb[it].w);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NITN; ++it) {
+            const int q = tid + it * NT;
+            if (q < NQ) {
+                const int a = q / (S / 2), i = q - a * (S / 2);
+                buf4N[a * S + 2 * i] = make_float4(na[it].x, na[it].y, nb[it].x, nb[it].y);
+                buf4N[a * S + 2 * i + 1] = make_float4(na[it].z, na[it].w, nb[it].z, nb[it].w);
+                if (i == 0 || i == S / 2 - 1) {
+                    const int j = i ? 2 : 0;
+                    edge[a][0][j] = make_float2(na[it].x, na[it].y); edge[a][0][j + 1] = make_float2(na[it].z, na[it].w);
+                    edge[a][1][j] = make_float2(nb[it].x, nb[it].y); edge[a][1][j + 1] = make_float2(nb[it].z, nb[it].w);
+                }
+            }
+        }
+    };
+    fetch(threadIdx.x);
+    commit(threadIdx.x);
+    long s1 = n1, s2 = n2;
+    __syncthreads();
+    for (; ky <= half; ky += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const bool pair = s1 != s2;
+        const int kn = ky + gridDim.x;
+        const bool more = kn <= half;
+        if (more && !(dbg & 8)) {
+            n1 = ypos[kn];
+            n2 = ypos[M - kn];
+            fetch(tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 1)) {
+            oipfft::StagesAll<F, NT, 1, 1, 25, 15, 8>::run(buf, tw, tid);
+            oipfft::StagesAll<S, NT, 4, 1, 25, 15, 2>::run(bufN, tws, tid);
+        }
+        // PAN spectra of this thread's bins (unit A in the real slot, unit B in the imaginary one); those of the two
+        // edge columns (kx = 0, N/2: divSpectrums' double-precision and real-only formulas) also go to edgeA
+        float2 Aa[NB], Ab[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
+            if (kx < F) {
+                const float2 zk = buf[2 * kx], zm = buf[2 * nkx + 1];
+                Aa[r] = spec_of(0, zk, zm);
+                Ab[r] = spec_of(1, zk, zm);
+                if (kx == 0 || 2 * kx == F) { edgeA[kx ? 1 : 0][0] = Aa[r]; edgeA[kx ? 1 : 0][1] = Ab[r]; }
+            }
+        }
+        // outputs o0, o0 + 1 (narrow arrays of the same index) into the two full-width buffers
+        auto xround = [&](int o0, const float2 (&A)[NB]) {
+            if (dbg & 2) return;
+            // H and G of the thread's bins: re-read every round (L2-resident, 120 KB) -- held in registers across
+            // the transforms they cost 40 VGPRs the stages need
+            float2 H[NB], G[NB][4];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                int kx = tid + NT * r;
+                kx = kx < F ? kx : 0;
+                H[r] = fj.xtab[kx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) G[r][j] = fj.xtab[(1 + j) * F + kx];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float2 *zn = bufN + (o0 + h) * 2 * S;
+                float2 e0[4], e1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { e0[j] = edge[o0 + h][0][j]; e1[j] = edge[o0 + h][1][j]; }
+                float2 *ob = buf + h * 2 * F;
+#pragma unroll
+                for (int r = 0; r < NB; ++r) {
+                    const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
+                    if (kx >= F) continue;
+                    const int c = kx % S, cm = c ? S - c : 0;      // the narrow bin of kx and of -kx
+                    const float2 zn0 = zn[2 * c], zn1 = zn[2 * cm + 1];
+                    // packed band spectrum at (ky, kx) and at (-ky, -kx): H and G of -kx are the conjugates
+                    float2 Z0 = oipfft::cmul(H[r], zn0), Z1 = cmulj(H[r], zn1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Z0 = cfma(G[r][j], e0[j], Z0); Z1 = cfmaj(G[r][j], e1[j], Z1); }
+                    const float2 C1 = cross_power_bin_fast(A[r], spec_of(0, Z0, Z1), false, false);
+                    const float2 C2 = cross_power_bin_fast(A[r], spec_of(1, Z0, Z1), false, false);
+                    // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
+                    ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                    ob[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+                }
+            }
+            // the two edge columns again with their own formulas (one copy of that code, two threads of the block)
+#pragma unroll 1
+            for (int r = 0; r < NB; ++r) {
+                const int kx = tid + NT * r;
+                if (kx != 0 && 2 * kx != F) continue;
+                const bool real_bin = ky == 0 || 2 * ky == M;
+                const float2 Ae = edgeA[kx ? 1 : 0][o0 ? 1 : 0];
+                float2 He = fj.xtab[kx], Ge[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ge[j] = fj.xtab[(1 + j) * F + kx];
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {
+                    const float2 *zn = bufN + (o0 + h) * 2 * S;
+                    float2 Z0 = oipfft::cmul(He, zn[0]), Z1 = cmulj(He, zn[1]);       // kx = 0 and N/2 both map to narrow bin 0
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { Z0 = cfma(Ge[j], edge[o0 + h][0][j], Z0); Z1 = cfmaj(Ge[j], edge[o0 + h][1][j], Z1); }
+                    const float2 C1 = cross_power_bin(Ae, spec_of(0, Z0, Z1), real_bin, true);
+                    const float2 C2 = cross_power_bin(Ae, spec_of(1, Z0, Z1), real_bin, true);
+                    float2 *ob = buf + h * 2 * F;
+                    ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                    ob[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);   // -kx == kx here
+                }
+            }
+        };
+        float4 ya[2][NIT2], yb[2][NIT2];
+        auto finish = [&]() {           // inverse row transform of the two buffers; results to registers
+            __syncthreads();
+            asm volatile("" : "+v"(tid));
+            if (!(dbg & 4)) oipfft::StagesAll<F, NT, 2, 1, 25, 15, 8>::run(buf, tw, tid);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int q = tid + it * NT;
+                    if (q < F / 2) {
+                        const float4 u = buf4[o * F + 2 * q], v = buf4[o * F + 2 * q + 1];
+                        ya[o][it] = make_float4(u.x, -u.y, v.x, -v.y);
+                        yb[o][it] = make_float4(u.z, -u.w, v.z, -v.w);
+                    }
+                }
+            }
+            __syncthreads();
+        };
+        auto store = [&](int o0) {
+            if (dbg & 16) return;
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                float2 *out = fj.out[o0 + o];
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int q = tid + it * NT;
+                    if (q < F / 2) {
+                        *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = ya[o][it];
+                        if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = yb[o][it];
+                    }
+                }
+            }
+        };
+        xround(0, Aa);
+        finish();
+        store(0);
+        if (fj.nout == 4) {
+            xround(2, Ab);
+            finish();
+        }
+        if (more) commit(tid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (fj.nout == 4) store(2);
+        s1 = n1; s2 = n2;
+        __syncthreads();
+    }
+}
+
 struct FusedRow {
     int F, threads, fwd_threads;
     void (*fwd1)(FusedJob, int, int, const int *, const float2 *);        // one spectrum -> one output
@@ -799,7 +1065,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Workspace carve-up for one correlation unit
 struct PcWork {
     float2 *z[5];
-    float2 *y[2];
+    float2 *y[4];
     float *fa;          // base window, f32
     float *fb[8];       // second images, f32 (up-sampled bands; two units' worth)
     float *fsmall;      // MSS window before resize
@@ -821,7 +1087,7 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     if (rc) return rc;
     char *p = (char *)ws;
     for (int i = 0; i < 5; ++i) { w->z[i] = i < nz ? (float2 *)p : nullptr; if (i < nz) p += zbytes; }
-    for (int i = 0; i < 2; ++i) { w->y[i] = i < ny ? (float2 *)p : nullptr; if (i < ny) p += zbytes; }
+    for (int i = 0; i < 4; ++i) { w->y[i] = i < ny ? (float2 *)p : nullptr; if (i < ny) p += zbytes; }
     w->fa = (float *)p; p += fbytes;
     for (int i = 0; i < 8; ++i) { w->fb[i] = i < nfb ? (float *)p : nullptr; if (i < nfb) p += fbytes; }
     w->fsmall = (float *)p; p += sbytes;
@@ -872,6 +1138,7 @@ int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeT
     }
     OipResizeTab t;
     t.sw = sw; t.sh = sh; t.dw = dw; t.dh = dh;
+    t.d_xspec = nullptr; t.xspec_state = 0;
     // the x4 kernel needs every output's first tap inside its source pixel's 5-wide window
     t.x4 = dw == 4 * sw && dh == 4 * sh;
     for (int dx = 0; dx < dw && t.x4; ++dx) { int o = (xofs[dx] - 1) - (dx / 4 - 2); t.x4 = o == 0 || o == 1; }
@@ -988,6 +1255,68 @@ int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int
     hipLaunchKernelGGL(resize_cubic_v_kernel<SrcT>, dim3((sw + kBlock - 1) / kBlock, (dh + kVRows - 1) / kVRows, count), dim3(kBlock), 0,
                        ctx->stream, vb, sw, sh, dh, (*tab)->d_yofs, reinterpret_cast<const float4 *>((*tab)->d_beta));
     OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
+
+// H and G_j of the horizontal x4 cubic up-sampling n -> N = 4 n as an operator on spectra (see corr_rows_up_kernel),
+// built in double from the same f32 taps the image-domain loader applies: h[e] is the tap that output d = e + 4 p
+// puts on source sample p, G_j is the transform of what clamping (instead of wrapping) the out-of-image taps adds to
+// column j of the operator, j in {0, 1, n-2, n-1}.  *out stays null when the geometry has no such form.
+int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, const float2 **out)
+{
+    OipResizeTab *t = const_cast<OipResizeTab *>(ctab);
+    *out = nullptr;
+    if (t->xspec_state == 1) { *out = (const float2 *)t->d_xspec; return OIP_OK; }
+    if (t->xspec_state < 0) return OIP_OK;
+    t->xspec_state = -1;
+    const int n = t->sw, N = t->dw;
+    if (N != 4 * n || n < 8 || !t->x4h) return OIP_OK;
+    const double scale = 1. / ((double)N / n);
+    std::vector<double> h(N, 0.0), g[4];
+    std::vector<char> hset(N, 0);
+    for (auto &v : g) v.assign(N, 0.0);
+    const int J[4] = {0, 1, n - 2, n - 1};
+    auto jidx = [&](int p) { for (int j = 0; j < 4; ++j) if (J[j] == p) return j; return -1; };
+    for (int d = 0; d < N; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        const int sx = (int)floorf(fx);
+        fx -= sx;
+        float w[4];
+        oip_interpolate_cubic_host(fx, w);
+        for (int j = 0; j < 4; ++j) {
+            const int p = sx - 1 + j;
+            const int e = ((d - 4 * p) % N + N) % N;
+            if (!hset[e]) { h[e] = w[j]; hset[e] = 1; }
+            else if (h[e] != (double)w[j]) return OIP_OK;          // taps not periodic in d: no circulant part
+            if (p < 0 || p >= n) {
+                const int a = jidx(p < 0 ? 0 : n - 1), b = jidx(((p % n) + n) % n);
+                if (a < 0 || b < 0) return OIP_OK;
+                g[a][d] += w[j];
+                g[b][d] -= w[j];
+            }
+        }
+    }
+    std::vector<float2> tab((size_t)5 * N);
+    const double step = -2.0 * 3.14159265358979323846 / N;
+    auto dft = [&](const std::vector<double> &v, float2 *dst) {
+        std::vector<int> nz;
+        for (int d = 0; d < N; ++d) if (v[d] != 0.0) nz.push_back(d);
+        for (int k = 0; k < N; ++k) {
+            double re = 0.0, im = 0.0;
+            for (int d : nz) {
+                const double ang = step * (double)(((long)k * d) % N);
+                re += v[d] * cos(ang);
+                im += v[d] * sin(ang);
+            }
+            dst[k] = make_float2((float)re, (float)im);
+        }
+    };
+    dft(h, tab.data());
+    for (int j = 0; j < 4; ++j) dft(g[j], tab.data() + (size_t)(1 + j) * N);
+    OIP_HIP(ctx, hipMalloc(&t->d_xspec, sizeof(float2) * tab.size()));
+    OIP_HIP(ctx, hipMemcpy(t->d_xspec, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+    t->xspec_state = 1;
+    *out = (const float2 *)t->d_xspec;
     return OIP_OK;
 }
 
@@ -1214,6 +1543,57 @@ int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, R
     return correlate_four(ctx, pl, w, rs, w.z[2], w.z[3], w.z[4], 1, d_resB);
 }
 
+// The same pair of units with the horizontal up-sampling applied to the band spectra (corr_rows_up_kernel): one
+// full-width forward transform (PAN_A + i PAN_B; aB may be absent), four quarter-width column transforms of the
+// vertically up-sampled bands (V images, rows x band_cols, packed two by two), one row-stage launch, four inverse
+// column transforms.  Against correlate_two_units: 2 instead of 5 array-sized forward column transforms, 6 instead of
+// 10 row transforms of 3000 points (in units of one).
+struct UpPath {
+    const OipFft2dPlan *narrow;     // M x band_cols
+    const float2 *xtab;
+};
+int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, const PcWork &w, RealSrc aA, RealSrc aB, const RealSrc *v /* 4 or 8 */,
+                       int nunits, int rows, int cols, int band_cols, double *d_resA, double *d_resB)
+{
+    int rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], aA, nunits > 1 ? aB : src_none(), rows, cols, true))) return rc;
+    const long zn_stride = (long)up.narrow->M * up.narrow->P;
+    const int narr = 2 * nunits;
+    ctx->prof_tag = "_quarter";
+    for (int a = 0; a < narr && !rc; ++a)
+        rc = forward_packed(ctx, up.narrow, w.z[1] + a * zn_stride, src_f32(v[2 * a].v), src_f32(v[2 * a + 1].v), rows, band_cols, true);
+    ctx->prof_tag = nullptr;
+    if (rc) return rc;
+    const float2 *twF, *twS;
+    if ((rc = oip_fft_table(ctx, 3000, &twF)) || (rc = oip_fft_table(ctx, 750, &twS))) return rc;
+    UpRowsJob fj;
+    memset(&fj, 0, sizeof fj);
+    fj.zp = w.z[0];
+    fj.zn = w.z[1];
+    fj.zn_stride = zn_stride;
+    fj.Pn = up.narrow->P;
+    for (int o = 0; o < 4; ++o) fj.out[o] = w.y[o];
+    fj.xtab = up.xtab;
+    fj.nout = narr;
+    { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
+    {
+        OipProfScope prof(ctx, "corr_rows_up_kernel");
+        long grid = ctx->cu_count;
+        if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
+        const char *et = getenv("OIP_UP_THREADS");                      // experiment knob (measured: 1.41 ms with 512 threads, 1.48 with 768)
+        if (et && atoi(et) == 768)
+            hipLaunchKernelGGL(corr_rows_up_kernel<768>, dim3((unsigned)grid), dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        else
+            hipLaunchKernelGGL(corr_rows_up_kernel<512>, dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        OIP_HIP(ctx, hipGetLastError());
+    }
+    for (int o = 0; o < narr; ++o) {
+        double *res = (o < 2 ? d_resA : d_resB) + 6 * (o & 1);
+        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[o], 2, res, true))) return rc;
+    }
+    return OIP_OK;
+}
+
 int fetch_results(oip_ctx *ctx, int count, double *host_out)
 {
     ctx->prof_chain = nullptr;
@@ -1355,13 +1735,27 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     const OipFft2dPlan *pl;
     int rc = oip_fft2d_plan(ctx, M, N, &pl);
     if (rc) return rc;
+    // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
+    // (u16 -> f32, rows x band_cols), the horizontal pass inside the FFT loader -- or, for the exact x4 geometry at
+    // 3000 columns, on the band spectra in the row stage (corr_rows_up_kernel; OIP_SPECTRAL_UP=0 keeps the loader).
+    const OipResizeTab *tab = nullptr;
+    if ((rc = resize_tables(ctx, band_cols, band_rows, cols, rows, &tab))) return rc;
+    UpPath up{nullptr, nullptr};
+    {
+        const char *e = getenv("OIP_SPECTRAL_UP");
+        const bool want = !(e && atoi(e) == 0);
+        if (want && rows == 4 * band_rows && cols == 4 * band_cols && M == rows && N == cols && N == 3000 && row_stage(pl).level == 2) {
+            if ((rc = upsample_spectrum_tables(ctx, tab, &up.xtab))) return rc;
+            if (up.xtab) {
+                if ((rc = oip_fft2d_plan(ctx, M, band_cols, &up.narrow))) return rc;
+                if (4 * up.narrow->P > pl->P || up.narrow->N != band_cols) up.xtab = nullptr;      // the four narrow arrays share one array-sized slot
+            }
+        }
+    }
     PcWork w;
-    if ((rc = carve(ctx, pl, rows, band_cols, 0, 5, 2, 8, &w))) return rc;      // f32 scratch: the V images
+    if ((rc = carve(ctx, pl, rows, band_cols, 0, up.xtab ? 2 : 5, up.xtab ? 4 : 2, 8, &w))) return rc;      // f32 scratch: the V images
     if ((rc = oip_small(ctx, sizeof(double) * 12 * (size_t)(n > 0 ? n : 1)))) return rc;
     double *d_res = (double *)ctx->d_small;
-    // PAN window: read as u16 by the FFT loader.  MSS windows: the vertical cubic pass runs as a kernel
-    // (u16 -> f32, rows x band_cols), the horizontal pass inside the FFT loader.
-    const OipResizeTab *tab = nullptr;
     // vertical passes of all bands of one or two units in one launch
     auto upsample = [&](const IbUnit *const *uns, int nun, float *const *fb, RealSrc *out) -> int {
         const uint16_t *srcs[kVBatch];
@@ -1380,6 +1774,11 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
         const IbUnit &A = units[k], &B = units[k + 1];
         const IbUnit *two[2] = {&A, &B};
         if ((rc = upsample(two, 2, w.fb, sAB))) return rc;
+        if (up.xtab) {
+            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_u16(B.pan, B.pan_pitch), sAB, 2, rows, cols, band_cols,
+                                         d_res + 12 * k, d_res + 12 * (k + 1)))) return rc;
+            continue;
+        }
         const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
         if ((rc = correlate_two_units(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, src_u16(B.pan, B.pan_pitch), sAB + 4, rows, cols,
                                       d_res + 12 * k, d_res + 12 * (k + 1), &vt))) return rc;
@@ -1388,8 +1787,12 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
         const IbUnit &A = units[k];
         const IbUnit *one[1] = {&A};
         if ((rc = upsample(one, 1, w.fb, sAB))) return rc;
-        const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
-        if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, rows, cols, d_res + 12 * k, &vt))) return rc;
+        if (up.xtab) {
+            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_none(), sAB, 1, rows, cols, band_cols, d_res + 12 * k, nullptr))) return rc;
+        } else {
+            const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
+            if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, rows, cols, d_res + 12 * k, &vt))) return rc;
+        }
     }
     if (n > 0 && (rc = fetch_results(ctx, 12 * n, host_out))) return rc;
     return OIP_OK;

@@ -48,6 +48,7 @@ for w in ("default", "prestitch", "rrc"):
     if st:
         shutil.copy(st[0], os.path.join(prof, "%s_%s_kernel_stats.csv" % (tag, w)))
     per = defaultdict(lambda: defaultdict(list))
+    rows = []
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for f in glob.glob(os.path.join(out, "pmc_%s_%s" % (c, w), "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
@@ -57,7 +58,16 @@ for w in ("default", "prestitch", "rrc"):
                 grid = int(row.get("Grid_Size", 0) or 0)
                 if name.endswith("_peak") and grid <= 50 * 256 and "fft_col128_peak_kernel" not in row["Kernel_Name"]:
                     name = "fft_window_F" + name.split("_F")[1].split("_")[0]          # 25-tile window launches
-                per[name][c].append(float(row["Counter_Value"]))
+                rows.append((name, grid, c, float(row["Counter_Value"])))
+    # the quarter-width band transforms run the same pass kernels on a quarter of the grid; the library profiles them
+    # under "<pass>_quarter"
+    gmax = defaultdict(int)
+    for name, grid, c, v in rows:
+        gmax[name] = max(gmax[name], grid)
+    for name, grid, c, v in rows:
+        if name.startswith("fft_pass_ct_kernel") and not name.endswith("_peak") and grid * 3 < gmax[name]:
+            name += "_quarter"
+        per[name][c].append(v)
     raw[w], traffic[w] = {}, {}
     for name, d in per.items():
         if not re.fullmatch(r"[A-Za-z_0-9]+", name) or name.startswith("__amd") or name in ("reduce_kernel", "vectorized_elementwise_kernel", "distribution_elementwise_grid_stride_kernel"):

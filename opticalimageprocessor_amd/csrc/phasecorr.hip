@@ -738,8 +738,8 @@ __global__ __launch_bounds__(NT) void corr_rows3_kernel(FusedJob fj, int M, int 
 // A, then of unit B) and four outputs Y = C(PAN, band 2a) + i C(PAN, band 2a+1).  LDS holds the PAN line pair, one
 // more full-width buffer and the eight narrow lines (144 KB): after the forward transforms the PAN spectra of the
 // thread's bins move to registers, and the outputs are formed, inverse-transformed and stored two at a time in the two
-// full-width buffers.  A thread owns the same bins kx of every line pair (and their mirrors in line -ky): its H and G
-// values come from the L2-resident table every round.
+// full-width buffers.  A thread owns the same bins of every line pair: kx <= N/2 and N - kx of line ky (and their
+// mirrors in line -ky), which share H and G up to conjugation.
 struct UpRowsJob {
     const float2 *zp;       // pitch P
     const float2 *zn;       // four narrow arrays, zn_stride elements apart, pitch Pn
@@ -781,11 +781,14 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
 {
     constexpr int F = 3000, S = F / 4;
     constexpr int TWF = oipfft::TwTable<F, 25, 15, 8>::value(), TWS = oipfft::TwTable<S, 25, 15, 2>::value();
-    constexpr int NB = (F + NT - 1) / NT;                           // bins kx = tid + NT * it of line ky per thread
+    // A thread owns the bins kx = tid + NT r <= N/2 of line ky and their mirrors N - kx of the same line: H and G are
+    // transforms of real sequences, so the mirror's table values are the conjugates -- half the table registers.
+    constexpr int NB = (F / 2 + 1 + NT - 1) / NT;
     __shared__ __align__(16) float2 buf[2 * 2 * F + 4 * 2 * S];    // PAN / output 0 | output 1 | narrow arrays; [point][line]
     __shared__ float2 tw[TWF], tws[TWS];
     __shared__ float2 edge[4][2][4];                               // [array][line][j]: narrow line samples 0, 1, S-2, S-1
     __shared__ float2 edgeA[2][2];                                 // PAN spectra (unit A, unit B) at kx = 0 and N/2
+    __shared__ float2 edgeT[2][5];                                 // H, G_0..3 at kx = 0 and N/2
     float2 *bufN = buf + 4 * F;
     float4 *buf4 = reinterpret_cast<float4 *>(buf), *buf4N = reinterpret_cast<float4 *>(bufN);
     const int dbg = fj.dbg;
@@ -794,6 +797,22 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
     if (ky > half) return;
     for (int i = threadIdx.x; i < TWF; i += NT) tw[i] = twF[i];
     for (int i = threadIdx.x; i < TWS; i += NT) tws[i] = twS[i];
+    if (threadIdx.x < 10) edgeT[threadIdx.x / 5][threadIdx.x % 5] = fj.xtab[(threadIdx.x % 5) * F + (threadIdx.x / 5) * (F / 2)];
+    // H and G of the thread's bins: re-read from the L2-resident table (120 KB) for each of the two cross-power rounds
+    // (held across the inverse transforms they cost the registers the prefetched lines need).  Vector-memory
+    // operations complete in order: the second load is issued before the stores of the first round and before the
+    // prefetch, so that waiting for it waits for nothing else.
+    float2 H[NB], G[NB][4];
+    auto load_tables = [&](int tid) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            int kx = tid + NT * r;
+            kx = kx <= F / 2 ? kx : 0;
+            H[r] = fj.xtab[kx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) G[r][j] = fj.xtab[(1 + j) * F + kx];
+        }
+    };
     constexpr int NIT2 = (F / 2 + NT - 1) / NT;
     constexpr int NQ = 4 * (S / 2);                 // 16-byte pieces of one line of the four narrow arrays
     constexpr int NITN = (NQ + NT - 1) / NT;
@@ -851,11 +870,7 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         const bool pair = s1 != s2;
         const int kn = ky + gridDim.x;
         const bool more = kn <= half;
-        if (more && !(dbg & 8)) {
-            n1 = ypos[kn];
-            n2 = ypos[M - kn];
-            fetch(tid);
-        }
+        load_tables(tid);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 1)) {
             oipfft::StagesAll<F, NT, 1, 1, 25, 15, 8>::run(buf, tw, tid);
@@ -863,31 +878,23 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         }
         // PAN spectra of this thread's bins (unit A in the real slot, unit B in the imaginary one); those of the two
         // edge columns (kx = 0, N/2: divSpectrums' double-precision and real-only formulas) also go to edgeA
-        float2 Aa[NB], Ab[NB];
+        float2 Aa[2 * NB], Ab[2 * NB];                  // [2 r]: bin kx, [2 r + 1]: bin N - kx
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
             const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
-            if (kx < F) {
+            if (kx <= F / 2) {
                 const float2 zk = buf[2 * kx], zm = buf[2 * nkx + 1];
-                Aa[r] = spec_of(0, zk, zm);
-                Ab[r] = spec_of(1, zk, zm);
-                if (kx == 0 || 2 * kx == F) { edgeA[kx ? 1 : 0][0] = Aa[r]; edgeA[kx ? 1 : 0][1] = Ab[r]; }
+                Aa[2 * r] = spec_of(0, zk, zm);
+                Ab[2 * r] = spec_of(1, zk, zm);
+                const float2 zk2 = buf[2 * nkx], zm2 = buf[2 * kx + 1];
+                Aa[2 * r + 1] = spec_of(0, zk2, zm2);
+                Ab[2 * r + 1] = spec_of(1, zk2, zm2);
+                if (kx == 0 || 2 * kx == F) { edgeA[kx ? 1 : 0][0] = Aa[2 * r]; edgeA[kx ? 1 : 0][1] = Ab[2 * r]; }
             }
         }
         // outputs o0, o0 + 1 (narrow arrays of the same index) into the two full-width buffers
-        auto xround = [&](int o0, const float2 (&A)[NB]) {
+        auto xround = [&](int o0, const float2 (&A)[2 * NB]) {
             if (dbg & 2) return;
-            // H and G of the thread's bins: re-read every round (L2-resident, 120 KB) -- held in registers across
-            // the transforms they cost 40 VGPRs the stages need
-            float2 H[NB], G[NB][4];
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                int kx = tid + NT * r;
-                kx = kx < F ? kx : 0;
-                H[r] = fj.xtab[kx];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) G[r][j] = fj.xtab[(1 + j) * F + kx];
-            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float2 *zn = bufN + (o0 + h) * 2 * S;
@@ -898,18 +905,31 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
 #pragma unroll
                 for (int r = 0; r < NB; ++r) {
                     const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
-                    if (kx >= F) continue;
+                    if (kx > F / 2) continue;
                     const int c = kx % S, cm = c ? S - c : 0;      // the narrow bin of kx and of -kx
-                    const float2 zn0 = zn[2 * c], zn1 = zn[2 * cm + 1];
-                    // packed band spectrum at (ky, kx) and at (-ky, -kx): H and G of -kx are the conjugates
-                    float2 Z0 = oipfft::cmul(H[r], zn0), Z1 = cmulj(H[r], zn1);
+                    {
+                        // packed band spectrum at (ky, kx) and at (-ky, -kx): H and G of -kx are the conjugates
+                        float2 Z0 = oipfft::cmul(H[r], zn[2 * c]), Z1 = cmulj(H[r], zn[2 * cm + 1]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { Z0 = cfma(G[r][j], e0[j], Z0); Z1 = cfmaj(G[r][j], e1[j], Z1); }
-                    const float2 C1 = cross_power_bin_fast(A[r], spec_of(0, Z0, Z1), false, false);
-                    const float2 C2 = cross_power_bin_fast(A[r], spec_of(1, Z0, Z1), false, false);
-                    // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
-                    ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                    ob[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+                        for (int j = 0; j < 4; ++j) { Z0 = cfma(G[r][j], e0[j], Z0); Z1 = cfmaj(G[r][j], e1[j], Z1); }
+                        const float2 C1 = cross_power_bin_fast(A[2 * r], spec_of(0, Z0, Z1), false, false);
+                        const float2 C2 = cross_power_bin_fast(A[2 * r], spec_of(1, Z0, Z1), false, false);
+                        // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
+                        ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                        ob[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+                    }
+                    if (kx != 0 && 2 * kx != F) {
+                        // the same for bin (ky, N - kx) and its mirror (-ky, kx)
+                        float2 Z0 = cmulj(H[r], zn[2 * cm]), Z1 = oipfft::cmul(H[r], zn[2 * c + 1]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { Z0 = cfmaj(G[r][j], e0[j], Z0); Z1 = cfma(G[r][j], e1[j], Z1); }
+                        const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec_of(0, Z0, Z1), false, false);
+                        const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec_of(1, Z0, Z1), false, false);
+                        ob[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                        ob[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+                    }
+                    // one bin pair at a time (keeps the LDS reads of all bins from being hoisted above the arithmetic)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             // the two edge columns again with their own formulas (one copy of that code, two threads of the block)
@@ -919,9 +939,10 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                 if (kx != 0 && 2 * kx != F) continue;
                 const bool real_bin = ky == 0 || 2 * ky == M;
                 const float2 Ae = edgeA[kx ? 1 : 0][o0 ? 1 : 0];
-                float2 He = fj.xtab[kx], Ge[4];
+                // (from LDS: a vector-memory load here would be younger than the prefetch and wait for it)
+                float2 He = edgeT[kx ? 1 : 0][0], Ge[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) Ge[j] = fj.xtab[(1 + j) * F + kx];
+                for (int j = 0; j < 4; ++j) Ge[j] = edgeT[kx ? 1 : 0][1 + j];
 #pragma unroll 1
                 for (int h = 0; h < 2; ++h) {
                     const float2 *zn = bufN + (o0 + h) * 2 * S;
@@ -972,7 +993,17 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         };
         xround(0, Aa);
         finish();
+        if (fj.nout == 4) load_tables(tid);
+        __builtin_amdgcn_sched_barrier(0);
         store(0);
+        // The lines of the NEXT pair are requested here and committed at the bottom of this same iteration: the first
+        // half of the iteration runs without their registers.
+        if (more && !(dbg & 8)) {
+            n1 = ypos[kn];
+            n2 = ypos[M - kn];
+            fetch(tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         if (fj.nout == 4) {
             xround(2, Ab);
             finish();
@@ -1580,7 +1611,7 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
         OipProfScope prof(ctx, "corr_rows_up_kernel");
         long grid = ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
-        const char *et = getenv("OIP_UP_THREADS");                      // experiment knob (measured: 1.41 ms with 512 threads, 1.48 with 768)
+        const char *et = getenv("OIP_UP_THREADS");                      // experiment knob (measured: 1.29 ms with 512 threads -- no spills --, 1.34 with 768)
         if (et && atoi(et) == 768)
             hipLaunchKernelGGL(corr_rows_up_kernel<768>, dim3((unsigned)grid), dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else

@@ -850,12 +850,13 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
     constexpr int NLD = F * V / NT;                     // tile elements per thread
     constexpr int NRV = F * kSeg / 2 / NT;              // 8-byte tap-run loads per thread and band
     static_assert(F * V % NT == 0 && F * kSeg / 2 % NT == 0 && 2 * F <= NT && F <= NT && NT % V == 0, "tile / block shape");
-    static_assert(sizeof(float) * 2 * F * kSeg + sizeof(unsigned short) * F * V <= sizeof(float2) * F * Vp, "staging fits the tile buffer");
+    static_assert(sizeof(float) * 2 * F * kSeg + 2 * sizeof(unsigned short) * F * V <= sizeof(float2) * F * Vp, "staging fits the tile buffer");
     __shared__ float2 buf[F * Vp];
     __shared__ float2 tw[TWN];
     __shared__ float2 twj[F];
     float *seg = reinterpret_cast<float *>(buf);                                         // [2][F][kSeg] tap runs
     unsigned short *seg16 = reinterpret_cast<unsigned short *>(seg + 2 * F * kSeg);       // [F][V] PAN pixels
+    unsigned short *seg16b = seg16 + F * V;                                               // [F][V] a second PAN window (imaginary slot)
 
     // lane tile: contiguous chunks per XCD (see decode_tile)
     const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
     const int cbase = cb < 0 ? 0 : (cb > lastc ? lastc : cb);
     int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (xin) {
+    if (xin && (io.re_v || io.im_v)) {
         const int sx = (x - 2) >> 2;
         a = reinterpret_cast<const float4 *>(io.alpha)[x];
         int c0 = sx - 1, c1 = sx, c2 = sx + 1, c3 = sx + 2;
@@ -883,13 +884,13 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
         c3 = c3 < 0 ? 0 : (c3 > lastc ? lastc : c3);
         r0 = c0 - cbase; r1 = c1 - cbase; r2 = c2 - cbase; r3 = c3 - cbase;
     }
-    const bool has16 = io.re16 != nullptr;
+    const bool has16 = io.re16 != nullptr, has16b = io.im16 != nullptr;
     const float *__restrict__ V0 = io.re_v, *__restrict__ V1 = io.im_v;
     for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
 
     // raw data of one tile: everything is loaded unconditionally from clamped addresses (a select on a
     // loaded value would wait for the load where it is issued); validity is applied when it is used
-    uint4 rpx = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rpx = make_uint4(0u, 0u, 0u, 0u), rpxb = make_uint4(0u, 0u, 0u, 0u);
     float2 rv[2][NRV];
     float2 rtw = make_float2(1.f, 0.f);
     auto fetch = [&](int o1, int tid) {
@@ -901,6 +902,7 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
             int xc = lane0 + 8 * half;
             xc = xc < io.cols ? xc : io.cols - 8;
             rpx = *reinterpret_cast<const uint4 *>(io.re16 + (size_t)y * io.pitch_re16 + xc);
+            if (has16b) rpxb = *reinterpret_cast<const uint4 *>(io.im16 + (size_t)y * io.pitch_im16 + xc);
         }
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -924,7 +926,10 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
         const int y0 = o2 * p.T + o1;
         if (has16) {
             const int n = tid >> 1, half = tid & 1;
-            if (n < F) *reinterpret_cast<uint4 *>(seg16 + n * V + 8 * half) = rpx;
+            if (n < F) {
+                *reinterpret_cast<uint4 *>(seg16 + n * V + 8 * half) = rpx;
+                if (has16b) *reinterpret_cast<uint4 *>(seg16b + n * V + 8 * half) = rpxb;
+            }
         }
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -956,7 +961,8 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
             if (xin && y < io.rows) {
                 if (has16) z.x = (float)seg16[n * V + v];
                 else if (V0) z.x = taps(seg + n * kSeg);
-                if (V1) z.y = taps(seg + (F + n) * kSeg);
+                if (has16b) z.y = (float)seg16b[n * V + v];
+                else if (V1) z.y = taps(seg + (F + n) * kSeg);
             }
             zz[i] = z;
         }
@@ -1343,11 +1349,15 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
         grid3 = dim3((unsigned)(8 * p.xcd_chunk), (unsigned)p.O1, (unsigned)p.O2);
     }
     // the persistent first pass with fused up-sampling, when the geometry allows (see the kernel)
+    // sources it takes: up-sampled V images (exact x4) with or without a u16 window in the real slot, or one / two u16
+    // windows alone (the PAN windows of a pair of units)
+    const bool up_v = (io.re_v || io.im_v) && io.x4 && !io.im16 && !(io.re16 && io.re_v) && (io.v_cols & 1) == 0 && io.v_cols >= 8 &&
+                      ((size_t)io.re_v & 7) == 0 && ((size_t)io.im_v & 7) == 0;
+    const bool pure16 = io.re16 && !io.re_v && !io.im_v &&
+                        (!io.im16 || ((io.pitch_im16 & 7) == 0 && ((size_t)io.im16 & 15) == 0));
     if (blocks_override <= 0 && !inverse && io.load_kind == 1 && p.mode == 0 && p.axis == 1 && p.vshift == 4 && p.tw_mode == 2 &&
-        (io.re_v || io.im_v) && io.x4 && !io.re && !io.im && !io.im16 && !(io.re16 && io.re_v) && (io.v_cols & 1) == 0 &&
-        io.v_cols >= 8 && io.cols >= 8 && io.rows >= 1 &&
-        (!io.re16 || ((io.cols & 7) == 0 && (io.pitch_re16 & 7) == 0 && ((size_t)io.re16 & 15) == 0)) &&
-        ((size_t)io.re_v & 7) == 0 && ((size_t)io.im_v & 7) == 0) {
+        (up_v || pure16) && !io.re && !io.im && io.cols >= 8 && io.rows >= 1 &&
+        (!io.re16 || ((io.cols & 7) == 0 && (io.pitch_re16 & 7) == 0 && ((size_t)io.re16 & 15) == 0))) {
         static const char *envu = getenv("OIP_FIRST_UP");                 // experiment knob: 0 disables, N = tile rows per workgroup
         const int tiles = envu ? atoi(envu) : 3;
         for (const FirstUpKernel &k : kFirstUp)

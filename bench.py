@@ -78,12 +78,16 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         # whole row stage (forward rows + cross-power + inverse rows): every spectrum of the job read
         # once, every output written once -- 3 in + 2 out for a PAN-vs-4-bands unit, 1 + 1 for a CCD pair
         "corr_rows_kernel": 8.0 * MN * rows_arrays,
-        # row stage of a pair of units with the horizontal up-sampling on the band spectra: PAN_A + i PAN_B and four
-        # quarter-width band arrays in, four outputs
+        # row stage of a pair of units with the up-sampling applied to the band spectra: PAN_A + i PAN_B in (1 array),
+        # every line of the four band transforms read once per frequency line it serves (4 x 1/4 array), four outputs
         "corr_rows_up_kernel": 8.0 * MN * 6.0,
-        # column passes of one quarter-width band array (two vertically up-sampled f32 images in)
+        # column passes of one quarter-width band array (two vertically up-sampled f32 images in): OIP_SPECTRAL_UP=1
         "fft_pass_ct_kernel_F128_pack_quarter": 8.0 * MN / 4.0 + 2 * 4.0 * win / 4.0,
         "fft_pass_ct_kernel_F125_quarter": 16.0 * MN / 4.0,
+        # the eight band windows of a pair of units as one complex array (u16 in, float2 out) and its two column passes
+        "pack_bands_kernel": 8 * 2.0 * win / 16.0 + 8.0 * MN / 4.0,
+        "fft_pass_ct_kernel_F32_band": 16.0 * MN / 4.0,
+        "fft_pass_ct_kernel_F125_band": 16.0 * MN / 4.0,
         # vertical half of the x4 up-sampling, the eight bands of a pair of units per launch: u16 band
         # window in (win/16 px), f32 rows x4 out (win/4 px)
         "resize_cubic_v_kernel": 8 * (4.0 * win / 4.0 + 2.0 * win / 16.0),

@@ -79,7 +79,7 @@ extern "C" void oip_destroy(oip_ctx *ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     oip_fft_destroy(ctx);
-    for (auto &t : ctx->resize_tabs) { hipFree(t.d_xofs); hipFree(t.d_alpha); hipFree(t.d_yofs); hipFree(t.d_beta); if (t.d_xspec) hipFree(t.d_xspec); }
+    for (auto &t : ctx->resize_tabs) { hipFree(t.d_xofs); hipFree(t.d_alpha); hipFree(t.d_yofs); hipFree(t.d_beta); if (t.d_xspec) hipFree(t.d_xspec); if (t.d_yspec) hipFree(t.d_yspec); }
     for (auto &p : ctx->prof_pending) { if (p.own_e0) hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
     if (ctx->d_tab1d) hipFree(ctx->d_tab1d);
     if (ctx->d_small) hipFree(ctx->d_small);

@@ -1075,6 +1075,8 @@ const FastKernel kFast[] = {
     {100, 4, 0, 256, {fft_pass_ct_kernel<100, 4, 0, 256, 0, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, 1, 4, 5, 5>, fft_pass_ct_kernel<100, 4, 0, 256, 2, 4, 5, 5>}},
     {160, 4, 0, 256, {fft_pass_ct_kernel<160, 4, 0, 256, 0, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, 1, 4, 8, 5>, fft_pass_ct_kernel<160, 4, 0, 256, 2, 4, 8, 5>}},
     {64, 5, 0, 256, {fft_pass_ct_kernel<64, 5, 0, 256, 0, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, 1, 4, 4, 4>, fft_pass_ct_kernel<64, 5, 0, 256, 2, 4, 4, 4>}},
+    // 4000 = 32 * 125: the column transform of the band windows themselves (a quarter of the correlation lines)
+    {32, 5, 0, 256, {fft_pass_ct_kernel<32, 5, 0, 256, 0, 8, 4>, fft_pass_ct_kernel<32, 5, 0, 256, 1, 8, 4>, fft_pass_ct_kernel<32, 5, 0, 256, 2, 8, 4>}},
     // row passes: 30000/10, 12288/10 -> 1250, the 200-column stitch overlap
     {3000, 1, 1, 512, {fft_pass_ct_kernel<3000, 1, 1, 512, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 1, 1, 512, 2, 3, 8, 5, 5, 5>}},
     {3000, 0, 1, 512, {fft_pass_ct_kernel<3000, 0, 1, 512, 0, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, 1, 3, 8, 5, 5, 5>, fft_pass_ct_kernel<3000, 0, 1, 512, 2, 3, 8, 5, 5, 5>}},
@@ -1230,6 +1232,7 @@ int oip_fft2d_plan(oip_ctx *ctx, int M, int N, const OipFft2dPlan **out)
     // points of a tile 47 * 2^16 B apart -- same channel -- and ran at half the bandwidth)
     static const char *envo = getenv("OIP_FFT_Y_ORDER");
     if (M == 16000) pl.yf = (envo && atoi(envo) == 125) ? std::vector<int>{125, 128} : std::vector<int>{128, 125};
+    else if (M == 4000) pl.yf = std::vector<int>{32, 125};          // the band windows of 16000 correlation lines
     else if (!split_axis(M, 256, 256, &pl.yf)) return oip_fail(ctx, OIP_E_UNSUPPORTED, "fft2d: cannot factor column length %d", M);
     // column (y) passes first: always mode A with lanes = x
     {
@@ -1385,7 +1388,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
             return OIP_OK;
         }
     }
-    if (p.fast >= 0) {
+    if (p.fast >= 0 && kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)]) {
         p.ntiles = blocks;
         long grid = blocks;
         hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
@@ -1418,10 +1421,18 @@ int oip_fft2d_exec(oip_ctx *ctx, const OipFft2dPlan *pl, float2 *data, int inver
     if (panels > lane_tiles) panels = lane_tiles;
     auto column_passes = [&](bool inv) -> int {
         for (int pn = 0; pn < panels; ++pn) {
-            const int lt0 = (int)((long)lane_tiles * pn / panels), lt1 = (int)((long)lane_tiles * (pn + 1) / panels);
             for (int k = 0; k < pl->n_y; ++k) {
                 const int i = inv ? pl->n_y - 1 - k : k;
                 OipFftPass p = pl->passes[i];
+                // the panel in THIS pass' lane tiles (the passes of one axis may use different tile widths); a panel
+                // boundary must fall on a boundary of every pass, so panels are cut in units of the widest tile
+                int vmax = 0;
+                for (int q = 0; q < pl->n_y; ++q) vmax = pl->passes[q].vshift > vmax ? pl->passes[q].vshift : vmax;
+                const int wide = (int)((p.lanes + (1L << vmax) - 1) >> vmax);              // tiles of the widest pass
+                const int w0 = (int)((long)wide * pn / panels), w1 = (int)((long)wide * (pn + 1) / panels);
+                const int lt0 = w0 << (vmax - p.vshift);
+                int lt1 = w1 << (vmax - p.vshift);
+                if (lt1 > p.lane_tiles || pn == panels - 1) lt1 = p.lane_tiles;
                 p.lt0 = lt0;
                 p.ltn = lt1 - lt0;
                 OipFftIo use = plain;

@@ -38,6 +38,8 @@ struct OipResizeTab {
     float *d_beta;      // dh x 4
     void *d_xspec;      // float2 [5][dw]: the horizontal up-sampling as an operator on spectra (built on first use)
     int xspec_state;    // 0 not tried, 1 built, -1 the geometry has no such form
+    void *d_yspec;      // float2 [5][dh]: the same for the vertical axis
+    int yspec_state;
 };
 
 // OpenCV imgwarp.cpp interpolateCubic, f32, evaluated on the host exactly as OpenCV does

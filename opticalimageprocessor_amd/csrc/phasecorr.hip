@@ -749,6 +749,13 @@ struct UpRowsJob {
     const float2 *xtab;     // [5][N]: H, G_0 .. G_3
     int nout;               // 4, or 2 for a single unit (arrays 2 and 3 are not read)
     int dbg;                // experiment mask like FusedJob::dbg
+    // VEXP: the vertical up-sampling is applied to the spectra as well.  zn then holds the column transforms of the
+    // band windows themselves (m = M / 4 rows): line ky of the up-sampled band is
+    //     Hv[ky] zn[ky mod m] + sum_i Gv_i[ky] raw[i],      raw = band rows {0, 1, m-2, m-1}
+    const float2 *vtab;     // [5][M]: Hv, Gv_0 .. Gv_3
+    const uint2 *raw16;     // [4 rows][4 arrays x n / 2]: (bX | bY << 16) of two neighbouring points
+    const int *ypos_s;      // row position of frequency line k in zn, k in [0, m)
+    int m;
 };
 
 // conj(a) b, acc + a b, acc + conj(a) b on packed-f32 instructions (two each; operand selection as in oipfft::cmul).
@@ -775,7 +782,7 @@ __device__ __forceinline__ float2 cfmaj(float2 a, float2 b, float2 acc)
     return oipfft::to_f2(r);
 }
 
-template <int NT>
+template <int NT, bool VEXP>
 __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, int P, const int *__restrict__ ypos,
                                                           const float2 *__restrict__ twF, const float2 *__restrict__ twS)
 {
@@ -818,6 +825,38 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
     constexpr int NITN = (NQ + NT - 1) / NT;
     float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
     long n1 = ypos[ky], n2 = ypos[ky ? M - ky : 0];     // rows (the pitches differ between zp and zn)
+    // rows of the narrow arrays: the same lines, or (VEXP) the lines ky mod m and -ky mod m of the band transforms
+    auto narrow_row = [&](int k, long full) { return VEXP ? (long)fj.ypos_s[k % fj.m] : full; };
+    long m1 = narrow_row(ky, n1), m2 = narrow_row(ky ? M - ky : 0, n2);
+    int kyc = ky;                                       // the frequency line whose loads are in the registers
+    float2 vt[5];                                       // VEXP: Hv, Gv_0..3 of line kyc
+    uint2 rawreg[NITN][4];                              // VEXP: the raw band rows at this thread's points (bX | bY << 16, two points)
+    // VEXP: the narrow lines, their coefficients and the raw rows are requested at the commit itself -- their
+    // registers (58 per thread) held across the second round's transforms spill, and a spilled load is waited for
+    // where it is issued.  They are a quarter of the input bytes and mostly L2 / Infinity Cache hits (every line of
+    // a band transform serves four frequency lines, the raw rows serve all).
+    auto fetch_narrow = [&](int tid) {
+        if (VEXP) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + kyc];
+#pragma unroll
+            for (int it = 0; it < NITN; ++it) {
+                int q = tid + it * NT;
+                q = q < NQ ? q : NQ - 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rawreg[it][r] = fj.raw16[(long)r * NQ + q];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NITN; ++it) {
+            int q = tid + it * NT;
+            q = q < NQ ? q : NQ - 1;
+            const int a = q / (S / 2), i = q - a * (S / 2);
+            const float2 *z = fj.zn + a * fj.zn_stride + 2 * i;
+            na[it] = *reinterpret_cast<const float4 *>(z + m1 * fj.Pn);
+            nb[it] = *reinterpret_cast<const float4 *>(z + m2 * fj.Pn);
+        }
+    };
     auto fetch = [&](int tid) {
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
@@ -826,17 +865,10 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
             la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
             lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
         }
-#pragma unroll
-        for (int it = 0; it < NITN; ++it) {
-            int q = tid + it * NT;
-            q = q < NQ ? q : NQ - 1;
-            const int a = q / (S / 2), i = q - a * (S / 2);
-            const float2 *z = fj.zn + a * fj.zn_stride + 2 * i;
-            na[it] = *reinterpret_cast<const float4 *>(z + n1 * fj.Pn);
-            nb[it] = *reinterpret_cast<const float4 *>(z + n2 * fj.Pn);
-        }
+        if (!VEXP) fetch_narrow(tid);
     };
     auto commit = [&](int tid) {
+        if (VEXP) fetch_narrow(tid);
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
             const int q = tid + it * NT;
@@ -850,6 +882,24 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
             const int q = tid + it * NT;
             if (q < NQ) {
                 const int a = q / (S / 2), i = q - a * (S / 2);
+                if (VEXP && !(dbg & 32)) {
+                    // line ky of the vertically up-sampled band pair from line ky mod m of its transform; Hv and Gv of
+                    // line -ky are the conjugates.  The raw band rows of this thread's points are kernel-long
+                    // constants (two u16 pairs per row and piece).
+                    const float2 hv = vt[0];
+                    float2 x0 = oipfft::cmul(hv, make_float2(na[it].x, na[it].y)), x1 = oipfft::cmul(hv, make_float2(na[it].z, na[it].w));
+                    float2 y0 = cmulj(hv, make_float2(nb[it].x, nb[it].y)), y1 = cmulj(hv, make_float2(nb[it].z, nb[it].w));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float2 gv = vt[1 + r];
+                        const uint2 u = rawreg[it][r];
+                        const float2 w0 = make_float2((float)(u.x & 0xffffu), (float)(u.x >> 16)), w1 = make_float2((float)(u.y & 0xffffu), (float)(u.y >> 16));
+                        x0 = cfma(gv, w0, x0); x1 = cfma(gv, w1, x1);
+                        y0 = cfmaj(gv, w0, y0); y1 = cfmaj(gv, w1, y1);
+                    }
+                    na[it] = make_float4(x0.x, x0.y, x1.x, x1.y);
+                    nb[it] = make_float4(y0.x, y0.y, y1.x, y1.y);
+                }
                 buf4N[a * S + 2 * i] = make_float4(na[it].x, na[it].y, nb[it].x, nb[it].y);
                 buf4N[a * S + 2 * i + 1] = make_float4(na[it].z, na[it].w, nb[it].z, nb[it].w);
                 if (i == 0 || i == S / 2 - 1) {
@@ -1001,6 +1051,9 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         if (more && !(dbg & 8)) {
             n1 = ypos[kn];
             n2 = ypos[M - kn];
+            m1 = narrow_row(kn, n1);
+            m2 = narrow_row(M - kn, n2);
+            kyc = kn;
             fetch(tid);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1170,6 +1223,7 @@ int resize_tables(oip_ctx *ctx, int sw, int sh, int dw, int dh, const OipResizeT
     OipResizeTab t;
     t.sw = sw; t.sh = sh; t.dw = dw; t.dh = dh;
     t.d_xspec = nullptr; t.xspec_state = 0;
+    t.d_yspec = nullptr; t.yspec_state = 0;
     // the x4 kernel needs every output's first tap inside its source pixel's 5-wide window
     t.x4 = dw == 4 * sw && dh == 4 * sh;
     for (int dx = 0; dx < dw && t.x4; ++dx) { int o = (xofs[dx] - 1) - (dx / 4 - 2); t.x4 = o == 0 || o == 1; }
@@ -1289,19 +1343,22 @@ int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int
     return OIP_OK;
 }
 
-// H and G_j of the horizontal x4 cubic up-sampling n -> N = 4 n as an operator on spectra (see corr_rows_up_kernel),
-// built in double from the same f32 taps the image-domain loader applies: h[e] is the tap that output d = e + 4 p
-// puts on source sample p, G_j is the transform of what clamping (instead of wrapping) the out-of-image taps adds to
-// column j of the operator, j in {0, 1, n-2, n-1}.  *out stays null when the geometry has no such form.
-int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, const float2 **out)
+// H and G_j of the x4 cubic up-sampling n -> N = 4 n along one axis (0: horizontal, 1: vertical) as an operator on
+// spectra (see corr_rows_up_kernel), built in double from the same f32 taps the image-domain kernels apply: h[e] is the
+// tap that output d = e + 4 p puts on source sample p, G_j is the transform of what clamping (instead of wrapping) the
+// out-of-image taps adds to column j of the operator, j in {0, 1, n-2, n-1}.  *out stays null when the geometry has no
+// such form.
+int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, int axis, const float2 **out)
 {
     OipResizeTab *t = const_cast<OipResizeTab *>(ctab);
     *out = nullptr;
-    if (t->xspec_state == 1) { *out = (const float2 *)t->d_xspec; return OIP_OK; }
-    if (t->xspec_state < 0) return OIP_OK;
-    t->xspec_state = -1;
-    const int n = t->sw, N = t->dw;
-    if (N != 4 * n || n < 8 || !t->x4h) return OIP_OK;
+    int &state = axis ? t->yspec_state : t->xspec_state;
+    void *&d_spec = axis ? t->d_yspec : t->d_xspec;
+    if (state == 1) { *out = (const float2 *)d_spec; return OIP_OK; }
+    if (state < 0) return OIP_OK;
+    state = -1;
+    const int n = axis ? t->sh : t->sw, N = axis ? t->dh : t->dw;
+    if (N != 4 * n || n < 8 || !(axis ? t->x4v : t->x4h)) return OIP_OK;
     const double scale = 1. / ((double)N / n);
     std::vector<double> h(N, 0.0), g[4];
     std::vector<char> hset(N, 0);
@@ -1344,10 +1401,10 @@ int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, const float
     };
     dft(h, tab.data());
     for (int j = 0; j < 4; ++j) dft(g[j], tab.data() + (size_t)(1 + j) * N);
-    OIP_HIP(ctx, hipMalloc(&t->d_xspec, sizeof(float2) * tab.size()));
-    OIP_HIP(ctx, hipMemcpy(t->d_xspec, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
-    t->xspec_state = 1;
-    *out = (const float2 *)t->d_xspec;
+    OIP_HIP(ctx, hipMalloc(&d_spec, sizeof(float2) * tab.size()));
+    OIP_HIP(ctx, hipMemcpy(d_spec, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
+    state = 1;
+    *out = (const float2 *)d_spec;
     return OIP_OK;
 }
 
@@ -1579,22 +1636,85 @@ int correlate_two_units(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, R
 // vertically up-sampled bands (V images, rows x band_cols, packed two by two), one row-stage launch, four inverse
 // column transforms.  Against correlate_two_units: 2 instead of 5 array-sized forward column transforms, 6 instead of
 // 10 row transforms of 3000 points (in units of one).
-struct UpPath {
-    const OipFft2dPlan *narrow;     // M x band_cols
-    const float2 *xtab;
+// One inter-band unit: a PAN window (rows x cols u16) and the matching windows of the four bands
+// (band_rows x band_cols u16), each with its own pitch -- a window of the resident raster or a compact
+// copy received from another rank.
+struct IbUnit {
+    const uint16_t *pan;
+    long pan_pitch;
+    const uint16_t *band[OIP_MSS_BANDS];
+    long band_pitch;
 };
-int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, const PcWork &w, RealSrc aA, RealSrc aB, const RealSrc *v /* 4 or 8 */,
-                       int nunits, int rows, int cols, int band_cols, double *d_resA, double *d_resB)
+
+struct UpPath {
+    const OipFft2dPlan *narrow;     // M x band_cols (vertical taps in the image domain), or
+    const OipFft2dPlan *small;      // band_rows x (4 band_cols): both axes on the spectra (vtab set)
+    const float2 *xtab, *vtab;
+};
+
+// The band windows of a launch as one complex array: array a = bX + i bY occupies columns [n a, n a + n) of an
+// m x (4 n) array of pitch Pn (the column passes then run over all four at once); rows {0, 1, m-2, m-1} of each array
+// also go to raw16[r][a n / 2 + p / 2] as (bX | bY << 16) of the points p, p + 1 (n even).
+struct BandPackJob {
+    const uint16_t *bx[4], *by[4];
+    long pitch[4];
+};
+__global__ __launch_bounds__(kBlock) void pack_bands_kernel(BandPackJob job, int m, int n, int Pn, float2 *__restrict__ z, unsigned *__restrict__ raw16)
+{
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int a = blockIdx.z;
+    if (p >= n) return;
+    const uint16_t *bx = job.bx[a] + p, *by = job.by[a] + p;
+    const long pitch = job.pitch[a];
+    for (int y = blockIdx.y; y < m; y += gridDim.y) {
+        const unsigned ux = bx[y * pitch], uy = by[y * pitch];
+        z[(long)y * Pn + a * n + p] = make_float2((float)ux, (float)uy);
+        const int r = y < 2 ? y : (y >= m - 2 ? y - (m - 4) : -1);
+        if (r >= 0) raw16[((long)r * 4 + a) * n + p] = ux | (uy << 16);
+    }
+}
+
+int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, const PcWork &w, RealSrc aA, RealSrc aB, const RealSrc *v /* 4 or 8: V images */,
+                       const IbUnit *const *units, int nunits, int rows, int cols, int band_rows, int band_cols, double *d_resA, double *d_resB)
 {
     int rc;
     if ((rc = forward_packed(ctx, pl, w.z[0], aA, nunits > 1 ? aB : src_none(), rows, cols, true))) return rc;
-    const long zn_stride = (long)up.narrow->M * up.narrow->P;
     const int narr = 2 * nunits;
-    ctx->prof_tag = "_quarter";
-    for (int a = 0; a < narr && !rc; ++a)
-        rc = forward_packed(ctx, up.narrow, w.z[1] + a * zn_stride, src_f32(v[2 * a].v), src_f32(v[2 * a + 1].v), rows, band_cols, true);
-    ctx->prof_tag = nullptr;
-    if (rc) return rc;
+    long zn_stride;
+    int Pn;
+    const int *ypos_s = nullptr;
+    unsigned *raw = nullptr;
+    if (up.vtab) {
+        // band windows -> one m x 3000 complex array (four arrays side by side) -> its column passes
+        Pn = up.small->P;
+        zn_stride = band_cols;
+        raw = reinterpret_cast<unsigned *>(w.z[1] + (long)up.small->M * Pn);
+        BandPackJob bj;
+        for (int a = 0; a < 4; ++a) {
+            const IbUnit *u = units[(a < narr ? a : 0) / 2];
+            bj.bx[a] = u->band[2 * (a & 1)]; bj.by[a] = u->band[2 * (a & 1) + 1]; bj.pitch[a] = u->band_pitch;
+        }
+        {
+            OipProfScope prof(ctx, "pack_bands_kernel");
+            int gy = band_rows < 64 ? band_rows : 64;
+            hipLaunchKernelGGL(pack_bands_kernel, dim3((band_cols + kBlock - 1) / kBlock, gy, 4), dim3(kBlock), 0, ctx->stream, bj, band_rows, band_cols, Pn,
+                               w.z[1], raw);
+            OIP_HIP(ctx, hipGetLastError());
+        }
+        ctx->prof_tag = "_band";
+        rc = oip_fft2d_exec(ctx, up.small, w.z[1], 0, nullptr, 1);
+        ctx->prof_tag = nullptr;
+        if (rc) return rc;
+        ypos_s = up.small->d_ypos;
+    } else {
+        Pn = up.narrow->P;
+        zn_stride = (long)up.narrow->M * Pn;
+        ctx->prof_tag = "_quarter";
+        for (int a = 0; a < narr && !rc; ++a)
+            rc = forward_packed(ctx, up.narrow, w.z[1] + a * zn_stride, src_f32(v[2 * a].v), src_f32(v[2 * a + 1].v), rows, band_cols, true);
+        ctx->prof_tag = nullptr;
+        if (rc) return rc;
+    }
     const float2 *twF, *twS;
     if ((rc = oip_fft_table(ctx, 3000, &twF)) || (rc = oip_fft_table(ctx, 750, &twS))) return rc;
     UpRowsJob fj;
@@ -1602,20 +1722,27 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
     fj.zp = w.z[0];
     fj.zn = w.z[1];
     fj.zn_stride = zn_stride;
-    fj.Pn = up.narrow->P;
+    fj.Pn = Pn;
     for (int o = 0; o < 4; ++o) fj.out[o] = w.y[o];
     fj.xtab = up.xtab;
     fj.nout = narr;
+    fj.vtab = up.vtab;
+    fj.raw16 = reinterpret_cast<const uint2 *>(raw);
+    fj.ypos_s = ypos_s;
+    fj.m = band_rows;
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
     {
         OipProfScope prof(ctx, "corr_rows_up_kernel");
         long grid = ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
         const char *et = getenv("OIP_UP_THREADS");                      // experiment knob (measured: 1.29 ms with 512 threads -- no spills --, 1.34 with 768)
-        if (et && atoi(et) == 768)
-            hipLaunchKernelGGL(corr_rows_up_kernel<768>, dim3((unsigned)grid), dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        const dim3 g((unsigned)grid);
+        if (up.vtab)
+            hipLaunchKernelGGL((corr_rows_up_kernel<512, true>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        else if (et && atoi(et) == 768)
+            hipLaunchKernelGGL((corr_rows_up_kernel<768, false>), g, dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else
-            hipLaunchKernelGGL(corr_rows_up_kernel<512>, dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+            hipLaunchKernelGGL((corr_rows_up_kernel<512, false>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         OIP_HIP(ctx, hipGetLastError());
     }
     for (int o = 0; o < narr; ++o) {
@@ -1746,16 +1873,6 @@ extern "C" int oip_stt_correlate(oip_ctx *ctx, const uint16_t *d_pan1, const uin
     return OIP_OK;
 }
 
-// One inter-band unit: a PAN window (rows x cols u16) and the matching windows of the four bands
-// (band_rows x band_cols u16), each with its own pitch -- a window of the resident raster or a compact
-// copy received from another rank.
-struct IbUnit {
-    const uint16_t *pan;
-    long pan_pitch;
-    const uint16_t *band[OIP_MSS_BANDS];
-    long band_pitch;
-};
-
 // The loop body of preproc.h:262-329 for n units: per unit and band (dx, dy, response) -> host_out[12 * u + 3 * b].
 // Units go two at a time (five forward and four inverse transforms per pair).
 static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, int cols, int band_rows, int band_cols,
@@ -1771,15 +1888,20 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     // 3000 columns, on the band spectra in the row stage (corr_rows_up_kernel; OIP_SPECTRAL_UP=0 keeps the loader).
     const OipResizeTab *tab = nullptr;
     if ((rc = resize_tables(ctx, band_cols, band_rows, cols, rows, &tab))) return rc;
-    UpPath up{nullptr, nullptr};
+    UpPath up{nullptr, nullptr, nullptr, nullptr};
     {
+        // OIP_SPECTRAL_UP: 0 = image domain, 1 = horizontal axis on the spectra, 2 (default) = both axes
         const char *e = getenv("OIP_SPECTRAL_UP");
-        const bool want = !(e && atoi(e) == 0);
-        if (want && rows == 4 * band_rows && cols == 4 * band_cols && M == rows && N == cols && N == 3000 && row_stage(pl).level == 2) {
-            if ((rc = upsample_spectrum_tables(ctx, tab, &up.xtab))) return rc;
+        const int want = e ? atoi(e) : 2;
+        if (want > 0 && rows == 4 * band_rows && cols == 4 * band_cols && M == rows && N == cols && N == 3000 && row_stage(pl).level == 2) {
+            if ((rc = upsample_spectrum_tables(ctx, tab, 0, &up.xtab))) return rc;
             if (up.xtab) {
                 if ((rc = oip_fft2d_plan(ctx, M, band_cols, &up.narrow))) return rc;
                 if (4 * up.narrow->P > pl->P || up.narrow->N != band_cols) up.xtab = nullptr;      // the four narrow arrays share one array-sized slot
+            }
+            if (up.xtab && want > 1 && optimal_dft_size(band_rows) == band_rows && band_rows >= 8) {
+                if ((rc = upsample_spectrum_tables(ctx, tab, 1, &up.vtab))) return rc;
+                if (up.vtab && (rc = oip_fft2d_plan(ctx, band_rows, cols, &up.small))) return rc;      // four arrays side by side
             }
         }
     }
@@ -1804,10 +1926,10 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     for (; k + 1 < n; k += 2) {
         const IbUnit &A = units[k], &B = units[k + 1];
         const IbUnit *two[2] = {&A, &B};
-        if ((rc = upsample(two, 2, w.fb, sAB))) return rc;
+        if (!up.vtab && (rc = upsample(two, 2, w.fb, sAB))) return rc;
         if (up.xtab) {
-            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_u16(B.pan, B.pan_pitch), sAB, 2, rows, cols, band_cols,
-                                         d_res + 12 * k, d_res + 12 * (k + 1)))) return rc;
+            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_u16(B.pan, B.pan_pitch), sAB, two, 2, rows, cols, band_rows,
+                                         band_cols, d_res + 12 * k, d_res + 12 * (k + 1)))) return rc;
             continue;
         }
         const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
@@ -1817,9 +1939,10 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     if (k < n) {
         const IbUnit &A = units[k];
         const IbUnit *one[1] = {&A};
-        if ((rc = upsample(one, 1, w.fb, sAB))) return rc;
+        if (!up.vtab && (rc = upsample(one, 1, w.fb, sAB))) return rc;
         if (up.xtab) {
-            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_none(), sAB, 1, rows, cols, band_cols, d_res + 12 * k, nullptr))) return rc;
+            if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_none(), sAB, one, 1, rows, cols, band_rows, band_cols,
+                                         d_res + 12 * k, nullptr))) return rc;
         } else {
             const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
             if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, rows, cols, d_res + 12 * k, &vt))) return rc;

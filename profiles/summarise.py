@@ -59,14 +59,16 @@ for w in ("default", "prestitch", "rrc"):
                 if name.endswith("_peak") and grid <= 50 * 256 and "fft_col128_peak_kernel" not in row["Kernel_Name"]:
                     name = "fft_window_F" + name.split("_F")[1].split("_")[0]          # 25-tile window launches
                 rows.append((name, grid, c, float(row["Counter_Value"])))
-    # the quarter-width band transforms run the same pass kernels on a quarter of the grid; the library profiles them
-    # under "<pass>_quarter"
+    # the band transforms run the same pass kernels on a quarter of the grid; the library profiles them under
+    # "<pass>_band"
     gmax = defaultdict(int)
     for name, grid, c, v in rows:
         gmax[name] = max(gmax[name], grid)
     for name, grid, c, v in rows:
         if name.startswith("fft_pass_ct_kernel") and not name.endswith("_peak") and grid * 3 < gmax[name]:
-            name += "_quarter"
+            name += "_band"                     # (OIP_SPECTRAL_UP=1 runs them at a quarter of the width: "_quarter")
+        if name == "fft_pass_ct_kernel_F32":
+            name += "_band"
         per[name][c].append(v)
     raw[w], traffic[w] = {}, {}
     for name, d in per.items():

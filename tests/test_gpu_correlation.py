@@ -161,8 +161,8 @@ def _interband_vs_oracle(ctx, Lp, W, slices, sections, corr, min_resp=0.1):
 
 def test_interband_reference_unit_shape_matches_oracle(ctx, oracle_mod):
     """The BASELINE unit shape itself -- 16000 x 3000 windows, x4 up-sampled 4000 x 750 bands -- through the
-    specialised path: vertical-tap kernel, quarter-width column transforms of the bands, the row stage that applies
-    the horizontal up-sampling to the band spectra (corr_rows_up_kernel), peak pass.  Nine slices: four paired runs
+    specialised path: column transforms of the band windows themselves (4000 x 750, four side by side), the row stage
+    that applies the x4 up-sampling of both axes to the band spectra (corr_rows_up_kernel), peak pass.  Nine slices: four paired runs
     and one single unit; the oracle (2.5 s per correlation: up-samples the image, then transforms it) checks the
     first pair and the single unit."""
     from oracle import phasecorr as pc
@@ -186,10 +186,11 @@ def test_interband_reference_unit_shape_matches_oracle(ctx, oracle_mod):
 
 
 def test_spectral_upsampling_route_equals_the_image_route(ctx, oracle_mod):
-    """3000-column units take the horizontal x4 cubic up-sampling on the band spectra (DFT_N(R s) = H DFT_n(s) + sum
-    G_j s_j, exact); OIP_SPECTRAL_UP=0 keeps it in the loader of the first FFT pass.  Both routes against each other
-    (rounding only: 1e-4 px; measured 4e-6) and against the oracle, on a pair plus a single unit, at two line counts
-    (64: every frequency line pairs with itself or its mirror inside one workgroup sweep; 400: several sweeps)."""
+    """3000-column units take the x4 cubic up-sampling of the bands on their spectra (DFT_N(R s) = H DFT_n(s) + sum
+    G_j s_j along an axis, exact): OIP_SPECTRAL_UP=2 (default) on both axes, =1 on the horizontal axis only (vertical
+    taps as an image kernel), =0 keeps both in the image domain (vertical kernel + loader of the first FFT pass).
+    All routes against each other (rounding only: 1e-4 px; measured 4e-6) and the default against the oracle, on a
+    pair plus a single unit, at two line counts (64: one sweep of the row kernel; 400: several sweeps)."""
     import os
     from oracle import phasecorr as pc
     for rows, seed in ((64, 4), (400, 5)):
@@ -200,21 +201,25 @@ def test_spectral_upsampling_route_equals_the_image_route(ctx, oracle_mod):
         bp = [[dplanes[b][:, 750 * u:] for b in range(4)] for u in range(3)]
         res = {}
         try:
-            for mode in ("0", "1"):
+            for mode in ("0", "1", "2"):
                 os.environ["OIP_SPECTRAL_UP"] = mode
                 res[mode] = ctx.interband_correlate_units(pp, [W] * 3, bp, [W // 4] * 3, rows, 3000)
         finally:
             os.environ.pop("OIP_SPECTRAL_UP", None)
-        assert np.isfinite(res["1"]).all()
-        d = np.abs(res["1"] - res["0"])
-        assert d[..., :2].max() < 1e-4 and d[..., 2].max() < 1e-4, (rows, d.max(axis=(0, 1)))
-        assert d.max() > 0, "both routes gave identical bits: the switch did not switch"
+        default = ctx.interband_correlate_units(pp, [W] * 3, bp, [W // 4] * 3, rows, 3000)
+        assert np.array_equal(default, res["2"])
+        for mode in ("1", "2"):
+            assert np.isfinite(res[mode]).all()
+            d = np.abs(res[mode] - res["0"])
+            assert d[..., :2].max() < 1e-4 and d[..., 2].max() < 1e-4, (rows, mode, d.max(axis=(0, 1)))
+            assert d.max() > 0, "two routes gave identical bits: the switch did not switch"
+        assert np.abs(res["2"] - res["1"]).max() > 0
         for u in range(3):
             a = oracle_mod.window_u16_to_f32(pan, 0, 3000 * u, rows, 3000)
             for b in range(4):
                 small = oracle_mod.window_u16_to_f32(bands[b], 0, 750 * u, rows // 4, 750)
                 (wdx, wdy), wr = pc.phase_correlate(a, oracle_mod.resize_cubic(small, 3000, rows))
-                gdx, gdy, gr = res["1"][u, b]
+                gdx, gdy, gr = res["2"][u, b]
                 assert abs(gr - wr) < 5 * RESP_TOL, (rows, u, b, gr, wr)
                 if wr >= 0.05:
                     assert abs(gdx - wdx) < SHIFT_TOL and abs(gdy - wdy) < SHIFT_TOL, (rows, u, b, (gdx, gdy), (wdx, wdy))

@@ -1659,18 +1659,27 @@ struct BandPackJob {
     const uint16_t *bx[4], *by[4];
     long pitch[4];
 };
-__global__ __launch_bounds__(kBlock) void pack_bands_kernel(BandPackJob job, int m, int n, int Pn, float2 *__restrict__ z, unsigned *__restrict__ raw16)
+template <bool PAIRS>        // PAIRS: two neighbouring columns per thread through 4-byte loads (host-checked alignment)
+__global__ __launch_bounds__(128) void pack_bands_kernel(BandPackJob job, int m, int n, int Pn, float2 *__restrict__ z, unsigned *__restrict__ raw16)
 {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    constexpr int W = PAIRS ? 2 : 1;
+    const int p = W * (blockIdx.x * 128 + threadIdx.x);
     const int a = blockIdx.z;
     if (p >= n) return;
     const uint16_t *bx = job.bx[a] + p, *by = job.by[a] + p;
     const long pitch = job.pitch[a];
     for (int y = blockIdx.y; y < m; y += gridDim.y) {
-        const unsigned ux = bx[y * pitch], uy = by[y * pitch];
-        z[(long)y * Pn + a * n + p] = make_float2((float)ux, (float)uy);
         const int r = y < 2 ? y : (y >= m - 2 ? y - (m - 4) : -1);
-        if (r >= 0) raw16[((long)r * 4 + a) * n + p] = ux | (uy << 16);
+        if (PAIRS) {
+            const unsigned ux = *reinterpret_cast<const unsigned *>(bx + y * pitch), uy = *reinterpret_cast<const unsigned *>(by + y * pitch);
+            *reinterpret_cast<float4 *>(z + (long)y * Pn + a * n + p) =
+                make_float4((float)(ux & 0xffffu), (float)(uy & 0xffffu), (float)(ux >> 16), (float)(uy >> 16));
+            if (r >= 0) *reinterpret_cast<uint2 *>(raw16 + ((long)r * 4 + a) * n + p) = make_uint2((ux & 0xffffu) | (uy << 16), (ux >> 16) | (uy & 0xffff0000u));
+        } else {
+            const unsigned ux = bx[y * pitch], uy = by[y * pitch];
+            z[(long)y * Pn + a * n + p] = make_float2((float)ux, (float)uy);
+            if (r >= 0) raw16[((long)r * 4 + a) * n + p] = ux | (uy << 16);
+        }
     }
 }
 
@@ -1696,9 +1705,16 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
         }
         {
             OipProfScope prof(ctx, "pack_bands_kernel");
-            int gy = band_rows < 64 ? band_rows : 64;
-            hipLaunchKernelGGL(pack_bands_kernel, dim3((band_cols + kBlock - 1) / kBlock, gy, 4), dim3(kBlock), 0, ctx->stream, bj, band_rows, band_cols, Pn,
-                               w.z[1], raw);
+            bool pairs = (band_cols & 1) == 0 && (Pn & 1) == 0;
+            for (int a = 0; a < 4; ++a)
+                pairs = pairs && (bj.pitch[a] & 1) == 0 && ((size_t)bj.bx[a] & 3) == 0 && ((size_t)bj.by[a] & 3) == 0;
+            const int gy = band_rows < 128 ? band_rows : 128;
+            if (pairs)
+                hipLaunchKernelGGL(pack_bands_kernel<true>, dim3((band_cols / 2 + 127) / 128, gy, 4), dim3(128), 0, ctx->stream, bj, band_rows, band_cols, Pn,
+                                   w.z[1], raw);
+            else
+                hipLaunchKernelGGL(pack_bands_kernel<false>, dim3((band_cols + 127) / 128, gy, 4), dim3(128), 0, ctx->stream, bj, band_rows, band_cols, Pn,
+                                   w.z[1], raw);
             OIP_HIP(ctx, hipGetLastError());
         }
         ctx->prof_tag = "_band";

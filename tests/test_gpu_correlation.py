@@ -225,6 +225,26 @@ def test_spectral_upsampling_route_equals_the_image_route(ctx, oracle_mod):
                     assert abs(gdx - wdx) < SHIFT_TOL and abs(gdy - wdy) < SHIFT_TOL, (rows, u, b, (gdx, gdy), (wdx, wdy))
 
 
+def test_spectral_route_with_unaligned_windows(ctx):
+    """window pointers that are not 16-byte (PAN) / 4-byte (bands) aligned take the generic loaders of the first PAN pass
+    and of the band pack kernel: same results as the image-domain route on the same windows"""
+    import os
+    rows, W = 64, 9016
+    pan, bands = _synth.pan_mss(rows, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=6)
+    dpan, dplanes = _cuda(pan), [_cuda(b) for b in bands]
+    pp = [dpan[:, 3000 * u + 5:] for u in range(2)]                      # odd pixel offsets
+    bp = [[dplanes[b][:, 750 * u + 1:] for b in range(4)] for u in range(2)]
+    res = {}
+    try:
+        for mode in ("0", "2"):
+            os.environ["OIP_SPECTRAL_UP"] = mode
+            res[mode] = ctx.interband_correlate_units(pp, [W] * 2, bp, [W // 4] * 2, rows, 3000)
+    finally:
+        os.environ.pop("OIP_SPECTRAL_UP", None)
+    d = np.abs(res["2"] - res["0"])
+    assert np.isfinite(res["2"]).all() and 0 < d.max() < 1e-4, d.max(axis=(0, 1))
+
+
 def test_interband_12288_wide_shape_matches_oracle(ctx, oracle_mod):
     """slice width 1228 -> 1250-point rows (the reference's 12288-pixel strips): fused row stage for 1250"""
     _interband_vs_oracle(ctx, 4000, 9824, 8, 1, 4000)

@@ -1122,6 +1122,81 @@ __global__ void centroid_kernel(const float *__restrict__ window, const long *__
     result[2] = response;
 }
 
+// The same in one launch, without re-running the last inverse pass on 25 tiles per part: block `part` reduces the
+// arg-max slots of its surface, evaluates the 25 window cells directly -- the last inverse column pass is
+//     c(y, x) = sum_{n < F1} data[(y mod S) + S n][x] exp(+2 pi i n y / M)        (S = M / F1; nothing was stored by it)
+// so a cell is a 128-term sum for the 16000-line geometry -- and runs weightedCentroid on them.  The cell values differ
+// from the pass's own in the last bits (another summation order), like any two float transforms.
+constexpr int kPeakWinThreads = 1024;
+__global__ __launch_bounds__(kPeakWinThreads) void peak_window_kernel(const float2 *__restrict__ data, int M, int N, int P, int F1, int S,
+                                                                     const float2 *__restrict__ twM, unsigned long long *__restrict__ slots,
+                                                                     int nparts, double *__restrict__ result)
+{
+    constexpr int NW = kPeakWinThreads / 64;
+    const int part = blockIdx.x;
+    __shared__ unsigned long long sbest[NW];
+    __shared__ float win[25];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long best = 0ull;
+    for (int i = threadIdx.x; i < kPeakSlots; i += kPeakWinThreads) {
+        const unsigned long long v = slots[part * kPeakSlots + i];
+        best = v > best ? v : best;
+        // last reader of this surface's slots: leave them empty for the next surface (the pass fills the imaginary
+        // one's slots even when only the real surface is wanted)
+        slots[part * kPeakSlots + i] = 0ull;
+        if (nparts == 1) slots[kPeakSlots + i] = 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) sbest[wave] = best;
+    __syncthreads();
+    best = sbest[0];
+    for (int w = 1; w < NW; ++w) best = sbest[w] > best ? sbest[w] : best;
+    const long key = oip_peak_key(best, 0);           // an all-NaN surface has no entry: minMaxLoc leaves (0, 0)
+    const int py = (int)(key / N), px = (int)(key - (long)py * N);
+    // a wave per window cell (all loads of the window in flight together)
+    for (int cell = wave; cell < 25; cell += NW) {
+        const int ys = py - 2 + cell / 5, xs = px - 2 + cell % 5;
+        float acc = 0.f;
+        const bool inside = ys >= 0 && ys < M && xs >= 0 && xs < N;     // weightedCentroid clamps the window to the image
+        if (inside) {
+            int yo = ys - (M >> 1); if (yo < 0) yo += M;                 // fftShift
+            int xo = xs - (N >> 1); if (xo < 0) xo += N;
+            const int o1 = yo % S;
+            for (int n = lane; n < F1; n += 64) {
+                const float2 z = data[(long)(o1 + S * n) * P + xo];
+                const float2 w = twM[(int)(((long)n * yo) % M)];         // exp(-2 pi i n yo / M); the sum wants its conjugate
+                acc += part ? __fsub_rn(__fmul_rn(z.y, w.x), __fmul_rn(z.x, w.y)) : __fadd_rn(__fmul_rn(z.x, w.x), __fmul_rn(z.y, w.y));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) win[cell] = inside ? acc : NAN;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double cxs = 0.0, cys = 0.0, si = 0.0;
+    for (int dy = 0; dy < 5; ++dy)
+        for (int dx = 0; dx < 5; ++dx) {
+            const int y = py - 2 + dy, x = px - 2 + dx;
+            if (y < 0 || y >= M || x < 0 || x >= N) continue;
+            const double v = (double)win[dy * 5 + dx];
+            cxs = __dadd_rn(cxs, __dmul_rn((double)x, v));
+            cys = __dadd_rn(cys, __dmul_rn((double)y, v));
+            si = __dadd_rn(si, v);
+        }
+    double response = si;
+    si = __dadd_rn(si, DBL_EPSILON);
+    const double cx = cxs / si, cy = cys / si;
+    response = response / (double)((long)M * N);
+    result[3 * part + 0] = (double)N / 2.0 - cx;
+    result[3 * part + 1] = (double)M / 2.0 - cy;
+    result[3 * part + 2] = response;
+}
+
 int optimal_dft_size(int n)
 {
     // cv::getOptimalDFTSize: smallest 2^a 3^b 5^c >= n
@@ -1557,8 +1632,19 @@ int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, flo
     io.slots = w.slots;
     int rc = oip_fft2d_exec(ctx, pl, y, 1, &io, rows_done ? 1 : 0);
     if (rc) return rc;
-    // all parts (the real and imaginary surface of y) in one launch each; the window launch reduces
-    // the arg-max slots itself
+    // arg-max -> 5x5 window -> centroid of all parts (the real and imaginary surface of y) in one launch
+    // (OIP_WINDOW_FFT=1: the earlier form -- re-run the last pass on the 25 tiles of the window, then a centroid launch)
+    static const char *envw = getenv("OIP_WINDOW_FFT");
+    if (!(envw && atoi(envw))) {
+        const float2 *twM;
+        if ((rc = oip_fft_table(ctx, pl->M, &twM))) return rc;
+        const int F1 = pl->yf[0];
+        OipProfScope prof(ctx, "peak_window_kernel");
+        hipLaunchKernelGGL(peak_window_kernel, dim3(nparts), dim3(kPeakWinThreads), 0, ctx->stream, y, pl->M, pl->N, pl->P, F1, pl->M / F1, twM, w.slots, nparts,
+                           d_results);
+        OIP_HIP(ctx, hipGetLastError());
+        return OIP_OK;
+    }
     OipFftIo wio;
     memset(&wio, 0, sizeof wio);
     wio.peak_key = w.keys;

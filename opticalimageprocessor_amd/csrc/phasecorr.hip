@@ -727,12 +727,13 @@ __global__ __launch_bounds__(NT) void corr_rows3_kernel(FusedJob fj, int M, int 
 // sample 0 or n-1 instead of wrapping to n-2, n-1, 0, 1).  So the N = 4n point transform of an up-sampled line is
 //     DFT_N(R s)[k] = H[k] DFT_n(s)[k mod n] + sum_j G_j[k] s[J_j],       H = DFT_N(h), G_j = DFT_N(E[:, J_j])
 // -- a 750-point transform, one complex multiply and four multiply-adds per bin instead of a 3000-point transform of
-// the up-sampled line, and the four band images of a unit need no full-size column passes at all: their columns are
-// transformed at the width of the band window (16000 x 750, a quarter of the array).  The identity is exact; what
-// changes against transforming the up-sampled image is the rounding (the f32 rounding of every up-sampled pixel is
-// replaced by the rounding of H, G and the products), 1e-6 px on the shifts -- the size of the difference between
-// any two float FFTs (tests/test_gpu_correlation.py compares both routes and the oracle, which up-samples first).
-// The vertical taps are still applied in the image domain (resize_cubic_v), with cv::resize's own arithmetic.
+// the up-sampled line.  The same holds along the columns (VEXP): the band windows are transformed at their own size
+// (4000 x 750) and line ky of the up-sampled band's column transform is Hv[ky] B^[ky mod 4000] + sum_i Gv_i[ky] raw_i.
+// Without VEXP (OIP_SPECTRAL_UP=1) the vertical taps are applied in the image domain (resize_cubic_v) and the columns of
+// the resulting 16000 x 750 images are transformed.  The identity is exact; what changes against transforming the
+// up-sampled image is the rounding (the f32 rounding of every up-sampled pixel is replaced by the rounding of H, G and
+// the products), 4e-6 px on the shifts -- the size of the difference between any two float FFTs
+// (tests/test_gpu_correlation.py compares the routes with each other and with the oracle, which up-samples first).
 //
 // One launch serves a pair of units: zp = PAN_A + i PAN_B (full width), four narrow arrays (bands 0|1 and 2|3 of unit
 // A, then of unit B) and four outputs Y = C(PAN, band 2a) + i C(PAN, band 2a+1).  LDS holds the PAN line pair, one

@@ -1755,6 +1755,7 @@ __global__ __launch_bounds__(128) void pack_bands_kernel(BandPackJob job, int m,
     if (p >= n) return;
     const uint16_t *bx = job.bx[a] + p, *by = job.by[a] + p;
     const long pitch = job.pitch[a];
+#pragma unroll 4
     for (int y = blockIdx.y; y < m; y += gridDim.y) {
         const int r = y < 2 ? y : (y >= m - 2 ? y - (m - 4) : -1);
         if (PAIRS) {

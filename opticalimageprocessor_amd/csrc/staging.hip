@@ -37,6 +37,7 @@ public:
     {
         const int n = threads();
         if (n == 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
+        std::lock_guard<std::mutex> one_at_a_time(mCall);          // an upload and a download thread may both be here
         const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
         {
             std::unique_lock<std::mutex> lk(mMu);
@@ -85,7 +86,7 @@ private:
         }
     }
     std::vector<std::thread> mWorkers;
-    std::mutex mMu;
+    std::mutex mMu, mCall;
     std::condition_variable mCv, mDone;
     unsigned long mGen = 0;
     int mPending = 0;
@@ -110,7 +111,14 @@ struct oip_stage_state {
     bool slot_used[kSlots] = {false, false, false, false};
     int next = 0;
     hipEvent_t ticket_ev[kTicketRing];
-    hipEvent_t compute_ev = nullptr;        // marks the compute stream's position for downloads
+    hipEvent_t compute_ev = nullptr;        // marks the compute stream's position for uploads
+    // the download lane: its own two slots, stream2 and event, so that oip_download_staged on one host thread and an
+    // upload on another never touch the same state (full duplex over the link)
+    void *dslot[2] = {nullptr, nullptr};
+    hipEvent_t dslot_free[2] = {nullptr, nullptr};
+    bool dslot_used[2] = {false, false};
+    int dnext = 0;
+    hipEvent_t down_compute_ev = nullptr;
     std::atomic<long> ticket{0};
     // LUT cache of oip_rrc_u16_host
     double *d_kb = nullptr;
@@ -133,7 +141,14 @@ static int stage_init(oip_ctx *ctx)
     }
     for (int i = 0; i < kTicketRing; ++i)
         if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
-    if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->down_compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    for (int i = 0; i < 2; ++i)
+        if (hipHostMalloc(&s->dslot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&s->dslot_free[i], hipEventDisableTiming) != hipSuccess) {
+            delete s;
+            return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
+        }
     ctx->stage = s;
     return OIP_OK;
 }
@@ -147,6 +162,8 @@ void oip_stage_destroy(oip_ctx *ctx)
     for (int i = 0; i < kSlots; ++i) { if (s->slot[i]) hipHostFree(s->slot[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
     for (int i = 0; i < kTicketRing; ++i) hipEventDestroy(s->ticket_ev[i]);
     if (s->compute_ev) hipEventDestroy(s->compute_ev);
+    if (s->down_compute_ev) hipEventDestroy(s->down_compute_ev);
+    for (int i = 0; i < 2; ++i) { if (s->dslot[i]) hipHostFree(s->dslot[i]); if (s->dslot_free[i]) hipEventDestroy(s->dslot_free[i]); }
     if (s->d_kb) hipFree(s->d_kb);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -326,21 +343,24 @@ extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, 
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
-    if ((rc = order_after_compute(ctx, s))) return rc;
+    // the download lane (see oip_stage_state): ordered after what the compute stream has enqueued so far
+    OIP_HIP(ctx, hipEventRecord(s->down_compute_ev, ctx->stream));
+    OIP_HIP(ctx, hipStreamWaitEvent(s->stream2, s->down_compute_ev, 0));
     int prev = -1;
     size_t prev_bytes = 0, prev_off = 0, done = 0;
     auto drain = [&](int i, size_t off, size_t n) -> int {
-        if (hipEventSynchronize(s->slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
-        CopyPool::get().copy((char *)host + off, s->slot[i], n);
+        if (hipEventSynchronize(s->dslot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        CopyPool::get().copy((char *)host + off, s->dslot[i], n);
         return OIP_OK;
     };
     while (done < bytes) {
-        int i;
-        if ((rc = slot_acquire(ctx, s, &i))) return rc;
+        const int i = s->dnext;
+        s->dnext ^= 1;
+        if (s->dslot_used[i]) OIP_HIP(ctx, hipEventSynchronize(s->dslot_free[i]));
         const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
-        OIP_HIP(ctx, hipMemcpyAsync(s->slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream));
-        hipEventRecord(s->slot_free[i], s->stream);
-        s->slot_used[i] = true;
+        OIP_HIP(ctx, hipMemcpyAsync(s->dslot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream2));
+        hipEventRecord(s->dslot_free[i], s->stream2);
+        s->dslot_used[i] = true;
         if (prev >= 0 && (rc = drain(prev, prev_off, prev_bytes))) return rc;
         prev = i; prev_off = done; prev_bytes = n;
         done += n;

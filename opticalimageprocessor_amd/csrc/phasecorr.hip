@@ -1047,8 +1047,11 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         if (fj.nout == 4) load_tables(tid);
         __builtin_amdgcn_sched_barrier(0);
         store(0);
-        // The lines of the NEXT pair are requested here and committed at the bottom of this same iteration: the first
-        // half of the iteration runs without their registers.
+        if (fj.nout == 4) xround(2, Ab);
+        __builtin_amdgcn_sched_barrier(0);
+        // The lines of the NEXT pair are requested here -- after the last consumer of anything the compiler may have
+        // spilled (a reload is a vector-memory load: younger than the prefetch, it would wait for it) -- and committed at
+        // the bottom of this same iteration: three quarters of the iteration run without their registers.
         if (more && !(dbg & 8)) {
             n1 = ypos[kn];
             n2 = ypos[M - kn];
@@ -1058,10 +1061,7 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
             fetch(tid);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (fj.nout == 4) {
-            xround(2, Ab);
-            finish();
-        }
+        if (fj.nout == 4) finish();
         if (more) commit(tid);
         __builtin_amdgcn_sched_barrier(0);
         if (fj.nout == 4) store(2);
@@ -1839,10 +1839,12 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
         OipProfScope prof(ctx, "corr_rows_up_kernel");
         long grid = ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
-        const char *et = getenv("OIP_UP_THREADS");                      // experiment knob (measured: 1.29 ms with 512 threads -- no spills --, 1.34 with 768)
+        const char *et = getenv("OIP_UP_THREADS");                      // experiment knob: 512 | 768 threads
         const dim3 g((unsigned)grid);
-        if (up.vtab)
+        if (up.vtab && et && atoi(et) == 512)
             hipLaunchKernelGGL((corr_rows_up_kernel<512, true>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        else if (up.vtab)       // measured: 1.30 ms with 768 threads (168 VGPRs, 8 spilled), 1.38 with 512 (240, none)
+            hipLaunchKernelGGL((corr_rows_up_kernel<768, true>), g, dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else if (et && atoi(et) == 768)
             hipLaunchKernelGGL((corr_rows_up_kernel<768, false>), g, dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else

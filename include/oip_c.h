@@ -183,6 +183,13 @@ int oip_interband_correlate_units(oip_ctx *ctx, const uint16_t *const *d_pan, co
                                   const uint16_t *const *d_bands, const size_t *band_pitch, int n, int rows,
                                   int cols, double *out);
 
+/* The x4 cubic up-sampling of cv::resize (preproc.h:302-307) along one axis as an operator on spectra -- what
+ * oip_interband_correlate applies to the transforms of the band windows instead of transforming the up-sampled
+ * image.  Host only.  out: 5 x (4 n) complex floats, rows H, G_0 .. G_3:
+ *   DFT_4n(up-sampled s)[k] = H[k] DFT_n(s)[k mod n] + sum_j G_j[k] s[J_j],   J = {0, 1, n-2, n-1}.
+ * OIP_E_UNSUPPORTED for n < 8. */
+int oip_upsample_operator(int n, float *out);
+
 /* The validity filter and means of Stitcher::CalcSttParameters (stitcher.h:181-198), host: table[3*s +
  * {0,1,2}] = dx, dy, response of section s, in section order.  OIP_E_RUNTIME when no section is valid
  * ("No valid delta value found for stitching parameter calculating"). */

@@ -22,6 +22,7 @@ from .capi import (  # noqa: F401
     polyfit,
     remap_shift_src_range,
     stt_mean,
+    upsample_operator,
     align_mss_src_range,
 )
 

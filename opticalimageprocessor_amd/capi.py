@@ -81,6 +81,7 @@ _SIGS = {
     "oip_polyfit": ([_dp, _dp, _i, _i, _dp], _i),
     "oip_polyfit_reference": ([_dp, _dp, _i, _i, _dp], _i),
     "oip_stt_mean": ([_dp, _i, _d, _d, _dp, _dp, _dp, C.POINTER(_i)], _i),
+    "oip_upsample_operator": ([_i, C.POINTER(C.c_float)], _i),
     "oip_remap_shift_bicubic_u16": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_bicubic_u16_f16acc": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_src_range": ([_l, _l, _l, _d, _i, _lp, _lp], _i),
@@ -187,6 +188,16 @@ def stt_mean(table, threshold=0.4, max_delta_y=0.0):
     if rc:
         raise ValueError("oip_stt_mean: bad argument")
     return dx.value, dy.value, r.value, v.value
+
+
+def upsample_operator(n):
+    """H, G_0..G_3 of the x4 cubic up-sampling n -> 4 n as an operator on spectra (include/oip_c.h): complex64 (5, 4 n)"""
+    lib = load_library()
+    out = np.zeros((5, 4 * n, 2), np.float32)
+    rc = lib.oip_upsample_operator(n, out.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise ValueError("oip_upsample_operator: unsupported length %d" % n)
+    return out[..., 0] + 1j * out[..., 1]
 
 
 def remap_shift_src_range(out_row0, out_rows, L, dy, section_rows=30000):

@@ -241,3 +241,67 @@ extern "C" int oip_stt_mean(const double *table, int sections, double threshold,
     if (response) *response = sr / valid;
     return OIP_OK;
 }
+
+// cv::resize(INTER_CUBIC) by exactly 4 along one axis as an operator on spectra: with R = C + E the
+// n -> N = 4 n up-sampling matrix (C circulant: zero-stuff, convolve with the 16-tap kernel h; E: what clamping instead
+// of wrapping the out-of-image taps adds, non-zero in columns J = {0, 1, n-2, n-1} only),
+//     DFT_N(R s)[k] = H[k] DFT_n(s)[k mod n] + sum_j G_j[k] s[J_j],     H = DFT_N(h), G_j = DFT_N(E[:, J_j]).
+// out[(t * N + k) * 2 + {0,1}] = re, im of H (t = 0) and G_0..G_3 (t = 1..4), as float.  Built in double from the f32
+// taps of cv::hal::resize's coefficient set-up (fx = (float)((d + 0.5) * scale - 0.5), interpolateCubic(fx - floor)),
+// the same the image-domain kernels apply.  OIP_E_UNSUPPORTED when the taps are not 4-periodic or n < 8.
+static inline void host_interpolate_cubic(float x, float *c)
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+extern "C" int oip_upsample_operator(int n, float *out)
+{
+    if (n < 8 || !out) return OIP_E_UNSUPPORTED;
+    const int N = 4 * n;
+    const double scale = 1. / ((double)N / n);
+    std::vector<double> h(N, 0.0), g[4];
+    std::vector<char> hset(N, 0);
+    for (auto &v : g) v.assign(N, 0.0);
+    const int J[4] = {0, 1, n - 2, n - 1};
+    auto jidx = [&](int p) { for (int j = 0; j < 4; ++j) if (J[j] == p) return j; return -1; };
+    for (int d = 0; d < N; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        const int sx = (int)floorf(fx);
+        fx -= sx;
+        float w[4];
+        host_interpolate_cubic(fx, w);
+        for (int j = 0; j < 4; ++j) {
+            const int p = sx - 1 + j;
+            const int e = ((d - 4 * p) % N + N) % N;
+            if (!hset[e]) { h[e] = w[j]; hset[e] = 1; }
+            else if (h[e] != (double)w[j]) return OIP_E_UNSUPPORTED;     // taps not periodic in d: no circulant part
+            if (p < 0 || p >= n) {
+                const int a = jidx(p < 0 ? 0 : n - 1), b = jidx(((p % n) + n) % n);
+                if (a < 0 || b < 0) return OIP_E_UNSUPPORTED;
+                g[a][d] += w[j];
+                g[b][d] -= w[j];
+            }
+        }
+    }
+    const double step = -2.0 * 3.14159265358979323846 / N;
+    auto dft = [&](const std::vector<double> &v, float *dst) {
+        std::vector<int> nz;
+        for (int d = 0; d < N; ++d) if (v[d] != 0.0) nz.push_back(d);
+        for (int k = 0; k < N; ++k) {
+            double re = 0.0, im = 0.0;
+            for (int d : nz) {
+                const double ang = step * (double)(((long)k * d) % N);
+                re += v[d] * cos(ang);
+                im += v[d] * sin(ang);
+            }
+            dst[2 * k] = (float)re;
+            dst[2 * k + 1] = (float)im;
+        }
+    };
+    dft(h, out);
+    for (int j = 0; j < 4; ++j) dft(g[j], out + (size_t)(1 + j) * N * 2);
+    return OIP_OK;
+}

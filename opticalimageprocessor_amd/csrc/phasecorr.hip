@@ -1420,10 +1420,8 @@ int launch_resize_v(oip_ctx *ctx, const SrcT *const *src, float *const *dst, int
 }
 
 // H and G_j of the x4 cubic up-sampling n -> N = 4 n along one axis (0: horizontal, 1: vertical) as an operator on
-// spectra (see corr_rows_up_kernel), built in double from the same f32 taps the image-domain kernels apply: h[e] is the
-// tap that output d = e + 4 p puts on source sample p, G_j is the transform of what clamping (instead of wrapping) the
-// out-of-image taps adds to column j of the operator, j in {0, 1, n-2, n-1}.  *out stays null when the geometry has no
-// such form.
+// spectra (see corr_rows_up_kernel; oip_upsample_operator in host.cpp builds them), cached on the device per resize
+// geometry.  *out stays null when the geometry has no such form.
 int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, int axis, const float2 **out)
 {
     OipResizeTab *t = const_cast<OipResizeTab *>(ctab);
@@ -1435,48 +1433,8 @@ int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, int axis, c
     state = -1;
     const int n = axis ? t->sh : t->sw, N = axis ? t->dh : t->dw;
     if (N != 4 * n || n < 8 || !(axis ? t->x4v : t->x4h)) return OIP_OK;
-    const double scale = 1. / ((double)N / n);
-    std::vector<double> h(N, 0.0), g[4];
-    std::vector<char> hset(N, 0);
-    for (auto &v : g) v.assign(N, 0.0);
-    const int J[4] = {0, 1, n - 2, n - 1};
-    auto jidx = [&](int p) { for (int j = 0; j < 4; ++j) if (J[j] == p) return j; return -1; };
-    for (int d = 0; d < N; ++d) {
-        float fx = (float)((d + 0.5) * scale - 0.5);
-        const int sx = (int)floorf(fx);
-        fx -= sx;
-        float w[4];
-        oip_interpolate_cubic_host(fx, w);
-        for (int j = 0; j < 4; ++j) {
-            const int p = sx - 1 + j;
-            const int e = ((d - 4 * p) % N + N) % N;
-            if (!hset[e]) { h[e] = w[j]; hset[e] = 1; }
-            else if (h[e] != (double)w[j]) return OIP_OK;          // taps not periodic in d: no circulant part
-            if (p < 0 || p >= n) {
-                const int a = jidx(p < 0 ? 0 : n - 1), b = jidx(((p % n) + n) % n);
-                if (a < 0 || b < 0) return OIP_OK;
-                g[a][d] += w[j];
-                g[b][d] -= w[j];
-            }
-        }
-    }
     std::vector<float2> tab((size_t)5 * N);
-    const double step = -2.0 * 3.14159265358979323846 / N;
-    auto dft = [&](const std::vector<double> &v, float2 *dst) {
-        std::vector<int> nz;
-        for (int d = 0; d < N; ++d) if (v[d] != 0.0) nz.push_back(d);
-        for (int k = 0; k < N; ++k) {
-            double re = 0.0, im = 0.0;
-            for (int d : nz) {
-                const double ang = step * (double)(((long)k * d) % N);
-                re += v[d] * cos(ang);
-                im += v[d] * sin(ang);
-            }
-            dst[k] = make_float2((float)re, (float)im);
-        }
-    };
-    dft(h, tab.data());
-    for (int j = 0; j < 4; ++j) dft(g[j], tab.data() + (size_t)(1 + j) * N);
+    if (oip_upsample_operator(n, reinterpret_cast<float *>(tab.data())) != OIP_OK) return OIP_OK;
     OIP_HIP(ctx, hipMalloc(&d_spec, sizeof(float2) * tab.size()));
     OIP_HIP(ctx, hipMemcpy(d_spec, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
     state = 1;

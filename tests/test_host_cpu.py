@@ -214,3 +214,28 @@ def test_align_src_range_is_superset(oracle_mod):
             m[s0:s1] = b[s0:s1]
         part, _ = oracle_mod.align_mss(masked, cx, cy, lps, 0, ovl, False, minl)
         assert np.array_equal(part[o0:o1], want[o0:o1]), (o0, o1, s0, s1)
+
+
+def test_upsample_operator_reproduces_the_transform_of_the_resized_image(oracle_mod):
+    """The inter-band correlation transforms the band window and applies the x4 cubic up-sampling to its spectrum
+    (DESIGN.md 4.3): DFT(resize(B)) = Hv Hh B^ + column / row corrections, with H, G from oip_upsample_operator.  Pinned
+    here against the oracle's cv::resize restatement on both axes (float64 FFTs; the resized image itself is float32,
+    so agreement is at its rounding: 1e-6 of the spectrum's peak)."""
+    rng = np.random.default_rng(3)
+    for m, n in ((8, 12), (25, 10), (40, 188)):
+        B = rng.integers(64, 4096, (m, n)).astype(np.float64)
+        U = oracle_mod.resize_cubic(B.astype(np.float32), 4 * n, 4 * m).astype(np.float64)
+        ref = np.fft.fft2(U)
+        opv, oph = oip.upsample_operator(m).astype(np.complex128), oip.upsample_operator(n).astype(np.complex128)
+        Hv, Gv, Hh, Gh = opv[0], opv[1:], oph[0], oph[1:]
+        Jv, Jh = [0, 1, m - 2, m - 1], [0, 1, n - 2, n - 1]
+        ky, kx = np.arange(4 * m), np.arange(4 * n)
+        B2 = np.fft.fft2(B)
+        Bcol = np.fft.fft(B[:, Jh], axis=0)                       # column transforms of the four raw columns
+        Brow = np.fft.fft(B[Jv, :], axis=1)                       # row transforms of the four raw rows
+        got = (Hv[:, None] * Hh[None, :]) * B2[np.ix_(ky % m, kx % n)]
+        got += (Hv[:, None] * Bcol[ky % m, :]) @ Gh
+        got += Gv.T @ (Hh[None, :] * Brow[:, kx % n] + B[np.ix_(Jv, Jh)] @ Gh)
+        assert np.abs(got - ref).max() < 2e-6 * np.abs(ref).max(), (m, n, np.abs(got - ref).max() / np.abs(ref).max())
+    with pytest.raises(ValueError):
+        oip.upsample_operator(4)

@@ -503,6 +503,11 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": avg_s * 1e3}
+            if dom == "corr_rows_up_kernel":
+                roof["note"] = ("row stage of a pair of units: six 3000-point row transforms, eight cross-powers per bin pair and "
+                                "the x4 up-sampling operator in one pass over the data; it moves its algorithmic bytes once "
+                                "(traffic / algorithmic = 1.01) and is bound by vector-instruction issue, not by HBM "
+                                "(profiles/r02_pmc_up.json; DESIGN.md 4.3) -- the HBM-bound passes of the step run at 3.6-5.8 TB/s")
         line = {
             "metric": "Mpix/s end-to-end RRC+stitch on 30000x100000x4 strip; % HBM roofline",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -268,10 +268,12 @@ def test_vertical_upsampling_kernels_agree(ctx):
 
 
 # ---- parity evidence that can be had without OpenCV (PARITY UNPINNED stays) ---------------
-def _straddling_scene(seed=21, W=2560):
+def _straddling_scene(seed=21, W=2560, Lp=3200, sections=2):
     """PAN + four bands whose slices carry increasing noise: the unit responses spread over 0.0 .. 1.0, eight to
-    eleven of sixteen per band above the reference's 0.4 threshold (IBCV_DEF_THRESHOLD), none within 0.01 of it."""
-    Lp, slices, sections, corr = 3200, 8, 2, 1600
+    eleven of sixteen per band above the reference's 0.4 threshold (IBCV_DEF_THRESHOLD), none within 0.01 of it.
+    (seed 23, W 24000, Lp 1600, one section: the same on 3000-column slices -- the spectral up-sampling route --
+    with five or six of eight units per band above the threshold, none within 0.007 of it.)"""
+    slices, corr = 8, 1600
     pan, bands = _synth.pan_mss(Lp, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=seed)
     rng = np.random.default_rng(seed)
     bw = W // 4 // slices
@@ -307,13 +309,15 @@ def test_gpu_against_float32_and_float64_oracles(ctx, oracle_mod):
     assert g64[0] < max(20 * o[0], 1e-4) and g64[1] < max(20 * o[1], 1e-4), (g64, o)
 
 
-def test_valid_set_straddling_the_reference_threshold(ctx, oracle_mod):
+@pytest.mark.parametrize("scene", [dict(), dict(seed=23, W=24000, Lp=1600, sections=1)], ids=["image-route", "spectral-route"])
+def test_valid_set_straddling_the_reference_threshold(ctx, oracle_mod, scene):
     """The reference keeps a unit when its response reaches 0.4 (preproc.h:492-512).  On a scene whose responses
     straddle that threshold the GPU and the oracle must keep the SAME units, and the polynomials fitted to the two
-    kept sets must give maps that agree to 1/64 px over the whole line (half a 1/32-px phase step)."""
+    kept sets must give maps that agree to 1/64 px over the whole line (half a 1/32-px phase step).  Once on
+    320-column slices (up-sampling in the image domain) and once on 3000-column slices (up-sampling on the spectra)."""
     import opticalimageprocessor_amd as oip
     from oracle import phasecorr as pc
-    pan, bands, (Lp, W, slices, sections, corr) = _straddling_scene()
+    pan, bands, (Lp, W, slices, sections, corr) = _straddling_scene(**scene)
     want = pc.calc_interband_correlation(pan, bands, slices, sections, corr)
     assert np.abs(want[..., 2] - 0.4).min() > 5e-3              # the scene itself keeps clear of the threshold
     planes = _cuda(np.stack(bands, 0))

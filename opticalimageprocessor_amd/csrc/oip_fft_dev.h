@@ -416,6 +416,15 @@ template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
     static constexpr int A = R == 15 ? 3 : (R == 25 ? 5 : 1);       // composite split R = A * B (1: plain radix)
     static __device__ __forceinline__ void decode(int item, int *base, int *b)
     {
+        if ((NA & (NA - 1)) == 0) {
+            // item bits: line | buffer | butterfly -- no division (a quarter of the row stage's vector instructions was
+            // integer arithmetic); a wave's accesses stay conflict-free: the two lines of a point are adjacent, the
+            // buffers half the banks apart (2 F float2 = 12000 dwords for F = 3000)
+            constexpr int LA = NA == 1 ? 0 : (NA == 2 ? 1 : (NA == 4 ? 2 : 3));
+            *b = item >> (1 + LA);
+            *base = ((item >> 1) & (NA - 1)) * 2 * F + (item & 1);
+            return;
+        }
         const int a = item / (2 * NB), rem = item - a * (2 * NB);
         *b = rem >> 1;
         *base = a * 2 * F + (rem & 1);                                // element offset of (buffer a, line), point 0

@@ -1799,10 +1799,10 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
         const char *et = getenv("OIP_UP_THREADS");                      // experiment knob: 512 | 768 threads
         const dim3 g((unsigned)grid);
-        if (up.vtab && et && atoi(et) == 512)
-            hipLaunchKernelGGL((corr_rows_up_kernel<512, true>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
-        else if (up.vtab)       // measured: 1.30 ms with 768 threads (168 VGPRs, 8 spilled), 1.38 with 512 (240, none)
+        if (up.vtab && et && atoi(et) == 768)
             hipLaunchKernelGGL((corr_rows_up_kernel<768, true>), g, dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
+        else if (up.vtab)       // measured in bench.py: 1.275 ms with 512 threads (244 VGPRs, no scratch), 1.36 with 768 (168, 28 spilled)
+            hipLaunchKernelGGL((corr_rows_up_kernel<512, true>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else if (et && atoi(et) == 768)
             hipLaunchKernelGGL((corr_rows_up_kernel<768, false>), g, dim3(768), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         else

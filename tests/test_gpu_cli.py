@@ -137,6 +137,32 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     assert np.array_equal(twice, np.concatenate([out[:, :out.shape[1] - 1], out[:, 1:]], axis=1))
 
 
+def test_default_action_at_the_30000_wide_geometry(ctx, oracle_mod, tmp_path):
+    """The C++ host on a strip of the BASELINE width: 30000 columns, 10 slices of 3000 -- the geometry whose inter-band
+    correlation runs on the band spectra -- one correlation section of 16000 lines.  The polynomials
+    are re-derived in-process through the same C ABI (bit-identical), the aligned image is compared with the oracle."""
+    import opticalimageprocessor_amd as oip
+    W, L = 30000, 16000
+    d = str(tmp_path)
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_TIFF_COMPRESS="none")
+    pan, bands = _synth.pan_mss(L, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=8)
+    np.concatenate(bands, axis=1).tofile(os.path.join(d, "W_MSS.RAW"))
+    pan.tofile(os.path.join(d, "W_PAN.RAW"))
+    args = [OIP, "--width", str(W), "--pan", "W_PAN.RAW", "--mss", "W_MSS.RAW", "--ibc-sections", "1", "--no-rrc4mss",
+            "--lines-section", "3000", "--overlap-lines", "100"]
+    r = subprocess.run(args, cwd=d, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    Lm, Wb = L // 4, W // 4
+    planes = _cuda(np.stack(bands, 0))
+    sh = ctx.interband_correlate(_cuda(pan), L, 0, L, planes, Lm * Wb, 0, Lm, W, 10, 1, 16000)
+    assert (sh[..., 2] >= 0.4).all()                          # every unit clears the reference's threshold
+    cx, cy = oip.filter_and_fit(sh, 0.4, 5)
+    want, nvalid = oracle_mod.align_mss(bands, cx, cy, 3000, 0, 100, False, 1500)
+    tif, tags, _ = _tiff.read_tiff_u16(os.path.join(d, "W_MSS.ALIGNED.TIFF"))
+    assert np.array_equal(tif[:, :, [2, 1, 0, 3]], want)
+    assert "%d lines valid" % nvalid in r.stdout
+
+
 def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
     """`oip task` (everything resident on the GPU, four RAW files in, two TIFFs out) must
     produce exactly the two products of DOC/sample-task.sh's five commands run through the file system."""

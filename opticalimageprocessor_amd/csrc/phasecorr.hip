@@ -749,7 +749,7 @@ struct UpRowsJob {
     float2 *out[4];
     const float2 *xtab;     // [5][N]: H, G_0 .. G_3
     int nout;               // 4, or 2 for a single unit (arrays 2 and 3 are not read)
-    int dbg;                // experiment mask like FusedJob::dbg
+    int dbg;                // experiment mask like FusedJob::dbg; 32: skip the vertical expansion (results are wrong)
     // VEXP: the vertical up-sampling is applied to the spectra as well.  zn then holds the column transforms of the
     // band windows themselves (m = M / 4 rows): line ky of the up-sampled band is
     //     Hv[ky] zn[ky mod m] + sum_i Gv_i[ky] raw[i],      raw = band rows {0, 1, m-2, m-1}

@@ -1,5 +1,5 @@
 """Phase breakdown of corr_rows_up_kernel by skipping phases (OIP_ROWS_DBG mask; results are wrong, times are the point).
-bits: 1 fwd stages, 2 cross-power, 4 inverse stages, 8 global loads after the first pair, 16 stores"""
+bits: 1 fwd stages, 2 cross-power, 4 inverse stages, 8 global loads after the first pair, 16 stores, 32 vertical expansion"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

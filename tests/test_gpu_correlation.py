@@ -56,6 +56,27 @@ PC_SHAPES = [
 ]
 
 
+def test_column_pass_panels_with_mixed_tile_widths(ctx, tmp_path):
+    """4000 = 32 * 125: the two column passes use 32- and 16-lane tiles.  Cutting the columns into panels
+    (OIP_FFT_PANELS, an experiment knob read once per process -- hence the child process) must cut each pass in its own
+    tile units: a shared lane-tile window once skipped half the columns of the narrower pass.  Same bits as unpanelled."""
+    import subprocess, sys, json, os
+    rows, cols = 4000, 1250
+    sc = _synth.scene(rows + 32, cols + 32, seed=11)
+    a = np.ascontiguousarray(sc[16:16 + rows, 16:16 + cols], dtype=np.float32)
+    b = np.ascontiguousarray(sc[16 - 5:16 - 5 + rows, 16 + 6:16 + 6 + cols], dtype=np.float32)
+    want = ctx.phase_correlate_f32(_cuda(a), _cuda(b), rows, cols)
+    np.save(tmp_path / "a.npy", a); np.save(tmp_path / "b.npy", b)
+    code = ("import sys, json, numpy as np, torch; sys.path.insert(0, %r); import opticalimageprocessor_amd as oip; "
+            "c = oip.Context(0); a = torch.from_numpy(np.load(%r)).cuda(); b = torch.from_numpy(np.load(%r)).cuda(); "
+            "print(json.dumps(c.phase_correlate_f32(a, b, %d, %d)))" %
+            (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "a.npy"), str(tmp_path / "b.npy"), rows, cols))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OIP_FFT_PANELS="3"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    (gdx, gdy), gr = json.loads(r.stdout.strip().splitlines()[-1])
+    assert (gdx, gdy, gr) == (want[0][0], want[0][1], want[1])
+
+
 @pytest.mark.parametrize("rows,cols,shift", PC_SHAPES)
 def test_phase_correlate_matches_oracle(ctx, oracle_mod, rows, cols, shift):
     from oracle import phasecorr as pc

@@ -75,6 +75,12 @@ def test_column_pass_panels_with_mixed_tile_widths(ctx, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     (gdx, gdy), gr = json.loads(r.stdout.strip().splitlines()[-1])
     assert (gdx, gdy, gr) == (want[0][0], want[0][1], want[1])
+    # the 5x5 window around the peak: evaluated directly (one launch with the arg-max and the centroid) or, as in round 1,
+    # by re-running the last pass on its 25 tiles (OIP_WINDOW_FFT=1) -- two summation orders of the same 128-term sums
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OIP_WINDOW_FFT="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    (odx, ody), orr = json.loads(r.stdout.strip().splitlines()[-1])
+    assert abs(odx - want[0][0]) < 1e-5 and abs(ody - want[0][1]) < 1e-5 and abs(orr - want[1]) < 1e-6, ((odx, ody, orr), want)
 
 
 @pytest.mark.parametrize("rows,cols,shift", PC_SHAPES)

@@ -783,6 +783,13 @@ __device__ __forceinline__ float2 cfmaj(float2 a, float2 b, float2 acc)
     return oipfft::to_f2(r);
 }
 
+// acc + s v for a real s (one packed multiply-add)
+__device__ __forceinline__ float2 sfma(float s, float2 v, float2 acc)
+{
+    OIP_FFT_FMA
+    return make_float2(acc.x + s * v.x, acc.y + s * v.y);
+}
+
 template <int NT, bool VEXP>
 __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, int P, const int *__restrict__ ypos,
                                                           const float2 *__restrict__ twF, const float2 *__restrict__ twS)
@@ -958,11 +965,18 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                     const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
                     if (kx > F / 2) continue;
                     const int c = kx % S, cm = c ? S - c : 0;      // the narrow bin of kx and of -kx
+                    // sum_j G_j e_j = S + i T and sum_j conj(G_j) e_j = S - i T with S = sum Re(G_j) e_j, T = sum Im(G_j) e_j:
+                    // bin kx and its mirror N - kx (conjugate table values) share the products, line by line
+                    float2 S0 = make_float2(0.f, 0.f), T0 = S0, S1 = S0, T1 = S0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        S0 = sfma(G[r][j].x, e0[j], S0); T0 = sfma(G[r][j].y, e0[j], T0);
+                        S1 = sfma(G[r][j].x, e1[j], S1); T1 = sfma(G[r][j].y, e1[j], T1);
+                    }
                     {
                         // packed band spectrum at (ky, kx) and at (-ky, -kx): H and G of -kx are the conjugates
-                        float2 Z0 = oipfft::cmul(H[r], zn[2 * c]), Z1 = cmulj(H[r], zn[2 * cm + 1]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { Z0 = cfma(G[r][j], e0[j], Z0); Z1 = cfmaj(G[r][j], e1[j], Z1); }
+                        const float2 Z0 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(H[r], zn[2 * c]), S0), T0);          // + S0 + i T0
+                        const float2 Z1 = oipfft::cadd_rot(oipfft::cadd(cmulj(H[r], zn[2 * cm + 1]), S1), T1);            // + S1 - i T1
                         const float2 C1 = cross_power_bin_fast(A[2 * r], spec_of(0, Z0, Z1), false, false);
                         const float2 C2 = cross_power_bin_fast(A[2 * r], spec_of(1, Z0, Z1), false, false);
                         // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
@@ -971,9 +985,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                     }
                     if (kx != 0 && 2 * kx != F) {
                         // the same for bin (ky, N - kx) and its mirror (-ky, kx)
-                        float2 Z0 = cmulj(H[r], zn[2 * cm]), Z1 = oipfft::cmul(H[r], zn[2 * c + 1]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { Z0 = cfmaj(G[r][j], e0[j], Z0); Z1 = cfma(G[r][j], e1[j], Z1); }
+                        const float2 Z0 = oipfft::cadd_rot(oipfft::cadd(cmulj(H[r], zn[2 * cm]), S0), T0);                // + S0 - i T0
+                        const float2 Z1 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(H[r], zn[2 * c + 1]), S1), T1);      // + S1 + i T1
                         const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec_of(0, Z0, Z1), false, false);
                         const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec_of(1, Z0, Z1), false, false);
                         ob[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));

@@ -783,6 +783,12 @@ __device__ __forceinline__ float2 cfmaj(float2 a, float2 b, float2 acc)
     return oipfft::to_f2(r);
 }
 
+// spec_of without its factor 1/2 (the row stage's horizontal tables carry it)
+__device__ __forceinline__ float2 spec2_of(int part, float2 zk, float2 zm)
+{
+    if (part == 0) return make_float2(zk.x + zm.x, zk.y - zm.y);
+    return make_float2(zk.y + zm.y, zm.x - zk.x);
+}
 // acc + s v for a real s (one packed multiply-add)
 __device__ __forceinline__ float2 sfma(float s, float2 v, float2 acc)
 {
@@ -977,8 +983,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                         // packed band spectrum at (ky, kx) and at (-ky, -kx): H and G of -kx are the conjugates
                         const float2 Z0 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(H[r], zn[2 * c]), S0), T0);          // + S0 + i T0
                         const float2 Z1 = oipfft::cadd_rot(oipfft::cadd(cmulj(H[r], zn[2 * cm + 1]), S1), T1);            // + S1 - i T1
-                        const float2 C1 = cross_power_bin_fast(A[2 * r], spec_of(0, Z0, Z1), false, false);
-                        const float2 C2 = cross_power_bin_fast(A[2 * r], spec_of(1, Z0, Z1), false, false);
+                        const float2 C1 = cross_power_bin_fast(A[2 * r], spec2_of(0, Z0, Z1), false, false);
+                        const float2 C2 = cross_power_bin_fast(A[2 * r], spec2_of(1, Z0, Z1), false, false);
                         // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
                         ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
                         ob[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
@@ -987,8 +993,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                         // the same for bin (ky, N - kx) and its mirror (-ky, kx)
                         const float2 Z0 = oipfft::cadd_rot(oipfft::cadd(cmulj(H[r], zn[2 * cm]), S0), T0);                // + S0 - i T0
                         const float2 Z1 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(H[r], zn[2 * c + 1]), S1), T1);      // + S1 + i T1
-                        const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec_of(0, Z0, Z1), false, false);
-                        const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec_of(1, Z0, Z1), false, false);
+                        const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec2_of(0, Z0, Z1), false, false);
+                        const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec2_of(1, Z0, Z1), false, false);
                         ob[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
                         ob[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
                     }
@@ -1013,8 +1019,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
                     float2 Z0 = oipfft::cmul(He, zn[0]), Z1 = cmulj(He, zn[1]);       // kx = 0 and N/2 both map to narrow bin 0
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { Z0 = cfma(Ge[j], edge[o0 + h][0][j], Z0); Z1 = cfmaj(Ge[j], edge[o0 + h][1][j], Z1); }
-                    const float2 C1 = cross_power_bin(Ae, spec_of(0, Z0, Z1), real_bin, true);
-                    const float2 C2 = cross_power_bin(Ae, spec_of(1, Z0, Z1), real_bin, true);
+                    const float2 C1 = cross_power_bin(Ae, spec2_of(0, Z0, Z1), real_bin, true);
+                    const float2 C2 = cross_power_bin(Ae, spec2_of(1, Z0, Z1), real_bin, true);
                     float2 *ob = buf + h * 2 * F;
                     ob[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
                     ob[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);   // -kx == kx here
@@ -1448,6 +1454,8 @@ int upsample_spectrum_tables(oip_ctx *ctx, const OipResizeTab *ctab, int axis, c
     if (N != 4 * n || n < 8 || !(axis ? t->x4v : t->x4h)) return OIP_OK;
     std::vector<float2> tab((size_t)5 * N);
     if (oip_upsample_operator(n, reinterpret_cast<float *>(tab.data())) != OIP_OK) return OIP_OK;
+    if (axis == 0)          // the horizontal tables carry the 1/2 of the unpacking of a packed band pair (spec2_of): exact
+        for (auto &v : tab) { v.x *= 0.5f; v.y *= 0.5f; }
     OIP_HIP(ctx, hipMalloc(&d_spec, sizeof(float2) * tab.size()));
     OIP_HIP(ctx, hipMemcpy(d_spec, tab.data(), sizeof(float2) * tab.size(), hipMemcpyHostToDevice));
     state = 1;

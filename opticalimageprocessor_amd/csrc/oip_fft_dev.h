@@ -508,4 +508,44 @@ template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesAll<F,
     }
 };
 
+// Two independent three-stage transforms (buffers bp: NAP x two lines of FP points, bn: NAN_ x two lines of FN points)
+// interleaved: between two barriers one stores a stage and the other loads its next one, so the six stages cost seven
+// barriers instead of twelve while only one register array is live at a time.
+template <class OpsA, class OpsB, int RA, int RB>
+__device__ __forceinline__ void stage_store_then_load(float2 *ba, const float2 *twa, float2 (&xa)[OpsA::PER][RA], float2 *bb,
+                                                      float2 (&xb)[OpsB::PER][RB], int tid)
+{
+    OpsA::store(ba, twa, xa, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    OpsB::load(bb, xb, tid);
+}
+template <int FP, int NAP, int FN, int NAN_, int NT, int R1, int R2, int R3P, int R3N> struct StagesDual3 {
+    static __device__ __forceinline__ void run(float2 *bp, const float2 *twp, float2 *bn, const float2 *twn, int tid)
+    {
+        using P1 = StageAllOps<FP, NT, NAP, 1, R1>;        using N1 = StageAllOps<FN, NT, NAN_, 1, R1>;
+        using P2 = StageAllOps<FP, NT, NAP, R1, R2>;       using N2 = StageAllOps<FN, NT, NAN_, R1, R2>;
+        using P3 = StageAllOps<FP, NT, NAP, R1 * R2, R3P>; using N3 = StageAllOps<FN, NT, NAN_, R1 * R2, R3N>;
+        float2 a1[P1::PER][R1];
+        P1::load(bp, a1, tid);
+        __syncthreads();
+        float2 b1[N1::PER][R1];
+        stage_store_then_load<P1, N1, R1, R1>(bp, twp, a1, bn, b1, tid);
+        __syncthreads();
+        float2 a2[P2::PER][R2];
+        stage_store_then_load<N1, P2, R1, R2>(bn, twn, b1, bp, a2, tid);
+        __syncthreads();
+        float2 b2[N2::PER][R2];
+        stage_store_then_load<P2, N2, R2, R2>(bp, twp, a2, bn, b2, tid);
+        __syncthreads();
+        float2 a3[P3::PER][R3P];
+        stage_store_then_load<N2, P3, R2, R3P>(bn, twn, b2, bp, a3, tid);
+        __syncthreads();
+        float2 b3[N3::PER][R3N];
+        stage_store_then_load<P3, N3, R3P, R3N>(bp, twp, a3, bn, b3, tid);
+        __syncthreads();
+        N3::store(bn, twn, b3, tid);
+        __syncthreads();
+    }
+};
+
 }  // namespace oipfft

@@ -937,8 +937,7 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         load_tables(tid);
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 1)) {
-            oipfft::StagesAll<F, NT, 1, 1, 25, 15, 8>::run(buf, tw, tid);
-            oipfft::StagesAll<S, NT, 4, 1, 25, 15, 2>::run(bufN, tws, tid);
+            oipfft::StagesDual3<F, 1, S, 4, NT, 25, 15, 8, 2>::run(buf, tw, bufN, tws, tid);
         }
         // PAN spectra of this thread's bins (unit A in the real slot, unit B in the imaginary one); those of the two
         // edge columns (kx = 0, N/2: divSpectrums' double-precision and real-only formulas) also go to edgeA

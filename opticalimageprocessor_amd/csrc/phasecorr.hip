@@ -928,13 +928,15 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
     commit(threadIdx.x);
     long s1 = n1, s2 = n2;
     __syncthreads();
+    bool first = true;
     for (; ky <= half; ky += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const bool pair = s1 != s2;
         const int kn = ky + gridDim.x;
         const bool more = kn <= half;
-        load_tables(tid);
+        if (first) load_tables(tid);            // later iterations: requested before the previous iteration's last stores
+        first = false;
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 1)) {
             oipfft::StagesDual3<F, 1, S, 4, NT, 25, 15, 8, 2>::run(buf, tw, bufN, tws, tid);
@@ -1081,6 +1083,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         __builtin_amdgcn_sched_barrier(0);
         if (fj.nout == 4) finish();
         if (more) commit(tid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_tables(tid);             // ahead of the stores: waiting for them then waits for nothing younger
         __builtin_amdgcn_sched_barrier(0);
         if (fj.nout == 4) store(2);
         s1 = n1; s2 = n2;

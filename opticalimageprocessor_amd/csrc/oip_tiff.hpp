@@ -27,6 +27,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -145,6 +146,9 @@ inline size_t lzw_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
             old = code;
             continue;
         }
+        // A conforming encoder sends ClearCode when it assigns entry 4093, so the decoder's table never reaches 4096
+        // entries; a stream that keeps sending codes without clearing is corrupt (libtiff: "Corrupted LZW table").
+        if (next >= 4096) throw std::runtime_error("corrupt LZW stream (table full without ClearCode)");
         int emit = code;
         if (code >= next) {
             if (code != next) throw std::runtime_error("corrupt LZW stream (code beyond the table)");
@@ -166,7 +170,7 @@ inline size_t lzw_decode(const uint8_t *src, size_t n, uint8_t *dst, size_t cap)
             if (produced < cap) memcpy(dst + produced, tmp.data(), cap - produced);
         }
         produced += len;
-        if (next < 4096) ++next;
+        ++next;
         if (next >= (1 << width) - 1 && width < 12) ++width;       // early change
         old = code;
         if (produced >= cap && pos >= n) break;
@@ -196,7 +200,10 @@ public:
         if (compression != TIFF_NONE && compression != TIFF_LZW) throw std::invalid_argument("TiffWriterU16: unsupported compression");
         mRowBytes = (size_t)width * spp * 2;
         const size_t data = mRowBytes * (size_t)height;
-        mBig = data + (size_t)height * 16 / 64 + 4096 > 0xFFFFF000ull;      // classic TIFF offsets are 32 bit (LZW output is smaller; BigTIFF is always valid)
+        // classic TIFF offsets are 32 bit.  LZW can also GROW a strip: at worst one 12-bit code per byte (x1.5), so the
+        // choice is made on the worst case and a classic file can never overflow half-way (BigTIFF is always valid).
+        const size_t worst = compression == TIFF_LZW ? data + data / 2 : data;
+        mBig = worst + (size_t)height * 16 / 64 + 4096 > 0xFFFFF000ull;
         mRowsPerStrip = (long)((8u << 20) / mRowBytes);
         if (mRowsPerStrip < 1) mRowsPerStrip = 1;
         if (mRowsPerStrip > height) mRowsPerStrip = height;
@@ -228,37 +235,34 @@ public:
             }
             return;
         }
-        // compressed: rows gather into whole strips, strips are encoded on a few threads, then written in order
+        // compressed: whole strips are encoded straight from the caller's rows in bounded batches (a few strips per
+        // worker thread at a time) and written in order; only the rows of a strip left incomplete by this call are kept
         const size_t rw = (size_t)mW * mSpp;
-        mPending.insert(mPending.end(), rows, rows + (size_t)count * rw);
         mRowsDone += count;
-        const long have = (long)(mPending.size() / rw);
-        long nstrips = have / mRowsPerStrip;
-        if (mRowsDone == mH && have % mRowsPerStrip) ++nstrips;           // the last, short strip
-        if (nstrips == 0) return;
-        std::vector<std::vector<uint8_t>> enc((size_t)nstrips);
-        tiffdetail::parallel_for((size_t)nstrips, [&](size_t k) {
-            const long r0 = (long)k * mRowsPerStrip;
-            const long n = std::min<long>(mRowsPerStrip, have - r0);
-            std::vector<uint16_t> buf((size_t)n * rw);
-            for (long r = 0; r < n; ++r) {
-                const uint16_t *src = mPending.data() + (size_t)(r0 + r) * rw;
-                uint16_t *d = buf.data() + (size_t)r * rw;
-                if (mSwap) swap_row(src, d); else memcpy(d, src, rw * 2);
-                tiffdetail::predictor2_encode(d, (size_t)mW, mSpp);
+        const bool last = mRowsDone == mH;
+        long r = 0;
+        if (!mPending.empty()) {
+            long have = (long)(mPending.size() / rw);
+            const long take = std::min<long>(count, mRowsPerStrip - have);
+            mPending.insert(mPending.end(), rows, rows + (size_t)take * rw);
+            r = take;
+            have += take;
+            if (have == mRowsPerStrip || (last && r == count)) {
+                encode_strips(mPending.data(), have);
+                mPending.clear();
             }
-            tiffdetail::lzw_encode((const uint8_t *)buf.data(), buf.size() * 2, enc[k]);
-        });
-        long used = 0;
-        for (long k = 0; k < nstrips; ++k) {
-            if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
-            mStripOff.push_back(mPos);
-            mStripLen.push_back(enc[k].size());
-            put(enc[k].data(), enc[k].size());
-            mPos += enc[k].size();
-            used += std::min<long>(mRowsPerStrip, have - k * mRowsPerStrip);
         }
-        mPending.erase(mPending.begin(), mPending.begin() + (size_t)used * rw);
+        const long full = (count - r) / mRowsPerStrip;
+        const long batch = 2 * (long)tiffdetail::worker_count();
+        for (long k0 = 0; k0 < full; k0 += batch) {
+            const long nk = std::min(batch, full - k0);
+            encode_strips(rows + (size_t)(r + k0 * mRowsPerStrip) * rw, nk * mRowsPerStrip);
+        }
+        r += full * mRowsPerStrip;
+        if (r < count) {
+            if (last) encode_strips(rows + (size_t)r * rw, count - r);           // the last, short strip
+            else mPending.insert(mPending.end(), rows + (size_t)r * rw, rows + (size_t)count * rw);
+        }
     }
 
     void close()
@@ -320,6 +324,34 @@ public:
     bool bigtiff() const { return mBig; }
 
 private:
+    // encode `nrows` rows (whole strips, the last one possibly short) on a few threads and append them to the file
+    void encode_strips(const uint16_t *rows, long nrows)
+    {
+        const size_t rw = (size_t)mW * mSpp;
+        const long nstrips = (nrows + mRowsPerStrip - 1) / mRowsPerStrip;
+        std::vector<std::vector<uint8_t>> enc((size_t)nstrips);
+        tiffdetail::parallel_for((size_t)nstrips, [&](size_t k) {
+            const long r0 = (long)k * mRowsPerStrip;
+            const long n = std::min<long>(mRowsPerStrip, nrows - r0);
+            std::vector<uint16_t> buf((size_t)n * rw);
+            for (long r = 0; r < n; ++r) {
+                const uint16_t *src = rows + (size_t)(r0 + r) * rw;
+                uint16_t *d = buf.data() + (size_t)r * rw;
+                if (mSwap) swap_row(src, d); else memcpy(d, src, rw * 2);
+                tiffdetail::predictor2_encode(d, (size_t)mW, mSpp);
+            }
+            tiffdetail::lzw_encode((const uint8_t *)buf.data(), buf.size() * 2, enc[k]);
+        });
+        for (long k = 0; k < nstrips; ++k) {
+            if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
+            if (!mBig && mPos + enc[k].size() > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
+            mStripOff.push_back(mPos);
+            mStripLen.push_back(enc[k].size());
+            put(enc[k].data(), enc[k].size());
+            mPos += enc[k].size();
+        }
+    }
+
     void swap_row(const uint16_t *src, uint16_t *dst) const
     {
         for (int x = 0; x < mW; ++x) {
@@ -434,7 +466,18 @@ inline void read_tiff_u16(const std::string &path, int *width, long *height, int
         for (uint64_t l : lens) { if (l > row_bytes * H - total) fail("strip sizes exceed the image"); total += l; }
         if (total != row_bytes * H) fail("strip sizes do not cover the image");
     }
-    out->resize((size_t)(W * H * S));
+    if (comp == TIFF_LZW) {
+        // header fields alone must not size the allocation: a 12-bit code (1.5 bytes) expands to at most 4096 - 258
+        // bytes, so the strips present bound what the image can decode to
+        uint64_t packed = 0;
+        for (uint64_t l : lens) packed += l;
+        if (row_bytes * H / 2560 > packed + 16) fail("image size is implausible for its compressed strips");
+    }
+    try {
+        out->resize((size_t)(W * H * S));
+    } catch (const std::bad_alloc &) {
+        fail("not enough memory for a " + std::to_string(W) + " x " + std::to_string(H) + " x " + std::to_string(S) + " image");
+    }
     unsigned char *dstb = reinterpret_cast<unsigned char *>(out->data());
     if (comp == TIFF_NONE) {
         size_t pos = 0;

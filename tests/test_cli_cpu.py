@@ -71,8 +71,10 @@ def _tiff_tool(tmp_path):
                    'FILE*f=fopen(v[3],"wb");fwrite(d.data(),2,d.size(),f);fclose(f);printf("%d %ld %d\\n",w,h,s);return 0;}'
                    'catch(std::exception&e){printf("ERR %s\\n",e.what());return 3;}}\n')
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)],
-                   check=True)
+    # AddressSanitizer + UBSan on the CPU build (sanitizers are not available on the GPU pool): every malformed-input
+    # case below must end in a clean ERR, not in an out-of-bounds access
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                    "-I", os.path.join(root, "opticalimageprocessor_amd", "csrc"), str(src), "-o", str(exe)], check=True)
     return exe
 
 
@@ -173,10 +175,51 @@ def test_tiff_reader(tmp_path):
              "hugew.tiff": patched(256, 8, "<I", 0xFFFFFFFF),             # width that overflows the image size
              "zerocount.tiff": patched(273, 4, "<I", 0),                  # tag with count 0
              "trunc.tiff": good[: len(good) // 2]}
+    # corrupt LZW payloads behind a valid header (one strip, 64 x 64 gray): a stream that fills the code table without ever
+    # sending ClearCode (Clear, then 6000 literal 9..12-bit codes -- used to write past the decoder's 4096-entry tables),
+    # random bytes, a truncated stream, and a tiny file whose header claims a 2^40-byte image
+    def lzw_file(payload, w=64, h=64):
+        tags = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, 16), (259, 3, 1, 5), (262, 3, 1, 1), (273, 4, 1, 8 + 2 + 12 * 10 + 4),
+                (277, 3, 1, 1), (278, 4, 1, h), (279, 4, 1, len(payload)), (339, 3, 1, 1)]
+        b = struct.pack("<2sHI", b"II", 42, 8) + struct.pack("<H", len(tags))
+        for t in tags:
+            b += struct.pack("<HHII", *t)
+        return b + struct.pack("<I", 0) + payload
+
+    def pack_codes(codes):
+        acc = nb = 0
+        out = bytearray()
+        width, nxt, first = 9, 258, True
+        for c in codes:
+            acc = (acc << width) | c; nb += width
+            while nb >= 8:
+                out.append((acc >> (nb - 8)) & 0xFF); nb -= 8
+            if c == 256:
+                width, nxt, first = 9, 258, True
+            elif first:
+                first = False                        # the first code after Clear adds no table entry
+            else:
+                nxt += 1
+                if nxt >= (1 << width) - 1 and width < 12:
+                    width += 1
+        if nb:
+            out.append((acc << (8 - nb)) & 0xFF)
+        return bytes(out)
+    noclear = pack_codes([256] + [(i * 37) % 256 for i in range(6000)])
+    good_payload = _tiff.lzw_encode((np.arange(4096) % 700).astype("<u2").tobytes())
+    cases.update({"noclear.tiff": lzw_file(noclear),
+                  "garbage.tiff": lzw_file(bytes(rng.integers(0, 256, 5000, dtype=np.uint8))),
+                  "lzwtrunc.tiff": lzw_file(good_payload[: len(good_payload) // 2]),
+                  "claims_huge.tiff": lzw_file(b"\x80\x00\x20\x20", w=1 << 20, h=1 << 19)})
+    # the healthy payload behind the same hand-made header decodes (the header builder itself is sound)
+    (tmp_path / "ok64.tiff").write_bytes(lzw_file(good_payload))
+    r = subprocess.run([str(exe), "read", str(tmp_path / "ok64.tiff"), str(tmp_path / "o7.raw")], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert np.array_equal(np.fromfile(tmp_path / "o7.raw", np.uint16), (np.arange(4096) % 700).astype(np.uint16))
     for name, data in cases.items():
         (tmp_path / name).write_bytes(data)
         r = subprocess.run([str(exe), "read", str(tmp_path / name), str(tmp_path / "o6.raw")], capture_output=True, text=True)
-        assert r.returncode == 3 and r.stdout.startswith("ERR"), (name, r.returncode, r.stdout)
+        assert r.returncode == 3 and r.stdout.startswith("ERR"), (name, r.returncode, r.stdout, r.stderr[-2000:])
 
 
 def test_task_subcommand_argument_errors(files):

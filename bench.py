@@ -60,6 +60,9 @@ def parse():
                     help="prestitch: the fp16-accumulate resampling variant (not the parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive pass from pageable host buffers")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short legs for the other single-GPU BASELINE configs (2, 3, 5 at N=1, 12288-wide) that "
+                         "the default one-GPU run attaches as `configs`")
     return ap.parse_args()
 
 
@@ -130,40 +133,51 @@ def optimal_dft_size(n):
     return best
 
 
-def cpu_baseline(W, L, slices, sections):
-    """The oracle (CPU restatement; RRC leg through the reference's own loop when oracle/_ref is present) timed on a
-    bounded sample of the same workload and scaled to the full step -- on ALL the cores this process may use (one
-    socket's worth at most), with the single-core figures kept beside it.  Every leg is embarrassingly
-    parallel over lines or units, so the all-core leg runs independent samples on independent workers: threads where
-    the work is C code that drops the GIL, spawned processes for the numpy FFT correlation."""
+def _cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 64))              # one socket's worth at most
+
+
+_RATES = {}
+
+
+def cpu_rates(W, base_rows, base_cols):
+    """Per-unit costs of the oracle (CPU restatement; RRC leg through the reference's own loop when oracle/_ref is
+    present) on this host, each measured once per (W, unit shape) on a bounded sample: seconds per PAN pixel of RRC,
+    per BIL line of split + RRC, per (unit, band) phase correlation, per aligned MSS line -- on ONE core and on ALL the
+    cores this process may use (one socket's worth at most).  Every leg is embarrassingly parallel over
+    lines or units, so the all-core figure runs independent samples on independent workers: threads where the work is C
+    code that drops the GIL, spawned processes for the numpy FFT correlation."""
+    key = (W, base_rows, base_cols)
+    if key in _RATES:
+        return _RATES[key]
     import concurrent.futures as cf
     import multiprocessing as mp
     import oracle
     from oracle import phasecorr as pc
     from opticalimageprocessor_amd import synth
     t_all = time.time()
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))              # one socket's worth at most
+    cores = _cores()
     rng = np.random.default_rng(1)
     kb = synth.lut(W)
-    # 1. PAN RRC on W x 16384: 1 thread (the reference as shipped), then row-parallel
-    hs = 16384
+    r = {"cores": cores}
+    # 1. PAN RRC on W x hs: 1 thread (the reference as shipped), then row-parallel
+    hs = max(4096, min(16384, (1 << 29) // W // 4096 * 4096))
     img = rng.integers(64, 4096, (hs, W), dtype=np.uint16)
     use_ref = oracle.ref_lib() is not None
     f = oracle.rrc_reference if use_ref else oracle.rrc
     best = 1e9
     for _ in range(3):
         t = time.time(); f(img, kb); best = min(best, time.time() - t)
-    rrc_1 = best * (L / hs)
-    rrc_mpix_1t = W * hs / best / 1e6
     best_mt = 1e9
     for _ in range(3):
         t = time.time(); oracle.rrc(img, kb, threads=cores); best_mt = min(best_mt, time.time() - t)
-    rrc_n = best_mt * (L / hs)
-    rrc_mpix_mt = W * hs / best_mt / 1e6
+    r["rrc_s_per_px"] = (best / (W * hs), best_mt / (W * hs))
+    r["rrc_via"] = "oracle/_ref (the reference's own InplaceRRC)" if use_ref else "the restatement"
+    r["rrc_sample"] = "%dx%d" % (W, hs)
     # 2. MSS split + RRC on W x 4096 BIL lines; all cores: one 4096-line chunk per worker thread
     ms = 4096
     bil = rng.integers(64, 4096, (ms, W), dtype=np.uint16)
@@ -172,16 +186,15 @@ def cpu_baseline(W, L, slices, sections):
     def mss_chunk(_):
         bands = oracle.split_mss(bil)
         return [oracle.rrc(b, k) for b, k in zip(bands, kb4)]
-    t = time.time(); mss_chunk(0); mss_1 = (time.time() - t) * ((L // 4) / ms)
+    t = time.time(); mss_chunk(0); m1 = (time.time() - t) / ms
     with cf.ThreadPoolExecutor(cores) as ex:
-        t = time.time(); list(ex.map(mss_chunk, range(cores))); mss_n = (time.time() - t) / cores * ((L // 4) / ms)
+        t = time.time(); list(ex.map(mss_chunk, range(cores))); mn = (time.time() - t) / cores / ms
+    r["mss_s_per_line"] = (m1, mn)
     # 3. correlation: one (section, slice, band) at full size per worker, spawned processes (numpy FFT)
-    base_rows, base_cols = min(L, 16000), W // slices
-    nub = slices * sections * 4
     t = time.time(); pc.bench_unit_band(7, base_rows, base_cols); t_ub = time.time() - t
-    corr_1 = t_ub * nub
-    corr_n = corr_1
-    workers = min(cores, 32)                    # ~2.5 GB per worker at 16000 x 3000
+    c1 = cn = t_ub
+    per_worker_gb = 2.5 * base_rows * base_cols / 48e6          # ~2.5 GB per worker at 16000 x 3000
+    workers = max(1, min(cores, 32, int(160 / max(per_worker_gb, 0.1))))
     if workers > 1:
         ctx_mp = mp.get_context("spawn")
         env_path = os.environ.get("PYTHONPATH", "")
@@ -191,9 +204,11 @@ def cpu_baseline(W, L, slices, sections):
                 list(ex.map(pc.bench_unit_band, range(workers), [64] * workers, [64] * workers))       # start the workers
                 t = time.time()
                 list(ex.map(pc.bench_unit_band, range(workers), [base_rows] * workers, [base_cols] * workers))
-                corr_n = (time.time() - t) / workers * nub
+                cn = (time.time() - t) / workers
         finally:
             os.environ["PYTHONPATH"] = env_path
+    r["corr_s_per_unit_band"] = (c1, cn)
+    r["corr_workers"] = workers
     # 4. align on 4096 MSS lines; all cores: one chunk per worker thread (the C restatement drops the GIL)
     al = 4096
     bands = [rng.integers(64, 4096, (al, W // 4), dtype=np.uint16) for _ in range(4)]
@@ -201,26 +216,92 @@ def cpu_baseline(W, L, slices, sections):
 
     def align_chunk(_):
         return oracle.align_mss(bands, cx, cy, 20000, 0, 520, False, 1500)[1]
-    scale = (L // 4 - 520) / (al - 520)
-    t = time.time(); align_chunk(0); align_1 = (time.time() - t) * scale
+    t = time.time(); align_chunk(0); a1 = (time.time() - t) / (al - 520)
     with cf.ThreadPoolExecutor(cores) as ex:
-        t = time.time(); list(ex.map(align_chunk, range(cores))); align_n = (time.time() - t) / cores * scale
+        t = time.time(); list(ex.map(align_chunk, range(cores))); an = (time.time() - t) / cores / (al - 520)
+    r["align_s_per_line"] = (a1, an)
+    r["wall_s"] = time.time() - t_all
+    r["unit"] = (base_rows, base_cols)
+    _RATES[key] = r
+    return r
+
+
+def cpu_baseline(W, L, slices, sections):
+    """The oracle's rates (cpu_rates) scaled to one step of the default action on a W x L strip."""
+    base_rows, base_cols = min(L, 16000), W // slices
+    r = cpu_rates(W, base_rows, base_cols)
+    nub = slices * sections * 4
+    tot = []
+    stages = []
+    for k in (0, 1):
+        st = {"rrc_pan": r["rrc_s_per_px"][k] * W * L, "mss_split_rrc": r["mss_s_per_line"][k] * (L // 4),
+              "correlation": r["corr_s_per_unit_band"][k] * nub, "align": r["align_s_per_line"][k] * (L // 4 - 520)}
+        stages.append(st)
+        tot.append(sum(st.values()))
     mpix = 1.25 * W * L / 1e6
-    total_1 = rrc_1 + mss_1 + corr_1 + align_1
-    total_n = rrc_n + mss_n + corr_n + align_n
     return {
-        "value": mpix / total_n, "unit": "Mpix/s", "cores": cores, "kind": "port",
+        "value": mpix / tot[1], "unit": "Mpix/s", "cores": r["cores"], "kind": "port",
         "sample": ("oracle (CPU restatement) on all %d cores this process may use, timed per stage on a bounded sample and scaled "
-                   "to the step: PAN RRC %dx%d via %s (row-parallel), MSS split+RRC and align one %d-line chunk per thread, "
+                   "to the step: PAN RRC %s via %s (row-parallel), MSS split+RRC and align one 4096-line chunk per thread, "
                    "correlation one full-size (%dx%d) unit-band per worker process x %d workers (numpy float64 FFT); "
-                   "%.1f s of wall time" % (cores, W, hs, "oracle/_ref (the reference's own InplaceRRC)" if use_ref else "the restatement",
-                                            ms, base_rows, base_cols, workers, time.time() - t_all)),
-        "stage_seconds_full_step": {"rrc_pan": rrc_n, "mss_split_rrc": mss_n, "correlation": corr_n, "align": align_n},
-        "one_core": {"value": mpix / total_1, "unit": "Mpix/s",
-                     "stage_seconds_full_step": {"rrc_pan": rrc_1, "mss_split_rrc": mss_1, "correlation": corr_1, "align": align_1}},
-        "rrc_reference_1thread_Mpix_s": rrc_mpix_1t,
-        "rrc_all_cores_Mpix_s": rrc_mpix_mt, "rrc_all_cores": cores,
+                   "%.1f s of wall time" % (r["cores"], r["rrc_sample"], r["rrc_via"], base_rows, base_cols, r["corr_workers"], r["wall_s"])),
+        "stage_seconds_full_step": stages[1],
+        "one_core": {"value": mpix / tot[0], "unit": "Mpix/s", "stage_seconds_full_step": stages[0]},
+        "rrc_reference_1thread_Mpix_s": 1e-6 / r["rrc_s_per_px"][0],
+        "rrc_all_cores_Mpix_s": 1e-6 / r["rrc_s_per_px"][1], "rrc_all_cores": r["cores"],
     }
+
+
+def cpu_baseline_prestitch(W, L, sections, overlap=200):
+    """The oracle on the cross-CCD path (CalcSttParameters on 16000 x overlap windows, RRC of both CCDs, SectionaryRemap
+    bicubic, StitchBigRaw), timed on bounded samples and scaled to one step over two W x L segments; one core and all
+    cores (one sample per thread: every stage is line-parallel, the C restatement drops the GIL)."""
+    import concurrent.futures as cf
+    import oracle
+    from oracle import phasecorr as pc
+    from opticalimageprocessor_amd import synth
+    t_all = time.time()
+    cores = _cores()
+    rng = np.random.default_rng(4)
+    base = cpu_rates(W, min(L, 16000), W // 10) if (W, min(L, 16000), W // 10) in _RATES else None
+    if base is None:
+        kb = synth.lut(W)
+        img = rng.integers(64, 4096, (4096, W), dtype=np.uint16)
+        f = oracle.rrc_reference if oracle.ref_lib() is not None else oracle.rrc
+        t = time.time(); f(img, kb); r1 = (time.time() - t) / img.size
+        t = time.time(); oracle.rrc(img, kb, threads=cores); rn = (time.time() - t) / img.size
+        rrc = (r1, rn)
+    else:
+        rrc = base["rrc_s_per_px"]
+    # correlation of one section: 16000 x overlap, float64 numpy FFT (single process: the sections are few and short)
+    a = rng.integers(64, 4096, (16000, overlap)).astype(np.float32)
+    b = np.roll(a, (2, 3), (0, 1))
+    t = time.time(); pc.phase_correlate(a, b); c1 = time.time() - t
+    # remap: SectionaryRemap needs more than 32767 lines (imageop.h:242-244); a narrower strip keeps the sample bounded
+    ws, ls = 2048, 32768
+    src = rng.integers(64, 4096, (ls, ws), dtype=np.uint16)
+    t = time.time(); oracle.prestitch(src, 2.37, -1.62); m1 = (time.time() - t) / src.size
+    nthr = min(cores, 16)
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        t = time.time(); list(ex.map(lambda _: oracle.prestitch(src, 2.37, -1.62), range(nthr))); mn = (time.time() - t) / nthr / src.size
+    mn *= nthr / cores if cores > nthr else 1.0               # perfect line-parallel scaling beyond the threads tried: generous to the CPU
+    left = rng.integers(64, 4096, (8192, 4096), dtype=np.uint16)
+    t = time.time(); oracle.stitch_raw(left, left, overlap // 2); s1 = (time.time() - t) / (2 * (4096 - overlap // 2) * 8192)
+    with cf.ThreadPoolExecutor(nthr) as ex:
+        t = time.time(); list(ex.map(lambda _: oracle.stitch_raw(left, left, overlap // 2), range(nthr)))
+        sn = (time.time() - t) / nthr / (2 * (4096 - overlap // 2) * 8192)
+    sn *= nthr / cores if cores > nthr else 1.0
+    out_px = 2 * (W - overlap // 2) * L
+    st1 = {"correlation": c1 * sections, "rrc_x2": rrc[0] * 2 * W * L, "remap": m1 * W * L, "stitch": s1 * out_px}
+    stn = {"correlation": c1 * sections / min(cores, sections), "rrc_x2": rrc[1] * 2 * W * L, "remap": mn * W * L, "stitch": sn * out_px}
+    mpix = 2.0 * W * L / 1e6
+    return {"value": mpix / sum(stn.values()), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": ("oracle (CPU restatement) per stage on bounded samples, scaled to two %dx%d segments: %d x (16000x%d) "
+                       "phase correlations (numpy float64 FFT), RRC via the rates of the default leg, SectionaryRemap bicubic "
+                       "on %dx%d per thread x %d threads, StitchBigRaw on 2 x 4096x8192 per thread; %.1f s of wall time" %
+                       (W, L, sections, overlap, ws, ls, nthr, time.time() - t_all)),
+            "stage_seconds_full_step": stn,
+            "one_core": {"value": mpix / sum(st1.values()), "unit": "Mpix/s", "stage_seconds_full_step": st1}}
 
 
 def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, threshold, reps=3):
@@ -313,14 +394,251 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
                     "the upload; file I/O excluded; best of %d" % (nblk, reps)}, (cx, cy)
 
 
+class Params:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def build_workload(env, p):
+    """Allocate the synthetic rasters of one workload on this rank and return (step, description dict).  `env` carries the
+    context, the device, rank/world and the imported modules; `p` names the workload (Params)."""
+    torch, synth, ctx, dev, rank, world = env.torch, env.synth, env.ctx, env.dev, env.rank, env.world
+    from opticalimageprocessor_amd.dist import (CcdBuffers, CcdPlan, HipBackend, ShardBuffers, StripPlan,
+                                                default_action_step, prestitch_stitch_step)
+    W = p.width
+    pb = 65536 if p.workload == "rrc" else p.lines
+    Lp = pb * world
+    kb_pan = synth.lut(W)
+    kb_mss = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
+    d_kb_pan, d_kb_mss = ctx.upload_kb(kb_pan), ctx.upload_kb(kb_mss)
+    info = {}
+    d = Params(W=W, pb=pb, info=info, kb_pan=kb_pan, d_kb_pan=d_kb_pan, d_kb_mss=d_kb_mss, plan=None, rows_arrays=5.0)
+    if p.workload == "prestitch":
+        OV = 200
+        kb2 = synth.lut(W, 5)
+        d_kb2 = ctx.upload_kb(kb2)
+        nsec = min(10, Lp // 16000)
+        cplan = CcdPlan(W, Lp, world, nsec, 16000, OV, 0)
+        pan1, pan2 = synth.ccd_pair(rank * pb, pb, W, OV, kb_pan, kb2, device=dev)
+        cbufs = CcdBuffers(cplan, rank, pan1, pan2)
+        prestt = torch.empty_like(pan1)
+        stitched = torch.empty(pb, 2 * (W - cplan.fold), dtype=torch.uint16, device=dev)
+        backend = HipBackend(ctx, cplan)
+
+        def step():
+            # main.cpp:270-286 then :177-190: correlation on the raw strips, RRC of both, remap of CCD 2, stitch
+            dx, dy, _ = prestitch_stitch_step(backend, cplan, cbufs, d_kb_pan, d_kb2, prestt, stitched, rank,
+                                              threshold=p.threshold, f16acc=p.fp16)
+            info["dx"], info["dy"] = dx, dy
+        d.__dict__.update(step=step, pix_per_rank=2 * W * pb, base_rows=16000, base_cols=OV, M=16000, N=OV, out_local=0,
+                          rows_arrays=2.0, prestt=prestt, stitched=stitched, sections=nsec,
+                          workload=("prestitch + stitch: 2 CCD segments %dx%d%s, %d x (16000x%d) phase correlations, RRC x2, "
+                                    "constant-shift bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d" %
+                                    (W, Lp, " in %d scan-line blocks" % world if world > 1 else "", nsec, OV,
+                                     "fp16" if p.fp16 else "fp32", cplan.fold)))
+    elif p.workload == "rrc":
+        raw_pan = synth.pan_strip(rank * pb, pb, W, kb_pan, device=dev)
+        dst = torch.empty_like(raw_pan)
+
+        def step():
+            ctx.rrc_u16(raw_pan, dst, W, pb, d_kb_pan)
+        d.__dict__.update(step=step, pix_per_rank=W * pb, base_rows=1, base_cols=1, M=1, N=1, out_local=0,
+                          workload="RRC kernel only, %dx%d u16 per GPU (BASELINE config 2)" % (W, pb))
+    else:
+        # default: the reference's sections for the WHOLE strip, whatever its length (BASELINE config 4);
+        # weak5n: `world` times the sections, so that every rank keeps the single-GPU run's correlation work
+        raw_pan = synth.pan_strip(rank * pb, pb, W, kb_pan, device=dev)
+        sections_total = p.sections * (world if p.workload == "weak5n" else 1)
+        plan = StripPlan(W, Lp, world, p.slices, sections_total)
+        bufs = ShardBuffers(plan, rank, dev)
+        raw_mss = synth.mss_strip(rank * plan.mb, plan.mb, W, kb_mss, device=dev)
+        o0, o1 = plan.align_out_rows(rank)
+        out = torch.zeros(max(o1 - o0, 1), W // 4, 4, dtype=torch.uint16, device=dev)
+        backend = HipBackend(ctx, plan)
+
+        def step():
+            cx, cy, _ = default_action_step(backend, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, rank,
+                                            threshold=p.threshold)
+            info["cx"], info["cy"] = cx, cy
+        base_rows, base_cols = plan.base_rows, W // p.slices
+        M, N = optimal_dft_size(base_rows), optimal_dft_size(base_cols)
+        workload = ("default action (--do-rrc4pan): PAN %dx%d + MSS 4x(%dx%d) per GPU; RRC + %dx%dx4 inter-band phase "
+                    "correlations (%dx%d FFT) + polyfit + bicubic align to 16UC4" %
+                    (W, pb, W // 4, plan.mb, p.sections, p.slices, M, N))
+        if world > 1:
+            workload += ("; strip of %d x %d lines with %d sections in total, %d..%d of its %d units per rank" %
+                         (world, pb, sections_total, min(len(plan.units_of(r)) for r in range(world)),
+                          max(len(plan.units_of(r)) for r in range(world)), plan.n_units))
+        d.__dict__.update(step=step, pix_per_rank=W * pb + W * plan.mb, base_rows=base_rows, base_cols=base_cols, M=M, N=N,
+                          out_local=o1 - o0, workload=workload, plan=plan, bufs=bufs, raw_pan=raw_pan, raw_mss=raw_mss, out=out)
+    # a synthetic scene that does not clear --ibc-threshold is an error here, not a reason to change the workload
+    d.step()
+    ctx.sync()
+    return d
+
+
+def measure(env, d, steps, warmup):
+    """W untimed warm-up steps, then exactly K timed steps between barriers; max over ranks.
+
+    Per-kernel table: ONE untimed step with every kernel bracketed by HIP events (the last warm-up step, or an extra
+    step when --warmup 0), recorded by the library on the stream the kernels run on.  The events cost about 2 % of a
+    step, so the timed region times only the dominant kernel found there -- which is the kernel the roofline object is
+    about."""
+    ctx, torch, dist = env.ctx, env.torch, env.dist
+    for _ in range(max(warmup - 1, 0)):
+        d.step()
+    ctx.profile_filter(None)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    d.step()
+    ctx.sync()
+    ctx.profile_enable(False)
+    prof_all = ctx.profile()
+    dom = max(prof_all.items(), key=lambda kv: kv[1][0])[0] if prof_all else None
+    env.barrier()
+    ctx.profile_reset()
+    ctx.profile_filter(dom)
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d.step()
+    ctx.sync()
+    env.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    ctx.profile_filter(None)
+    prof = ctx.profile()                     # the dominant kernel, over the timed region
+    t = torch.tensor([elapsed], dtype=torch.float64, device=env.dev if env.dist_backend == "nccl" else "cpu")
+    if env.world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), prof_all, prof, dom
+
+
+def summarise(env, d, p, elapsed, steps, prof_all, prof, dom):
+    ms_per_step = elapsed / steps * 1e3
+    value = d.pix_per_rank * env.world * steps / elapsed / 1e6
+    ab = algorithmic_bytes(d.W, d.pb, d.M, d.N, d.base_rows, d.base_cols, d.out_local, d.rows_arrays)
+    kernels = {}
+    for name, (ms, n) in prof_all.items():
+        avg = ms / max(n, 1)
+        e = {"launches_per_step": float(n), "avg_ms": avg, "total_ms_per_step": ms}
+        nbytes = ab.get(name) or fft_pass_bytes(name, d.M, d.N, d.base_rows, d.base_cols)
+        if nbytes:
+            e["algorithmic_GBs"] = nbytes / (avg * 1e-3) / 1e9
+            ab[name] = nbytes
+        kernels[name] = e
+    roof = None
+    if dom and dom in prof and prof[dom][1] > 0:
+        # the dominant kernel's row comes from the timed region
+        avg = prof[dom][0] / prof[dom][1]
+        kernels[dom].update({"avg_ms_untimed_step": kernels[dom]["avg_ms"], "avg_ms": avg,
+                             "launches_per_step": prof[dom][1] / steps, "total_ms_per_step": prof[dom][0] / steps})
+        if ab.get(dom):
+            kernels[dom]["algorithmic_GBs"] = ab[dom] / (avg * 1e-3) / 1e9
+            avg_s = avg * 1e-3
+            achieved = ab[dom] / avg_s / 1e9
+            traffic = tsrc = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            tkey = "default" if p.workload == "weak5n" else p.workload
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                traffic = tj.get(tkey, {}).get(dom)
+                tsrc = tj.get("_source", {}).get(tkey)
+            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (("profiles/traffic.json (%s): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this "
+                                        "command taken when the profile set was committed, (2*FETCH_SIZE + WRITE_SIZE)*1024 B per launch; "
+                                        "NOT re-measured in this run" % (tsrc or "profiles/collect.sh")) if traffic is not None else None),
+                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": avg_s * 1e3}
+            if dom == "corr_rows_up_kernel":
+                roof["note"] = ("row stage of a pair of units: six 3000-point row transforms, eight cross-powers per bin pair and "
+                                "the x4 up-sampling operator in one pass over the data; it moves its algorithmic bytes once "
+                                "(traffic / algorithmic = 1.01) and is bound by vector-instruction issue, not by HBM "
+                                "(DESIGN.md 4.3) -- the HBM-bound passes of the step run at 3.6-5.8 TB/s")
+    return ms_per_step, value, kernels, roof
+
+
+def rrc_line(kernels):
+    rk = "rrc_u16_flat_kernel" if "rrc_u16_flat_kernel" in kernels else "rrc_u16_kernel"
+    if rk in kernels and "algorithmic_GBs" in kernels[rk]:
+        g = kernels[rk]["algorithmic_GBs"]
+        return {"GBs_read_plus_write": g, "frac_of_8TBs": g / HBM_PEAK_GBS, "GBs_read_only": g / 2,
+                "frac_of_8TBs_read_only": g / 2 / HBM_PEAK_GBS, "Mpix_s": g / 4 * 1e3}
+    return None
+
+
+def config_legs(env, args, line):
+    """The other single-GPU BASELINE configurations, run after the headline workload with a few steps each and attached to
+    the line as `configs`: 2 (RRC 30000x65536), 3 (65536 lines, 4 sections), the N = 1 form of 5 (cross-CCD, fp32 and
+    fp16 accumulate with the measured max |delta| in DN) and the reference's native 12288-wide strips."""
+    torch = env.torch
+    out = {}
+
+    def leg(name, p, steps=5, warmup=1, cpu=None, extra=None):
+        t0 = time.time()
+        torch.cuda.empty_cache()
+        d = build_workload(env, p)
+        elapsed, prof_all, prof, dom = measure(env, d, steps, warmup)
+        ms, value, kernels, roof = summarise(env, d, p, elapsed, steps, prof_all, prof, dom)
+        e = {"workload": d.workload, "steps": steps, "warmup": warmup, "ms_per_step": ms, "Mpix_s": value,
+             "dominant_kernel": ({k: roof[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch")}
+                                 if roof else None),
+             "kernels_ms_per_step": {k: round(v["total_ms_per_step"], 4) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms_per_step"])}}
+        r = rrc_line(kernels)
+        if r:
+            e["rrc_kernel"] = r
+        if extra:
+            e.update(extra(d))
+        if cpu and not args.no_cpu_baseline:
+            e["cpu_baseline"] = cpu()
+        e["wall_s"] = round(time.time() - t0, 1)
+        out[name] = e
+        return d
+
+    W = 30000
+    base = line.get("cpu_baseline")
+
+    def cpu_rrc():
+        return {"value": base["rrc_all_cores_Mpix_s"], "unit": "Mpix/s", "cores": base["rrc_all_cores"],
+                "kind": "reference" if "oracle/_ref" in base["sample"] else "port",
+                "sample": "InplaceRRC row-parallel on all cores (restatement, bit-equal to oracle/_ref); the reference's own loop on "
+                          "one thread: %.0f Mpix/s" % base["rrc_reference_1thread_Mpix_s"]}
+    leg("config2_rrc_30000x65536", Params(workload="rrc", width=W, lines=65536, slices=10, sections=5, threshold=args.ibc_threshold, fp16=False),
+        steps=20, cpu=cpu_rrc if base else None)
+    leg("config3_30000x65536_4sections", Params(workload="default", width=W, lines=65536, slices=10, sections=4, threshold=args.ibc_threshold, fp16=False),
+        cpu=lambda: cpu_baseline(W, 65536, 10, 4))
+    keep = {}
+
+    def grab(d):
+        keep["prestt32"] = d.prestt.clone()
+        return {"shift": {"dx": d.info.get("dx"), "dy": d.info.get("dy"), "truth_px": list(env.synth.CCD_SHIFT)}}
+    pl = 100000
+    leg("config5_n1_prestitch_2x30000x100000_fp32", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold, fp16=False),
+        cpu=lambda: cpu_baseline_prestitch(W, pl, min(10, pl // 16000)), extra=grab)
+
+    def delta(d):
+        a, b = keep.pop("prestt32"), d.prestt
+        worst, diff, tot = 0, 0, 0
+        for y in range(0, a.shape[0], 8192):
+            x = (a[y:y + 8192].to(torch.int32) - b[y:y + 8192].to(torch.int32)).abs()
+            worst = max(worst, int(x.max().item())); diff += int((x > 0).sum().item()); tot += int(x.sum().item())
+        n = a.numel()
+        return {"fp16_vs_fp32": {"max_abs_delta_DN": worst, "mean_abs_delta_DN": tot / n, "pixels_differing_frac": diff / n,
+                                 "tolerance_asserted_DN": 6, "where": "tests/test_gpu_resample.py::test_remap_f16acc_tolerance"}}
+    leg("config5_n1_prestitch_2x30000x100000_fp16acc", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold, fp16=True),
+        extra=delta)
+    keep.clear()
+    leg("reference_geometry_12288x100000", Params(workload="default", width=12288, lines=100000, slices=10, sections=5, threshold=args.ibc_threshold, fp16=False),
+        cpu=lambda: cpu_baseline(12288, 100000, 10, 5))
+    return out
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
     import opticalimageprocessor_amd as oip
     from opticalimageprocessor_amd import synth
-    from opticalimageprocessor_amd.dist import (CcdBuffers, CcdPlan, HipBackend, ShardBuffers, StripPlan,
-                                                default_action_step, prestitch_stitch_step)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -352,205 +670,71 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream)
 
-    W = args.width
-    if args.workload == "rrc":
-        pb = 65536
-    else:
-        pb = args.lines
-    Lp = pb * world
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kb_pan = synth.lut(W)
-    kb_mss = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
-    d_kb_pan, d_kb_mss = ctx.upload_kb(kb_pan), ctx.upload_kb(kb_mss)
-    raw_pan = synth.pan_strip(rank * pb, pb, W, kb_pan, device=dev)
-    threshold = args.ibc_threshold
-    info = {}
-
-    if args.workload == "prestitch":
-        OV = 200
-        kb2 = synth.lut(W, 5)
-        d_kb2 = ctx.upload_kb(kb2)
-        del raw_pan
-        nsec = min(10, Lp // 16000)
-        cplan = CcdPlan(W, Lp, world, nsec, 16000, OV, 0)
-        pan1, pan2 = synth.ccd_pair(rank * pb, pb, W, OV, kb_pan, kb2, device=dev)
-        cbufs = CcdBuffers(cplan, rank, pan1, pan2)
-        prestt = torch.empty_like(pan1)
-        stitched = torch.empty(pb, 2 * (W - cplan.fold), dtype=torch.uint16, device=dev)
-        backend = HipBackend(ctx, cplan)
-
-        def step():
-            # main.cpp:270-286 then :177-190: correlation on the raw strips, RRC of both, remap of CCD 2, stitch
-            dx, dy, _ = prestitch_stitch_step(backend, cplan, cbufs, d_kb_pan, d_kb2, prestt, stitched, rank,
-                                              threshold=threshold, f16acc=args.fp16_accumulate)
-            info["dx"], info["dy"] = dx, dy
-        pix_per_rank = 2 * W * pb
-        plan = None
-        base_rows, base_cols = 16000, OV
-        M, N = 16000, OV
-        out_local = 0
-        workload = ("prestitch + stitch: 2 CCD segments %dx%d%s, %d x (16000x%d) phase correlations, RRC x2, constant-shift "
-                    "bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d" %
-                    (W, Lp, " in %d scan-line blocks" % world if world > 1 else "", nsec, OV,
-                     "fp16" if args.fp16_accumulate else "fp32", cplan.fold))
-        step()
-    elif args.workload == "rrc":
-        dst = torch.empty_like(raw_pan)
-
-        def step():
-            ctx.rrc_u16(raw_pan, dst, W, pb, d_kb_pan)
-        pix_per_rank = W * pb
-        plan = None
-        M = N = base_rows = base_cols = 1
-        out_local = 0
-        workload = "RRC kernel only, %dx%d u16 per GPU (BASELINE config 2)" % (W, pb)
-    else:
-        # default: the reference's sections for the WHOLE strip, whatever its length (BASELINE config 4);
-        # weak5n: `world` times the sections, so that every rank keeps the single-GPU run's correlation work
-        sections_total = args.sections * (world if args.workload == "weak5n" else 1)
-        plan = StripPlan(W, Lp, world, args.slices, sections_total)
-        bufs = ShardBuffers(plan, rank, dev)
-        raw_mss = synth.mss_strip(rank * plan.mb, plan.mb, W, kb_mss, device=dev)
-        o0, o1 = plan.align_out_rows(rank)
-        out = torch.zeros(max(o1 - o0, 1), W // 4, 4, dtype=torch.uint16, device=dev)
-        backend = HipBackend(ctx, plan)
-
-        def step():
-            cx, cy, _ = default_action_step(backend, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, rank,
-                                            threshold=threshold)
-            info["cx"], info["cy"] = cx, cy
-        pix_per_rank = W * pb + W * plan.mb
-        base_rows, base_cols = plan.base_rows, W // args.slices
-        M, N = optimal_dft_size(base_rows), optimal_dft_size(base_cols)
-        out_local = o1 - o0
-        workload = ("default action (--do-rrc4pan): PAN %dx%d + MSS 4x(%dx%d) per GPU; RRC + %dx%dx4 inter-band phase "
-                    "correlations (%dx%d FFT) + polyfit + bicubic align to 16UC4" %
-                    (W, pb, W // 4, plan.mb, args.sections, args.slices, M, N))
-        if world > 1:
-            workload += ("; strip of %d x %d lines with %d sections in total, %d..%d of its %d units per rank" %
-                         (world, pb, sections_total, min(len(plan.units_of(r)) for r in range(world)),
-                          max(len(plan.units_of(r)) for r in range(world)), plan.n_units))
-        # a synthetic scene that does not clear --ibc-threshold is an error here, not a reason to change the workload
-        step()
-    ctx.sync()
-
-    # Per-kernel table: ONE untimed step with every kernel bracketed by HIP events (the last warm-up step, or an
-    # extra step when --warmup 0).  The events cost about 2 % of a step, so the timed region times only the
-    # dominant kernel found here -- which is the kernel the roofline object is about.
-    for _ in range(max(args.warmup - 1, 0)):
-        step()
-    ctx.profile_filter(None)
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    step()
-    ctx.sync()
-    ctx.profile_enable(False)
-    prof_all = ctx.profile()
-    dom = max(prof_all.items(), key=lambda kv: kv[1][0])[0] if prof_all else None
-    barrier()
-    ctx.profile_reset()
-    ctx.profile_filter(dom)
-    ctx.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    ctx.profile_filter(None)
-    prof = ctx.profile()                     # the dominant kernel, over the timed region
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    env = Params(torch=torch, dist=dist, synth=synth, ctx=ctx, dev=dev, rank=rank, world=world, barrier=barrier,
+                 dist_backend=dist_backend)
+    p = Params(workload=args.workload, width=args.width, lines=args.lines, slices=args.slices, sections=args.sections,
+               threshold=args.ibc_threshold, fp16=args.fp16_accumulate)
+    d = build_workload(env, p)
+    elapsed, prof_all, prof, dom = measure(env, d, args.steps, args.warmup)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = pix_per_rank * world * args.steps / elapsed / 1e6
-        ab = algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_local, 2.0 if args.workload == "prestitch" else 5.0)
-        kernels = {}
-        for name, (ms, n) in prof_all.items():
-            avg = ms / max(n, 1)
-            e = {"launches_per_step": float(n), "avg_ms": avg, "total_ms_per_step": ms}
-            nbytes = ab.get(name) or fft_pass_bytes(name, M, N, base_rows, base_cols)
-            if nbytes:
-                e["algorithmic_GBs"] = nbytes / (avg * 1e-3) / 1e9
-                ab[name] = nbytes
-            kernels[name] = e
-        roof = None
-        if dom and dom in prof and prof[dom][1] > 0:
-            # the dominant kernel's row comes from the timed region
-            avg = prof[dom][0] / prof[dom][1]
-            kernels[dom].update({"avg_ms_untimed_step": kernels[dom]["avg_ms"], "avg_ms": avg,
-                                 "launches_per_step": prof[dom][1] / args.steps, "total_ms_per_step": prof[dom][0] / args.steps})
-            if ab.get(dom):
-                kernels[dom]["algorithmic_GBs"] = ab[dom] / (avg * 1e-3) / 1e9
-        if dom and ab.get(dom) and dom in prof and prof[dom][1] > 0:
-            avg_s = prof[dom][0] / prof[dom][1] * 1e-3
-            achieved = ab[dom] / avg_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("default" if args.workload == "weak5n" else args.workload, {}).get(dom)
-            roof = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": avg_s * 1e3}
-            if dom == "corr_rows_up_kernel":
-                roof["note"] = ("row stage of a pair of units: six 3000-point row transforms, eight cross-powers per bin pair and "
-                                "the x4 up-sampling operator in one pass over the data; it moves its algorithmic bytes once "
-                                "(traffic / algorithmic = 1.01) and is bound by vector-instruction issue, not by HBM "
-                                "(profiles/r02_pmc_up.json; DESIGN.md 4.3) -- the HBM-bound passes of the step run at 3.6-5.8 TB/s")
+        W, pb = d.W, d.pb
+        ms_per_step, value, kernels, roof = summarise(env, d, p, elapsed, args.steps, prof_all, prof, dom)
         line = {
             "metric": "Mpix/s end-to-end RRC+stitch on 30000x100000x4 strip; % HBM roofline",
             "value": value, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16 rasters; fp64 RRC/maps, f32 bicubic and FFT", "data": "synthetic",
-            "config": {"workload": workload, "width": W, "pan_lines_per_gpu": pb, "parallelism": "rowblock%d" % world,
+            "config": {"workload": d.workload, "width": W, "pan_lines_per_gpu": pb, "parallelism": "rowblock%d" % world,
                        "backend": "rccl" if dist_backend == "nccl" else dist_backend + " (rehearsal, host-staged)",
-                       "ibc_threshold": threshold, "inputs": "resident in HBM"},
+                       "ibc_threshold": p.threshold, "inputs": "resident in HBM"},
+            "value_note": ("`value` is the whole step with the rasters already resident in HBM when the timed region starts (the bench "
+                           "contract); the PCIe-inclusive rate of the same step -- pageable host rasters in, aligned image out, file "
+                           "I/O excluded -- is the `end_to_end` object of this line and is never `value`"),
             "roofline": roof,
             "kernels": kernels,
             "kernels_note": "per-kernel HIP-event times of one untimed step, except the dominant kernel: timed over the timed region (where only it carries events)",
         }
-        rk = "rrc_u16_flat_kernel" if "rrc_u16_flat_kernel" in kernels else "rrc_u16_kernel"
-        if rk in kernels and "algorithmic_GBs" in kernels[rk]:
-            g = kernels[rk]["algorithmic_GBs"]
-            line["rrc_kernel"] = {"GBs_read_plus_write": g, "frac_of_8TBs": g / HBM_PEAK_GBS,
-                                  "GBs_read_only": g / 2, "Mpix_s": g / 4 * 1e3}
+        r = rrc_line(kernels)
+        if r:
+            line["rrc_kernel"] = r
         if args.workload == "prestitch":
-            line["shift"] = {"dx": info.get("dx"), "dy": info.get("dy"), "truth_px": list(synth.CCD_SHIFT)}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "prestitch":
-            pass        # CPU baseline for this workload: see DESIGN.md (oracle remap is measured in the tests)
-        elif world == 1 and not args.no_cpu_baseline and args.workload in ("default", "weak5n"):
-            line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
+            line["shift"] = {"dx": d.info.get("dx"), "dy": d.info.get("dy"), "truth_px": list(synth.CCD_SHIFT)}
+        if world == 1 and not args.no_cpu_baseline:
+            if args.workload == "prestitch":
+                line["cpu_baseline"] = cpu_baseline_prestitch(W, pb, d.sections)
+            elif args.workload in ("default", "weak5n"):
+                line["cpu_baseline"] = cpu_baseline(W, pb, args.slices, args.sections)
+            else:
+                import oracle
+                img = np.random.default_rng(1).integers(64, 4096, (4096, W), dtype=np.uint16)
+                use_ref = oracle.ref_lib() is not None
+                f = oracle.rrc_reference if use_ref else oracle.rrc
+                best = 1e9
+                for _ in range(5):
+                    t1 = time.time(); f(img, d.kb_pan); best = min(best, time.time() - t1)
+                line["cpu_baseline"] = {"value": W * 4096 / best / 1e6, "unit": "Mpix/s", "cores": 1,
+                                        "kind": "reference" if use_ref else "port",
+                                        "sample": "InplaceRRC on %dx4096 u16, best of 5" % W}
         if world == 1 and args.workload == "default" and not args.no_end_to_end:
-            e2e, (ecx, ecy) = end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, threshold)
-            e2e["same_fit_as_resident_step"] = bool(np.array_equal(ecx, info["cx"]) and np.array_equal(ecy, info["cy"]))
+            e2e, (ecx, ecy) = end_to_end_default(ctx, d.plan, d.bufs, d.raw_pan, d.raw_mss, d.d_kb_pan, d.d_kb_mss, d.out, p.threshold)
+            e2e["same_fit_as_resident_step"] = bool(np.array_equal(ecx, d.info["cx"]) and np.array_equal(ecy, d.info["cy"]))
             # the host-buffer form of the RRC seam alone (IMO::InplaceRRC on DoRRC4RAW's heap buffer), in place
             hb = np.random.default_rng(2).integers(64, 4096, (32768, W), dtype=np.uint16)
-            ctx.rrc_u16_host(hb[:2048], kb_pan)
-            t1 = time.perf_counter(); ctx.rrc_u16_host(hb, kb_pan); dt = time.perf_counter() - t1
+            ctx.rrc_u16_host(hb[:2048], d.kb_pan)
+            t1 = time.perf_counter(); ctx.rrc_u16_host(hb, d.kb_pan); dt = time.perf_counter() - t1
             e2e["rrc_host_buffer_Gpix_s"] = hb.size / dt / 1e9
+            del hb
             line["end_to_end"] = e2e
-        elif world == 1 and not args.no_cpu_baseline:
-            import oracle
-            img = np.random.default_rng(1).integers(64, 4096, (4096, W), dtype=np.uint16)
-            use_ref = oracle.ref_lib() is not None
-            f = oracle.rrc_reference if use_ref else oracle.rrc
-            best = 1e9
-            for _ in range(5):
-                t1 = time.time(); f(img, kb_pan); best = min(best, time.time() - t1)
-            line["cpu_baseline"] = {"value": W * 4096 / best / 1e6, "unit": "Mpix/s", "cores": 1,
-                                    "kind": "reference" if use_ref else "port",
-                                    "sample": "InplaceRRC on %dx4096 u16, best of 5" % W}
+        if world == 1 and args.workload == "default" and not args.no_configs and W == 30000 and pb == 100000:
+            d = None                        # release the headline workload's rasters before the other configurations
+            line["configs"] = config_legs(env, args, line)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

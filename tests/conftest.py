@@ -37,3 +37,23 @@ def ctx():
     yield c
     torch.cuda.synchronize()
     c.close()
+
+
+@pytest.fixture()
+def parity_log(request):
+    """Records the measured |GPU - oracle| of a tolerance test next to the bar it was held to (DESIGN.md section 2 quotes
+    this file): one JSON line per call in gpurun_out/parity_deltas.jsonl, best effort."""
+    import json
+
+    def log(**vals):
+        rec = {"test": request.node.name}
+        rec.update({k: (float(v) if hasattr(v, "__float__") else v) for k, v in vals.items()})
+        print("\nparity: %s" % json.dumps(rec))
+        try:
+            d = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "parity_deltas.jsonl"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        except OSError:
+            pass
+    return log

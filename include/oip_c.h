@@ -100,8 +100,13 @@ int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *
  * IMO::ReadFileContent + LoadRawImage / WriteBufferToFile move a raster through one pageable heap buffer,
  * serially with the arithmetic.  These entry points move it in 32 MiB blocks through a ring of pinned
  * buffers on a staging stream of the context's own, so disk, host copies, PCIe and the kernels of the
- * compute stream overlap.  Staging calls may run on a second host thread while the first drives kernels
- * through the same context; two staging calls must not overlap each other.
+ * compute stream overlap.  Staging calls may run on other host threads while the first drives kernels
+ * through the same context: they use streams and pinned slots of their own and never touch the compute
+ * stream's state.  Calls of one lane serialise on a lock (ring lane: read_file / write_file / upload_staged /
+ * rrc_u16_host; download lane: download_staged), the two lanes run concurrently (full duplex).
+ * Ordering: downloads and file writes start after the compute-stream work enqueued before the call; UPLOADS
+ * DO NOT wait for the compute stream -- before re-uploading into a buffer that queued kernels still read,
+ * call oip_stage_order_after_compute(ctx) (or upload elsewhere).
  *   ticket != NULL : the call returns once the last block's DMA is ENQUEUED and *ticket identifies it;
  *                    oip_stage_wait(ctx, t) makes the compute stream wait (on the device) for everything up
  *                    to t.  ticket == NULL: the compute stream is ordered behind the transfer by the call itself.
@@ -118,6 +123,7 @@ int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes,
 int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes);
 int oip_stage_wait(oip_ctx *ctx, long ticket);
 int oip_stage_sync(oip_ctx *ctx);
+int oip_stage_order_after_compute(oip_ctx *ctx);      /* the ring lane's later transfers wait for the compute stream's work enqueued so far */
 int oip_stage_threads(void);                          /* threads of the host copy pool (OIP_HOST_COPY_THREADS) */
 
 /* PreProcessor::LoadMSS split (preproc.h:62-75) fused with DoRRC4MSS (preproc.h:202-222):

@@ -67,6 +67,7 @@ _SIGS = {
     "oip_download_staged": ([_vp, _vp, _vp, _sz], _i),
     "oip_stage_wait": ([_vp, _l], _i),
     "oip_stage_sync": ([_vp], _i),
+    "oip_stage_order_after_compute": ([_vp], _i),
     "oip_stage_threads": ([], _i),
     "oip_mss_split_rrc_u16": ([_vp, _vp, _vp, _sz, _i, _l, _vp], _i),
     "oip_phase_correlate_f32": ([_vp, _vp, _vp, _i, _i, _dp, _dp, _dp], _i),
@@ -299,6 +300,9 @@ class Context:
 
     def stage_wait(self, ticket):
         self._ck(self.lib.oip_stage_wait(self.h, ticket))
+
+    def stage_order_after_compute(self):
+        self._ck(self.lib.oip_stage_order_after_compute(self.h))
 
     def stage_sync(self):
         self._ck(self.lib.oip_stage_sync(self.h))

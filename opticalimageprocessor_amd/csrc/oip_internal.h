@@ -96,6 +96,8 @@ int oip_workspace(oip_ctx *ctx, size_t bytes, void **out);   // grow-only worksp
 int oip_small(oip_ctx *ctx, size_t bytes);                   // make d_small / h_small hold at least `bytes`
 void oip_fft_destroy(oip_ctx *ctx);
 void oip_stage_destroy(oip_ctx *ctx);
+// rrc.hip: the RRC launch on an explicit stream (no profiler scope; safe from a staging thread)
+int oip_rrc_launch(oip_ctx *ctx, hipStream_t stream, const uint16_t *d_src, uint16_t *d_dst, int w, long h, const double *d_kb);
 
 #define OIP_HIP(ctx, call)                                                              \
     do {                                                                                \

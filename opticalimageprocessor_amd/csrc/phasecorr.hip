@@ -1151,12 +1151,21 @@ __global__ void centroid_kernel(const float *__restrict__ window, const long *__
 // so a cell is a 128-term sum for the 16000-line geometry -- and runs weightedCentroid on them.  The cell values differ
 // from the pass's own in the last bits (another summation order), like any two float transforms.
 constexpr int kPeakWinThreads = 1024;
-__global__ __launch_bounds__(kPeakWinThreads) void peak_window_kernel(const float2 *__restrict__ data, int M, int N, int P, int F1, int S,
+// up to four complex arrays per launch (the four outputs of a pair of units): block = array * nparts + part; array j uses
+// the slot set slots + j * 2 * kPeakSlots
+struct PeakWinJob {
+    const float2 *data[4];
+    double *result[4];
+};
+__global__ __launch_bounds__(kPeakWinThreads) void peak_window_kernel(PeakWinJob job, int M, int N, int P, int F1, int S,
                                                                      const float2 *__restrict__ twM, unsigned long long *__restrict__ slots,
-                                                                     int nparts, double *__restrict__ result)
+                                                                     int nparts)
 {
     constexpr int NW = kPeakWinThreads / 64;
-    const int part = blockIdx.x;
+    const int arr = blockIdx.x / nparts, part = blockIdx.x - arr * nparts;
+    const float2 *__restrict__ data = job.data[arr];
+    double *__restrict__ result = job.result[arr];
+    slots += (long)arr * 2 * kPeakSlots;
     __shared__ unsigned long long sbest[NW];
     __shared__ float win[25];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1251,7 +1260,7 @@ struct PcWork {
     float *fa;          // base window, f32
     float *fb[8];       // second images, f32 (up-sampled bands; two units' worth)
     float *fsmall;      // MSS window before resize
-    unsigned long long *slots;  // [2][kPeakSlots] arg-max slots, empty between surfaces
+    unsigned long long *slots;  // [4 arrays][2][kPeakSlots] arg-max slots, empty between surfaces
     long *keys;         // peak key scratch
     float *window;      // 25 floats
 };
@@ -1262,7 +1271,7 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     const size_t zbytes = align_up(sizeof(float2) * (size_t)M * pl->P, 256);
     const size_t fbytes = align_up(sizeof(float) * (size_t)rows * cols, 256);
     const size_t sbytes = align_up(sizeof(float) * (size_t)(small_elems > 0 ? small_elems : 1), 256);
-    const size_t pbytes = align_up(sizeof(unsigned long long) * 2 * kPeakSlots, 256);
+    const size_t pbytes = align_up(sizeof(unsigned long long) * 4 * 2 * kPeakSlots, 256);
     size_t total = zbytes * (nz + ny) + fbytes * (1 + nfb) + sbytes + pbytes + 512;
     void *ws;
     int rc = oip_workspace(ctx, total, &ws);
@@ -1278,7 +1287,7 @@ int carve(oip_ctx *ctx, const OipFft2dPlan *pl, int rows, int cols, int small_el
     w->window = (float *)p;
     // the slots must start empty (later surfaces are cleaned by the centroid kernel)
     ctx->prof_chain = nullptr;
-    OIP_HIP(ctx, hipMemsetAsync(w->slots, 0, sizeof(unsigned long long) * 2 * kPeakSlots, ctx->stream));
+    OIP_HIP(ctx, hipMemsetAsync(w->slots, 0, sizeof(unsigned long long) * 4 * 2 * kPeakSlots, ctx->stream));
     return OIP_OK;
 }
 
@@ -1604,40 +1613,56 @@ int xpower_stage(oip_ctx *ctx, const OipFft2dPlan *pl, const RowStage &rs, const
     return OIP_OK;
 }
 
-// inverse transform of y whose last pass only leaves per-tile maxima, then for each wanted part:
+// arg-max -> 5x5 window -> centroid of both parts (the real and imaginary surface) of `narr` arrays whose last inverse
+// pass left per-tile maxima in slot sets 0 .. narr-1: one launch
+int peak_windows(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, float2 *const *y, double *const *d_results, int narr, int nparts)
+{
+    const float2 *twM;
+    int rc;
+    if ((rc = oip_fft_table(ctx, pl->M, &twM))) return rc;
+    const int F1 = pl->yf[0];
+    PeakWinJob job;
+    for (int j = 0; j < 4; ++j) { job.data[j] = y[j < narr ? j : 0]; job.result[j] = d_results[j < narr ? j : 0]; }
+    OipProfScope prof(ctx, "peak_window_kernel");
+    hipLaunchKernelGGL(peak_window_kernel, dim3(narr * nparts), dim3(kPeakWinThreads), 0, ctx->stream, job, pl->M, pl->N, pl->P, F1, pl->M / F1, twM,
+                       w.slots, nparts);
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
+
+// inverse transform of y whose last pass only leaves per-tile maxima (in slot set `slot_set`), then -- unless `defer`:
+// the caller batches the arrays of a launch through peak_windows -- for each wanted part:
 // arg-max -> recompute the 5x5 window -> centroid -> result slot
 int inverse_and_peaks(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, float2 *y, int nparts, double *d_results,
-                      bool rows_done)
+                      bool rows_done, int slot_set = 0, bool defer = false)
 {
     OipFftIo io;
     memset(&io, 0, sizeof io);
     io.store_kind = 1;
-    io.slots = w.slots;
+    io.slots = w.slots + (long)slot_set * 2 * kPeakSlots;
     int rc = oip_fft2d_exec(ctx, pl, y, 1, &io, rows_done ? 1 : 0);
     if (rc) return rc;
     // arg-max -> 5x5 window -> centroid of all parts (the real and imaginary surface of y) in one launch
     // (OIP_WINDOW_FFT=1: the earlier form -- re-run the last pass on the 25 tiles of the window, then a centroid launch)
     static const char *envw = getenv("OIP_WINDOW_FFT");
     if (!(envw && atoi(envw))) {
-        const float2 *twM;
-        if ((rc = oip_fft_table(ctx, pl->M, &twM))) return rc;
-        const int F1 = pl->yf[0];
-        OipProfScope prof(ctx, "peak_window_kernel");
-        hipLaunchKernelGGL(peak_window_kernel, dim3(nparts), dim3(kPeakWinThreads), 0, ctx->stream, y, pl->M, pl->N, pl->P, F1, pl->M / F1, twM, w.slots, nparts,
-                           d_results);
-        OIP_HIP(ctx, hipGetLastError());
-        return OIP_OK;
+        if (defer) return OIP_OK;
+        float2 *const ys[1] = {y};
+        double *const rs[1] = {d_results};
+        PcWork w1 = w;
+        w1.slots = io.slots;
+        return peak_windows(ctx, pl, w1, ys, rs, 1, nparts);
     }
     OipFftIo wio;
     memset(&wio, 0, sizeof wio);
     wio.peak_key = w.keys;
-    wio.slots = w.slots;
+    wio.slots = io.slots;
     wio.window = w.window;
     wio.part = nparts;
     if ((rc = oip_fft2d_window(ctx, pl, y, &wio))) return rc;
     {
         OipProfScope prof(ctx, "centroid_kernel");
-        hipLaunchKernelGGL(centroid_kernel, dim3(nparts), dim3(64), 0, ctx->stream, w.window, w.keys, pl->M, pl->N, d_results, w.slots);
+        hipLaunchKernelGGL(centroid_kernel, dim3(nparts), dim3(64), 0, ctx->stream, w.window, w.keys, pl->M, pl->N, d_results, io.slots);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
@@ -1665,8 +1690,13 @@ int correlate_four(oip_ctx *ctx, const OipFft2dPlan *pl, const PcWork &w, const 
     float2 *const y[2] = {w.y[0], w.y[1]};
     int rc;
     if ((rc = xpower_stage(ctx, pl, rs, sa, sb, 4, y))) return rc;
-    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results, rs.k != nullptr))) return rc;
-    return inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, rs.k != nullptr);
+    static const char *envw = getenv("OIP_WINDOW_FFT");
+    const bool batched = !(envw && atoi(envw));
+    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[0], 2, d_results, rs.k != nullptr, 0, batched))) return rc;
+    if ((rc = inverse_and_peaks(ctx, pl, w, w.y[1], 2, d_results + 6, rs.k != nullptr, batched ? 1 : 0, batched))) return rc;
+    if (!batched) return OIP_OK;
+    double *const res[2] = {d_results, d_results + 6};
+    return peak_windows(ctx, pl, w, y, res, 2, 2);
 }
 
 // base image a against four images b0..b3: 3 forward + 2 inverse complex transforms
@@ -1833,10 +1863,16 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
             hipLaunchKernelGGL((corr_rows_up_kernel<512, false>), g, dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF, twS);
         OIP_HIP(ctx, hipGetLastError());
     }
+    // the inverse column passes of the outputs, each into its own slot set; one window launch for all of them
+    // (with OIP_WINDOW_FFT=1 every output still runs its own window passes: slot set 0 each time)
+    static const char *envw = getenv("OIP_WINDOW_FFT");
+    const bool batched = !(envw && atoi(envw));
+    double *res[4];
     for (int o = 0; o < narr; ++o) {
-        double *res = (o < 2 ? d_resA : d_resB) + 6 * (o & 1);
-        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[o], 2, res, true))) return rc;
+        res[o] = (o < 2 ? d_resA : d_resB) + 6 * (o & 1);
+        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[o], 2, res[o], true, batched ? o : 0, batched))) return rc;
     }
+    if (batched) return peak_windows(ctx, pl, w, w.y, res, narr, 2);
     return OIP_OK;
 }
 

@@ -251,14 +251,15 @@ inline void row_blocks(const oip_ctx *ctx, int gx, long h, long *rows_per_block,
 
 }  // namespace
 
-extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, long h, const double *d_kb)
+// The launcher proper, on an explicit stream and without touching the context's profiler or error-free state: the
+// staging layer (oip_rrc_u16_host) calls it from a second host thread on streams of its own while the first thread
+// drives kernels through ctx->stream.
+int oip_rrc_launch(oip_ctx *ctx, hipStream_t stream, const uint16_t *d_src, uint16_t *d_dst, int w, long h, const double *d_kb)
 {
-    OIP_CHECK_CTX(ctx);
     if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16: bad argument");
     if (h == 0) return OIP_OK;
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
     const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
-    OipProfScope prof(ctx, (w % 8 == 0 && (align & 15) == 0) ? "rrc_u16_flat_kernel" : "rrc_u16_kernel");
     if (w % 8 == 0 && (align & 15) == 0) {
         const int P = w / 8;
         long g = P, t = 64;
@@ -271,22 +272,31 @@ extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst,
         long gy = (nsuper + spb - 1) / spb;
         if (gy > 65535) { gy = 65535; spb = (nsuper + gy - 1) / gy; spb = (spb + kRowsInFlight - 1) / kRowsInFlight * kRowsInFlight; gy = (nsuper + spb - 1) / spb; }
         const long gx = (sr + kBlock - 1) / kBlock;
-        hipLaunchKernelGGL(rrc_u16_flat_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst,
+        hipLaunchKernelGGL(rrc_u16_flat_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, stream, d_src, d_dst,
                            P, nchunks, sr, a, kb, nsuper, spb);
     } else if (w % 4 == 0 && (align & 7) == 0) {
         int gx = (w / 4 + kBlock - 1) / kBlock, gy;
         long rpb;
         row_blocks(ctx, gx, h, &rpb, &gy);
-        hipLaunchKernelGGL(rrc_u16_kernel<4>, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, h, kb, rpb);
+        hipLaunchKernelGGL(rrc_u16_kernel<4>, dim3(gx, gy), dim3(kBlock), 0, stream, d_src, d_dst, w, h, kb, rpb);
     } else {
         long n = (long)w * h;
         long blocks = (n + kBlock - 1) / kBlock;
         long cap = (long)ctx->cu_count * 32;
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(rrc_u16_scalar_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_src, d_dst, w, n, kb);
+        hipLaunchKernelGGL(rrc_u16_scalar_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, d_src, d_dst, w, n, kb);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
+}
+
+extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, long h, const double *d_kb)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16: bad argument");
+    const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
+    OipProfScope prof(ctx, (w % 8 == 0 && (align & 15) == 0) ? "rrc_u16_flat_kernel" : "rrc_u16_kernel");
+    return oip_rrc_launch(ctx, ctx->stream, d_src, d_dst, w, h, d_kb);
 }
 
 extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16_t *d_planes, size_t plane_stride,

@@ -9,10 +9,19 @@
 //     HBM --DMA--> pinned slot --fwrite--> file
 //     pageable buffer --pool memcpy--> pinned slot --DMA--> HBM   (and back)
 // so disk, host copies, PCIe and the kernels of the context's compute stream overlap.  Staging calls
-// use only the staging stream and ring: they may run on a second host thread while the first one
-// drives kernels through the same context (two staging calls must not overlap each other).  A call
-// returns a TICKET; oip_stage_wait(ctx, ticket) makes the compute stream wait -- on the device, not the
+// use only staging streams and pinned slots of their own and never change the context's compute stream or
+// profiler: they may run on other host threads while the first one drives kernels through the same
+// context.  Three lanes, each serialised by its own mutex (a second caller of the same lane waits):
+//   ring lane      oip_read_file_to_device, oip_write_device_to_file, oip_upload_staged, oip_rrc_u16_host
+//                  (four pinned slots; stream `stream`, oip_rrc_u16_host also `rrc_stream`)
+//   download lane  oip_download_staged (two pinned slots, stream `stream2`)
+// so an upload thread and a download thread run full duplex.  The state is created once under a lock.
+// A call returns a TICKET; oip_stage_wait(ctx, ticket) makes the compute stream wait -- on the device, not the
 // host -- for the transfers up to that ticket, and oip_stage_sync(ctx) blocks the host until they are done.
+// Ordering against the compute stream: downloads and file writes start after the compute-stream work
+// enqueued before the call.  UPLOADS DO NOT WAIT for the compute stream (an uploader thread must keep the
+// link busy while a 60-ms correlation is queued): re-uploading into a buffer that queued kernels still read
+// is the caller's hazard -- call oip_stage_order_after_compute(ctx) first, or upload into another buffer.
 #include "oip_internal.h"
 
 #include <atomic>
@@ -105,7 +114,9 @@ constexpr int kTicketRing = 64;
 // the staging state lives behind the context (opaque to the other translation units)
 struct oip_stage_state {
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // second lane of oip_rrc_u16_host (up and down transfers of neighbouring blocks overlap)
+    hipStream_t stream2 = nullptr;          // the download lane's stream
+    hipStream_t rrc_stream = nullptr;       // second stream of oip_rrc_u16_host (up and down transfers of neighbouring blocks overlap)
+    std::mutex ring_mu, down_mu;            // one caller per lane at a time
     void *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t slot_free[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // recorded after the DMA that last used the slot
     bool slot_used[kSlots] = {false, false, false, false};
@@ -125,13 +136,17 @@ struct oip_stage_state {
     std::vector<double> kb_host;
 };
 
+static std::mutex g_stage_init_mu;
 static int stage_init(oip_ctx *ctx)
 {
+    // first staging calls may come from two threads at once: the state is created exactly once
+    std::lock_guard<std::mutex> once(g_stage_init_mu);
     if (ctx->stage) return OIP_OK;
     OIP_HIP(ctx, hipSetDevice(ctx->device));
     oip_stage_state *s = new oip_stage_state();
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
+        hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->rrc_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
     for (int i = 0; i < kSlots; ++i) {
         if (hipHostMalloc(&s->slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&s->slot_free[i], hipEventDisableTiming) != hipSuccess) {
@@ -159,6 +174,7 @@ void oip_stage_destroy(oip_ctx *ctx)
     if (!s) return;
     if (s->stream) hipStreamSynchronize(s->stream);
     if (s->stream2) { hipStreamSynchronize(s->stream2); hipStreamDestroy(s->stream2); }
+    if (s->rrc_stream) { hipStreamSynchronize(s->rrc_stream); hipStreamDestroy(s->rrc_stream); }
     for (int i = 0; i < kSlots; ++i) { if (s->slot[i]) hipHostFree(s->slot[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
     for (int i = 0; i < kTicketRing; ++i) hipEventDestroy(s->ticket_ev[i]);
     if (s->compute_ev) hipEventDestroy(s->compute_ev);
@@ -188,14 +204,23 @@ static long ticket_issue(oip_ctx *ctx, oip_stage_state *s)
     return t;
 }
 
-// uploads must see what the compute stream wrote before (and vice versa for downloads): the staging stream
-// waits for the compute stream's work enqueued so far
+// the ring lane's stream waits for the compute stream's work enqueued so far: file writes read what kernels
+// produced; uploads only on request (oip_stage_order_after_compute -- see the note at the top of the file)
 static int order_after_compute(oip_ctx *ctx, oip_stage_state *s)
 {
     hipEvent_t e = s->compute_ev;
     OIP_HIP(ctx, hipEventRecord(e, ctx->stream));
     OIP_HIP(ctx, hipStreamWaitEvent(s->stream, e, 0));
     return OIP_OK;
+}
+
+extern "C" int oip_stage_order_after_compute(oip_ctx *ctx)
+{
+    if (!ctx) return OIP_E_INVALID;
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lane(ctx->stage->ring_mu);
+    return order_after_compute(ctx, ctx->stage);
 }
 
 extern "C" int oip_stage_wait(oip_ctx *ctx, long ticket)
@@ -229,6 +254,7 @@ extern "C" int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t of
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->ring_mu);
     FILE *f = fopen(path, "rb");
     if (!f) return oip_fail(ctx, OIP_E_INVALID, "cannot open file [%s]: %d", path, errno);      // imageop.h:55-57
     if (bytes == 0) {                                                                            // all available (imageop.h:59-63)
@@ -275,6 +301,7 @@ extern "C" int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t 
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->ring_mu);
     FILE *f = fopen(path, append ? "ab" : "wb");
     if (!f) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);      // imageop.h:86-88
     if ((rc = order_after_compute(ctx, s))) { fclose(f); return rc; }
@@ -319,6 +346,7 @@ extern "C" int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, si
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->ring_mu);
     size_t done = 0;
     while (done < bytes) {
         int i;
@@ -343,6 +371,7 @@ extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, 
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->down_mu);
     // the download lane (see oip_stage_state): ordered after what the compute stream has enqueued so far
     OIP_HIP(ctx, hipEventRecord(s->down_compute_ev, ctx->stream));
     OIP_HIP(ctx, hipStreamWaitEvent(s->stream2, s->down_compute_ev, 0));
@@ -374,15 +403,17 @@ extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, 
 // the LUT is uploaded once per distinct table (cached), the host copies run on the persistent pool.
 extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb_host)
 {
-    OIP_CHECK_CTX(ctx);
+    if (!ctx) return OIP_E_INVALID;         // (no OIP_CHECK_CTX: the compute thread's profiler chain is not this call's to reset)
     if (w <= 0 || h < 0 || !buff || !kb_host) return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16_host: bad argument");
     if (h == 0) return OIP_OK;
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->ring_mu);
     OIP_HIP(ctx, hipSetDevice(ctx->device));
     if (s->kb_host.size() != (size_t)w * 2 || memcmp(s->kb_host.data(), kb_host, sizeof(double) * 2 * w) != 0) {
         OIP_HIP(ctx, hipStreamSynchronize(s->stream));
+        OIP_HIP(ctx, hipStreamSynchronize(s->rrc_stream));
         if (s->d_kb) OIP_HIP(ctx, hipFree(s->d_kb));
         s->d_kb = nullptr;
         OIP_HIP(ctx, hipMalloc((void **)&s->d_kb, (size_t)w * 16));
@@ -403,7 +434,6 @@ extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, con
         }
         ctx->stage_bytes = block;
     }
-    hipStream_t saved = ctx->stream;
     const long nchunks = (h + rows - 1) / rows;
     // per chunk: pinned slot up -> device block (slot c & 1) -> kernel -> same pinned slot down; the ring has four
     // pinned slots, so the host copies of chunk c+1 (in) and c-1 (out) run while chunk c is on the device
@@ -427,12 +457,10 @@ extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, con
         const size_t nb = (size_t)n * row_bytes;
         CopyPool::get().copy(s->slot[i], buff + r0 * (long)w, nb);
         void *d = ctx->d_stage[c & 1];
-        hipStream_t st = (c & 1) ? s->stream2 : s->stream;          // device block and stream alternate: neighbours overlap
+        hipStream_t st = (c & 1) ? s->rrc_stream : s->stream;       // device block and stream alternate: neighbours overlap
         if (hipMemcpyAsync(d, s->slot[i], nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "H2D failed"); break; }
-        ctx->stream = st;
-        rc = oip_rrc_u16(ctx, (uint16_t *)d, (uint16_t *)d, w, n, s->d_kb);
-        ctx->stream = saved;
-        if (rc != OIP_OK) break;
+        // explicit stream: the context's compute stream and profiler stay the compute thread's
+        if ((rc = oip_rrc_launch(ctx, st, (uint16_t *)d, (uint16_t *)d, w, n, s->d_kb)) != OIP_OK) break;
         if (hipMemcpyAsync(s->slot[i], d, nb, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H failed"); break; }
         hipEventRecord(s->slot_free[i], st);
         s->slot_used[i] = true;
@@ -440,8 +468,7 @@ extern "C" int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, con
         // bring home the chunk before this one while this one is on the device
         if (c >= 1 && (rc = drain((int)((c - 1) % 3)))) break;
     }
-    ctx->stream = saved;
     for (int k = 0; k < 3 && rc == OIP_OK; ++k) rc = drain(k);
-    if (rc != OIP_OK) { hipStreamSynchronize(s->stream); hipStreamSynchronize(s->stream2); }
+    if (rc != OIP_OK) { hipStreamSynchronize(s->stream); hipStreamSynchronize(s->rrc_stream); }
     return rc;
 }

@@ -21,8 +21,8 @@ RESP_TOL = 1e-4      # absolute, on the response
 # How many units each test's response mask (oracle response < 0.1 or < 0.05: no usable peak, the arg-max is decided by
 # rounding noise) may leave out of the SHIFT comparison -- the counts the synthetic scenes produce, asserted so that a
 # change which silently masks more units fails.  Responses are compared on every unit.
-MASKED = {"interband_small": 64, "12288_wide": 32, "reference_unit_shape": 12, "spectral_route_64": 12, "spectral_route_400": 12,
-          "straddling": 64}
+MASKED = {"interband_small": 11, "12288_wide": 0, "reference_unit_shape": 0, "spectral_route_64": 0, "spectral_route_400": 0,
+          "straddling": 2}          # measured on the MI355X (profiles/r03_parity_deltas.jsonl)
 
 
 def _cuda(a):

@@ -126,6 +126,61 @@ def test_rrc_host_buffer(ctx, oracle_mod):
     assert np.array_equal(buf, want)
 
 
+def test_staging_lanes_run_beside_the_compute_thread(ctx, oracle_mod):
+    """The threading contract of include/oip_c.h: while the first thread drives kernels (with the profiler on) and
+    downloads through the same context, a second thread runs oip_rrc_u16_host and a third uploads -- ring lane and
+    download lane on their own streams and locks, the compute stream and the profiler untouched by them.  Every result
+    must be exact and the profiler must have seen only the compute thread's launches."""
+    import threading
+    import torch
+    rng = _rng(16)
+    w, h = 4096, 12000
+    kb = _lut(rng, w)
+    imgs = [rng.integers(0, 4096, (h, w), dtype=np.uint16) for _ in range(3)]
+    wants = [oracle_mod.rrc(a, kb, threads=8) for a in imgs]
+    d_kb = ctx.upload_kb(kb)
+    d_src = _cuda(imgs[0]); d_dst = torch.empty_like(d_src)
+    d_up = torch.zeros(h, w, dtype=torch.uint16, device="cuda")
+    host_bufs = [imgs[1].copy(), imgs[1].copy()]
+    errors, tickets = [], []
+
+    def host_rrc():
+        try:
+            for b in host_bufs:
+                ctx.rrc_u16_host(b, kb)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    def uploader():
+        try:
+            for _ in range(2):
+                tickets.append(ctx.upload_staged(d_up, imgs[2], want_ticket=True))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    ctx.sync()
+    ctx.profile_reset(); ctx.profile_enable(True)
+    th = [threading.Thread(target=host_rrc), threading.Thread(target=uploader)]
+    [t.start() for t in th]
+    downs = []
+    for _ in range(6):
+        ctx.rrc_u16(d_src, d_dst, w, h, d_kb)
+        out = np.empty((h, w), np.uint16)
+        ctx.download_staged(out, d_dst)
+        downs.append(out)
+    [t.join() for t in th]
+    ctx.sync()
+    ctx.profile_enable(False)
+    prof = ctx.profile()
+    assert not errors, errors
+    for out in downs:
+        assert np.array_equal(out, wants[0])
+    for b in host_bufs:
+        assert np.array_equal(b, wants[1])
+    ctx.stage_wait(tickets[-1]); ctx.sync()
+    assert np.array_equal(_u16(d_up), imgs[2])
+    assert prof["rrc_u16_flat_kernel"][1] == 6, prof         # the staged RRC launches are not the compute thread's
+
+
 def test_rrc_idempotent_lut_full_size(ctx):
     """BASELINE config 2 size (30000 x 65536): k=1,b=0 is the identity, k=0,b=c a constant --
     size-independent properties, no oracle run at this size."""

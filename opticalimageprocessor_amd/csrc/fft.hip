@@ -694,10 +694,13 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 // Measured 0.128 -> 0.104 ms per launch (3.7 TB/s).  Walking several tile rows per workgroup with the next
 // tile's loads in flight (OIP_PEAK_TILES) changes nothing: what is left is the cost of reading 128-byte
 // segments 125 lines (3 MB) apart, the same 0.03-0.04 ms the first forward pass pays for its strided stores.
-__global__ __launch_bounds__(256) void fft_col128_peak_kernel(const float2 *__restrict__ data, OipFftPass p, OipFftIo io,
+template <int VS>
+__global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 *__restrict__ data, OipFftPass p, OipFftIo io,
                                                               const float2 *__restrict__ twF, const float2 *__restrict__ twT)
 {
-    constexpr int F = 128, V = 16, Vp = V + 1;
+    // VS = 4: 16 lanes (128-byte row segments), 256 threads; VS = 5: 32 lanes (256-byte segments), 512 threads.  Thread
+    // (q, v) = (tid >> VS, tid & (V - 1)), q < 16, owns the points q + 16 m of lane v either way.
+    constexpr int F = 128, V = 1 << VS, Vp = V + 1;
     __shared__ float2 buf[F * Vp];
     __shared__ float2 tw[32];
     __shared__ float2 twj[F];
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256) void fft_col128_peak_kernel(const float2 *__re
     const int rel = (int)(blockIdx.x & 7) * p.xcd_chunk + (int)(blockIdx.x >> 3);
     if (rel >= ltn) return;
     const int lt = p.lt0 + rel;
-    const int lane0 = lt << 4;
+    const int lane0 = lt << VS;
     const int nv = p.lanes - lane0 < V ? (int)(p.lanes - lane0) : V;
     const int v = threadIdx.x & (V - 1);
     const bool lane_ok = v < nv;
@@ -724,13 +727,13 @@ __global__ __launch_bounds__(256) void fft_col128_peak_kernel(const float2 *__re
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             x[m] = make_float2(0.f, 0.f);
-            if (lane_ok) x[m] = data[base + (long)((tid >> 4) + 16 * m) * p.nstride + v];
+            if (lane_ok) x[m] = data[base + (long)((tid >> VS) + 16 * m) * p.nstride + v];
         }
         if (tid < F) rtw = twT[(long)o * tid];
     };
     // inverse = conj(forward(conj(.))); the inter-pass twiddle of point n multiplies the conjugated input
     auto stage1 = [&](int tid) {
-        const int qq = tid >> 4;
+        const int qq = tid >> VS;
 #pragma unroll
         for (int m = 0; m < 8; ++m) x[m] = cmul(make_float2(x[m].x, -x[m].y), twj[qq + 16 * m]);
         bf8(x);
@@ -746,7 +749,7 @@ __global__ __launch_bounds__(256) void fft_col128_peak_kernel(const float2 *__re
     for (;;) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));           // per-iteration opaque copy: no loop-invariant stage addressing held in registers
-        const int qq = tid >> 4;
+        const int qq = tid >> VS;
         const int o1n = o1 + gridDim.y;
         const bool more = o1n < p.O1;
         if (more) fetch(o1n, tid);              // in flight under stages 2 and 3 and the scan of the current tile
@@ -1375,15 +1378,25 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
             }
     }
     // the register-staged peak pass for the 128-point inverse column pass (see the kernel)
-    if (blocks_override <= 0 && inverse && io.store_kind == 1 && p.mode == 0 && p.axis == 1 && p.F == 128 && p.vshift == 4 &&
+    if (blocks_override <= 0 && inverse && io.store_kind == 1 && p.mode == 0 && p.axis == 1 && p.F == 128 && (p.vshift == 4 || p.vshift == 5) &&
         p.tw_mode == 2 && p.grid3) {
         static const char *envk = getenv("OIP_PEAK_V2");                  // experiment knob: 0 = generic pass kernel
         if (!(envk && atoi(envk) == 0)) {
             static const char *envt = getenv("OIP_PEAK_TILES");             // experiment knob: tile rows per workgroup
             const int tiles = envt && atoi(envt) > 0 ? atoi(envt) : 1;      // measured: 0.104 / 0.106 / 0.106 / 0.110 ms for 1 / 2 / 3 / 5
             if (p.O2 != 1) return oip_fail(ctx, OIP_E_RUNTIME, "peak pass: the last inverse pass spans the whole axis");
+            // experiment knob: 32-lane tiles (256-byte row segments, 512 threads) for this pass alone, whatever the plan chose
+            static const char *envl = getenv("OIP_PEAK_LANES");
+            if (envl && atoi(envl) == 32 && p.vshift == 4 && p.ltn <= 0) {
+                p.vshift = 5;
+                p.Vp = 33;
+                p.lane_tiles = (int)((p.lanes + 31) >> 5);
+                p.xcd_chunk = (p.lane_tiles + 7) / 8;
+                grid3.x = (unsigned)(8 * p.xcd_chunk);
+            }
             grid3.y = (unsigned)((p.O1 + tiles - 1) / tiles);
-            hipLaunchKernelGGL(fft_col128_peak_kernel, grid3, dim3(256), 0, ctx->stream, data, p, io, twF, twT);
+            if (p.vshift == 4) hipLaunchKernelGGL(fft_col128_peak_kernel<4>, grid3, dim3(256), 0, ctx->stream, data, p, io, twF, twT);
+            else hipLaunchKernelGGL(fft_col128_peak_kernel<5>, grid3, dim3(512), 0, ctx->stream, data, p, io, twF, twT);
             OIP_HIP(ctx, hipGetLastError());
             return OIP_OK;
         }

@@ -328,7 +328,7 @@ public:
     }
     ~Node()
     {
-        for (auto c : comm) if (c) ncclCommDestroy(c);
+        if (!comms_aborted) for (auto c : comm) if (c) ncclCommDestroy(c);       // ncclCommAbort has already freed them otherwise
         for (auto c : ctx) if (c) oip_destroy(c);
     }
     hipStream_t stream(int r) { return (hipStream_t)oip_get_stream(ctx[r]); }
@@ -347,7 +347,13 @@ public:
         for (int r = 0; r < N; ++r)
             th.emplace_back([&, r] {
                 try { hipSetDevice(r); fn(r); }
-                catch (...) { ex[r] = std::current_exception(); failed = true; bar.abort(); }
+                catch (...) {
+                    // A rank that gives up after a pre-exchange barrier leaves its peers inside a grouped send/recv, blocked in
+                    // oip_sync on a kernel that waits for this rank for ever: setting a flag does not unblock a device-side wait.
+                    // Aborting every communicator makes those kernels exit, the peers' streams drain, their oip_sync returns
+                    // and they leave through sync_point(); the process then exits non-zero with this rank's message.
+                    ex[r] = std::current_exception(); failed = true; bar.abort(); abort_comms();
+                }
             });
         for (auto &t : th) t.join();
         // the rank that failed first tells why; the others only report that a peer gave up
@@ -363,6 +369,19 @@ public:
     void sync_point()
     {
         if (!bar.wait() || failed) throw PeerFailed();
+    }
+    void abort_comms()
+    {
+        bool expected = false;
+        if (comms_aborted.compare_exchange_strong(expected, true))
+            for (auto c : comm) if (c) ncclCommAbort(c);
+    }
+    // an RCCL call that fails is this rank's failure: raised at once (run() then aborts the communicators), never carried
+    // into a stream synchronisation that a peer may not be able to complete
+    void nccl_ok(ncclResult_t rc, const char *what)
+    {
+        if (rc != ncclSuccess) throw std::runtime_error(std::string(what) + " failed: " + ncclGetErrorString(rc));
+        if (failed) throw PeerFailed();
     }
 
     // exchange step 1: window pieces.  The holder packs the (lines x columns) sub-block contiguously and sends it,
@@ -402,10 +421,10 @@ public:
         }
         sync_point();
         if (!sends.empty() || !recvs.empty()) {
-            ncclGroupStart();
-            for (auto &s : sends) if (ncclSend(s.buf, s.bytes, ncclUint8, s.peer, comm[r], st) != ncclSuccess) failed = true;
-            for (auto &v : recvs) if (ncclRecv(v.buf, v.bytes, ncclUint8, v.peer, comm[r], st) != ncclSuccess) failed = true;
-            if (ncclGroupEnd() != ncclSuccess) failed = true;
+            nccl_ok(ncclGroupStart(), "ncclGroupStart");
+            for (auto &s : sends) nccl_ok(ncclSend(s.buf, s.bytes, ncclUint8, s.peer, comm[r], st), "ncclSend (window piece)");
+            for (auto &v : recvs) nccl_ok(ncclRecv(v.buf, v.bytes, ncclUint8, v.peer, comm[r], st), "ncclRecv (window piece)");
+            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
         }
         check(r, oip_sync(ctx[r]));
         for (void *t : temps) oip_free(ctx[r], t);
@@ -422,13 +441,13 @@ public:
         bool any = false;
         for (const LineTransfer &t : tr) any = any || t.src == r || t.dst == r;
         if (any) {
-            ncclGroupStart();
+            nccl_ok(ncclGroupStart(), "ncclGroupStart");
             for (const LineTransfer &t : tr)
                 for (int b = 0; b < planes; ++b) {
-                    if (t.src == r && ncclSend(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.dst, comm[r], st) != ncclSuccess) failed = true;
-                    if (t.dst == r && ncclRecv(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.src, comm[r], st) != ncclSuccess) failed = true;
+                    if (t.src == r) nccl_ok(ncclSend(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.dst, comm[r], st), "ncclSend (halo lines)");
+                    if (t.dst == r) nccl_ok(ncclRecv(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.src, comm[r], st), "ncclRecv (halo lines)");
                 }
-            if (ncclGroupEnd() != ncclSuccess) failed = true;
+            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
         }
         check(r, oip_sync(ctx[r]));
         sync_point();
@@ -445,7 +464,7 @@ public:
         check(r, oip_memcpy_h2d(ctx[r], d_send, table->data(), n * sizeof(double)));
         check(r, oip_sync(ctx[r]));
         sync_point();
-        if (ncclAllGather(d_send, d_recv, n, ncclDouble, comm[r], stream(r)) != ncclSuccess) failed = true;
+        nccl_ok(ncclAllGather(d_send, d_recv, n, ncclDouble, comm[r], stream(r)), "ncclAllGather");
         std::vector<double> all(n * N);
         check(r, oip_memcpy_d2h(ctx[r], all.data(), d_recv, n * N * sizeof(double)));
         check(r, oip_sync(ctx[r]));
@@ -463,6 +482,7 @@ public:
     std::vector<ncclComm_t> comm;
     std::vector<std::string> err;
     std::atomic<bool> failed{false};
+    std::atomic<bool> comms_aborted{false};
 };
 
 struct MultiGpuDefaultOptions {
@@ -516,9 +536,16 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
         ck(oip_malloc(c, (void **)&bil, (size_t)plan.mb * lineBytes));
         ck(oip_malloc(c, (void **)&planes, plane_stride * MSS_BANDS * 2));
         ck(oip_memset(c, planes, 0, plane_stride * MSS_BANDS * 2));
-        size_t got = 0;
-        ck(oip_read_file_to_device(c, panFile.c_str(), (size_t)r * plan.pb * lineBytes, (size_t)plan.pb * lineBytes, pan, &got, nullptr));
-        ck(oip_read_file_to_device(c, mssFile.c_str(), (size_t)r * plan.mb * lineBytes, (size_t)plan.mb * lineBytes, bil, &got, nullptr));
+        // a short read would leave uninitialised HBM under the correlation: the block must arrive whole (as DevBuf::load_file checks)
+        auto read_block = [&](const std::string &file, size_t offset, size_t bytes, void *dst) {
+            size_t got = 0;
+            ck(oip_read_file_to_device(c, file.c_str(), offset, bytes, dst, &got, nullptr));
+            if (got != bytes)
+                throw std::runtime_error("read file [" + file + "] failed: " + std::to_string(got) + " of " + std::to_string(bytes) +
+                                         " bytes at offset " + std::to_string(offset));
+        };
+        read_block(panFile, (size_t)r * plan.pb * lineBytes, (size_t)plan.pb * lineBytes, pan);
+        read_block(mssFile, (size_t)r * plan.mb * lineBytes, (size_t)plan.mb * lineBytes, bil);
         double *d_kb = nullptr;
         ck(oip_malloc(c, (void **)&d_kb, (size_t)W * 16));
         if (o.doRRC4PAN) {
@@ -661,9 +688,15 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
         const size_t blockBytes = (size_t)plan.pb * lineBytes;
         ck(oip_malloc(c, (void **)&p1, blockBytes));
         ck(oip_malloc(c, (void **)&p2, blockBytes));
-        size_t got = 0;
-        ck(oip_read_file_to_device(c, pan1.c_str(), (size_t)b0 * lineBytes, blockBytes, p1, &got, nullptr));
-        ck(oip_read_file_to_device(c, pan2.c_str(), (size_t)b0 * lineBytes, blockBytes, p2, &got, nullptr));
+        auto read_block = [&](const std::string &file, size_t offset, size_t bytes, void *dst) {
+            size_t got = 0;
+            ck(oip_read_file_to_device(c, file.c_str(), offset, bytes, dst, &got, nullptr));
+            if (got != bytes)
+                throw std::runtime_error("read file [" + file + "] failed: " + std::to_string(got) + " of " + std::to_string(bytes) +
+                                         " bytes at offset " + std::to_string(offset));
+        };
+        read_block(pan1, (size_t)b0 * lineBytes, blockBytes, p1);
+        read_block(pan2, (size_t)b0 * lineBytes, blockBytes, p2);
         ck(oip_sync(c));
         // exchange 1 + correlation on the RAW lines (App. B-1)
         const std::vector<int> mine = plan.units_of(r);

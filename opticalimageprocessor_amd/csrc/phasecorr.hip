@@ -1092,6 +1092,238 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
     }
 }
 
+// ---- row stage with the VERTICAL x4 up-sampling applied to the band spectra (padded row lengths) ---------------------
+//
+// The reference's own strips are 12288 pixels wide: ten slices of 1228 columns, band windows of 307, and
+// cv::phaseCorrelate pads the 1228-column images to 1250 (preproc.h:302-316).  1250 is not four times anything the
+// band window has, so the horizontal taps stay in the image domain -- but 16000 = 4 x 4000 still holds on the vertical
+// axis: cv::resize interpolates horizontally first (f32, reproduced exactly by hpack_bands_kernel on the 4000 band
+// rows), and the vertical operator V = C + E acts on those rows, so along a column
+//     DFT_M(V h)[ky] = Hv[ky] DFT_m(h)[ky mod m] + sum_i Gv_i[ky] h[J_i],       J = {0, 1, m-2, m-1}
+// exactly (corr_rows_up_kernel, VEXP).  The horizontally up-sampled bands of a pair of units are transformed at
+// their own height (four arrays bX + i bY side by side, m x 4N) and line ky of an up-sampled band's column transform
+// is rebuilt on the way into LDS.  Against the image-domain route a pair of units costs 2 array-sized forward column
+// transforms instead of 5, no vertical up-sampling kernel and one row-stage launch (5 spectra in, 4 out) instead of two
+// (3 in, 2 out each).
+//
+// LDS: five two-line buffers [PAN_A + i PAN_B | array 0 .. 3]; output o = C(PAN_u, band 2a) + i C(PAN_u, band 2a+1)
+// (arrays 0, 1: unit A = real slot of the PAN buffer; arrays 2, 3: unit B) overwrites array o's buffer in place -- the
+// thread of column kx is the only reader of bins (kx, ky) and (-kx, -ky).
+struct VRowsJob {
+    const float2 *zp;       // pitch P
+    const float2 *zn;       // m rows x four arrays, zn_stride elements apart, pitch Pn (column transforms done)
+    long zn_stride;
+    int Pn;
+    float2 *out[4];
+    int nout;               // 4, or 2 for a single unit (arrays 2 and 3 are neither read nor written)
+    int dbg;
+    const float2 *vtab;     // [5][M]: Hv, Gv_0 .. Gv_3
+    const float2 *raw;      // [4 rows][4 arrays][zn_stride]: (bX, bY) of the horizontally up-sampled band rows {0, 1, m-2, m-1}
+    const int *ypos_s;      // row position of frequency line k in zn, k in [0, m)
+    int m;
+};
+
+template <int F, int NT, int... Rs>
+__global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int P, const int *__restrict__ ypos,
+                                                         const float2 *__restrict__ twF)
+{
+    constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
+    constexpr int N = F, NARR = 5;
+    constexpr int NIT = (N + NT - 1) / NT;
+    static_assert(N % 2 == 0, "two points per lane");
+    constexpr int NIT2 = (N / 2 + NT - 1) / NT;
+    constexpr int NQ = 4 * (N / 2);                 // 16-byte pieces of one line of the four band arrays
+    constexpr int NITN = (NQ + NT - 1) / NT;
+    __shared__ __align__(16) float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
+    __shared__ float2 tw[TWN];
+    float4 *buf4 = reinterpret_cast<float4 *>(buf);
+    const int dbg = fj.dbg;
+    const int half = M / 2;
+    const int narr = fj.nout;                       // band arrays in use
+    int ky = blockIdx.x;
+    if (ky > half) return;
+    for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
+    float4 la[NIT2], lb[NIT2];
+    long n1 = ypos[ky], n2 = ypos[ky ? M - ky : 0];
+    long m1 = fj.ypos_s[ky % fj.m], m2 = fj.ypos_s[(ky ? M - ky : 0) % fj.m];
+    int kyc = ky;                                   // the frequency line whose PAN loads are in the registers
+    auto fetch = [&](int tid) {                     // the PAN line pair: prefetched one iteration ahead
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it) {
+            int q = tid + it * NT;
+            q = q < N / 2 ? q : N / 2 - 1;
+            la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
+            lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
+        }
+    };
+    auto commit = [&](int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it) {
+            const int q = tid + it * NT;
+            if (q < N / 2) {
+                buf4[2 * q] = make_float4(la[it].x, la[it].y, lb[it].x, lb[it].y);
+                buf4[2 * q + 1] = make_float4(la[it].z, la[it].w, lb[it].z, lb[it].w);
+            }
+        }
+        // The band lines, their coefficients and the raw rows are requested here (L2 / Infinity Cache hits: every line of
+        // a band transform serves four frequency lines, the raw rows serve all): line ky of the vertically up-sampled band
+        // pair is Hv[ky] zn[ky mod m] + sum_i Gv_i[ky] raw_i; Hv and Gv of line -ky are the conjugates.
+        float2 vt[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + kyc];
+#pragma unroll
+        for (int it = 0; it < NITN; ++it) {
+            const int q = tid + it * NT;
+            const int a = q / (N / 2), i = q - a * (N / 2);
+            if (q >= NQ || a >= narr) continue;
+            const float2 *z = fj.zn + a * fj.zn_stride + 2 * i;
+            const float4 na = *reinterpret_cast<const float4 *>(z + m1 * fj.Pn), nb = *reinterpret_cast<const float4 *>(z + m2 * fj.Pn);
+            float4 rw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rw[r] = *reinterpret_cast<const float4 *>(fj.raw + ((long)r * 4 + a) * fj.zn_stride + 2 * i);
+            const float2 hv = vt[0];
+            float2 x0 = oipfft::cmul(hv, make_float2(na.x, na.y)), x1 = oipfft::cmul(hv, make_float2(na.z, na.w));
+            float2 y0 = cmulj(hv, make_float2(nb.x, nb.y)), y1 = cmulj(hv, make_float2(nb.z, nb.w));
+            if (!(dbg & 32)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float2 gv = vt[1 + r];
+                    const float2 w0 = make_float2(rw[r].x, rw[r].y), w1 = make_float2(rw[r].z, rw[r].w);
+                    x0 = cfma(gv, w0, x0); x1 = cfma(gv, w1, x1);
+                    y0 = cfmaj(gv, w0, y0); y1 = cfmaj(gv, w1, y1);
+                }
+            }
+            buf4[(1 + a) * F + 2 * i] = make_float4(x0.x, x0.y, y0.x, y0.y);
+            buf4[(1 + a) * F + 2 * i + 1] = make_float4(x1.x, x1.y, y1.x, y1.y);
+        }
+    };
+    fetch(threadIdx.x);
+    commit(threadIdx.x);
+    long s1 = n1, s2 = n2;
+    __syncthreads();
+    for (; ky <= half; ky += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));               // per-iteration opaque copy: no stage addressing hoisted out of the loop
+        const bool pair = s1 != s2;
+        const int kn = ky + gridDim.x;
+        const bool more = kn <= half;
+        if (more && !(dbg & 8)) {
+            n1 = ypos[kn];
+            n2 = ypos[M - kn];
+            m1 = fj.ypos_s[kn % fj.m];
+            m2 = fj.ypos_s[(M - kn) % fj.m];
+            kyc = kn;
+            fetch(tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 1)) oipfft::StagesPipe<F, NT, NARR, 1, Rs...>::run(buf, tw, tid);
+#pragma unroll 1
+        for (int it = 0; it < NIT; ++it) {
+            const int kx = tid + it * NT;
+            if (kx >= N || (dbg & 2)) continue;
+            const int nkx = kx ? N - kx : 0;
+            const bool edge_col = (kx == 0) || (2 * kx == N);
+            const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
+            const float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
+            const float2 Aa = spec_of(0, zk0, zm0), Ab = spec_of(1, zk0, zm0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                if (a >= narr) continue;
+                float2 *b = buf + (1 + a) * 2 * F;
+                const float2 zk = b[2 * kx], zm = b[2 * nkx + 1];
+                const float2 A = a < 2 ? Aa : Ab;
+                const float2 C1 = cross_power_bin_fast(A, spec_of(0, zk, zm), real_bin, edge_col);
+                const float2 C2 = cross_power_bin_fast(A, spec_of(1, zk, zm), real_bin, edge_col);
+                // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
+                b[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                b[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(tid));
+        if (!(dbg & 4)) oipfft::StagesPipe<F, NT, 4, 1, Rs...>::run(buf + 2 * F, tw, tid);
+        float4 ya[4][NIT2], yb[4][NIT2];            // line ky / line -ky, two points each
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < N / 2) {
+                    const float4 u = buf4[(1 + o) * F + 2 * q], v = buf4[(1 + o) * F + 2 * q + 1];
+                    ya[o][it] = make_float4(u.x, -u.y, v.x, -v.y);
+                    yb[o][it] = make_float4(u.z, -u.w, v.z, -v.w);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) commit(tid);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 16)) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o >= narr) continue;
+                float2 *out = fj.out[o];
+#pragma unroll
+                for (int it = 0; it < NIT2; ++it) {
+                    const int q = tid + it * NT;
+                    if (q < N / 2) {
+                        *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = ya[o][it];
+                        if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = yb[o][it];
+                    }
+                }
+            }
+        }
+        s1 = n1; s2 = n2;
+        __syncthreads();
+    }
+}
+
+// Horizontal half of cv::resize(INTER_CUBIC) x4 on the u16 band windows of a launch (HResizeCubic: four taps, edge
+// replicated, every product and sum a separate f32 rounding -- the order of resize_cubic_kernel), packed two bands per
+// complex value: array a = H(bX) + i H(bY) occupies columns [a stride, a stride + cols) of an m x (4 stride) array of
+// pitch Pn, columns [cols, stride) zero (cv::phaseCorrelate's right padding); rows {0, 1, m-2, m-1} also go to
+// raw[r][a][x] for the vertical operator's edge terms.
+struct HPackJob {
+    const uint16_t *bx[4], *by[4];
+    long pitch[4];
+};
+__global__ __launch_bounds__(128) void hpack_bands_kernel(HPackJob job, int m, int n, int cols, int stride, int Pn, const int *__restrict__ xofs,
+                                                          const float4 *__restrict__ alpha, float2 *__restrict__ z, float2 *__restrict__ raw)
+{
+    const int x = blockIdx.x * 128 + threadIdx.x;
+    const int a = blockIdx.z;
+    if (x >= stride) return;
+    const bool in = x < cols;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) {
+        const int sx = xofs[x];
+        w = alpha[x];
+        c0 = sx - 1; c1 = sx; c2 = sx + 1; c3 = sx + 2;
+        c0 = c0 < 0 ? 0 : (c0 > n - 1 ? n - 1 : c0);
+        c1 = c1 < 0 ? 0 : (c1 > n - 1 ? n - 1 : c1);
+        c2 = c2 < 0 ? 0 : (c2 > n - 1 ? n - 1 : c2);
+        c3 = c3 < 0 ? 0 : (c3 > n - 1 ? n - 1 : c3);
+    }
+    const uint16_t *bx = job.bx[a], *by = job.by[a];
+    const long pitch = job.pitch[a];
+    auto taps = [&](const uint16_t *S) {
+        float v = __fmul_rn((float)S[c0], w.x);
+        v = __fadd_rn(v, __fmul_rn((float)S[c1], w.y));
+        v = __fadd_rn(v, __fmul_rn((float)S[c2], w.z));
+        v = __fadd_rn(v, __fmul_rn((float)S[c3], w.w));
+        return v;
+    };
+#pragma unroll 2
+    for (int y = blockIdx.y; y < m; y += gridDim.y) {
+        float2 v = make_float2(0.f, 0.f);
+        if (in) v = make_float2(taps(bx + y * pitch), taps(by + y * pitch));
+        z[(long)y * Pn + (long)a * stride + x] = v;
+        const int r = y < 2 ? y : (y >= m - 2 ? y - (m - 4) : -1);
+        if (r >= 0) raw[((long)r * 4 + a) * stride + x] = v;
+    }
+}
+
 struct FusedRow {
     int F, threads, fwd_threads;
     void (*fwd1)(FusedJob, int, int, const int *, const float2 *);        // one spectrum -> one output
@@ -1252,6 +1484,7 @@ OipAxisDigits digits_of(const std::vector<int> &f, int L)
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline bool smooth_len(long n) { for (int p : {2, 3, 5}) while (n % p == 0) n /= p; return n == 1; }
 
 // Workspace carve-up for one correlation unit
 struct PcWork {
@@ -1749,6 +1982,8 @@ struct UpPath {
     const OipFft2dPlan *narrow;     // M x band_cols (vertical taps in the image domain), or
     const OipFft2dPlan *small;      // band_rows x (4 band_cols): both axes on the spectra (vtab set)
     const float2 *xtab, *vtab;
+    bool vonly;                     // padded row lengths (1228 -> 1250): horizontal taps in the image domain, vertical axis on
+                                    // the spectra (corr_rows_v_kernel); small = band_rows x (4 N)
 };
 
 // The band windows of a launch as one complex array: array a = bX + i bY occupies columns [n a, n a + n) of an
@@ -1874,6 +2109,70 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
     }
     if (batched) return peak_windows(ctx, pl, w, w.y, res, narr, 2);
     return OIP_OK;
+}
+
+// A pair of units (or one) of a padded geometry -- the reference's 12288-wide strips: 1228-column slices, 1250-point
+// rows -- with the vertical up-sampling on the spectra (corr_rows_v_kernel): one full-height forward column transform
+// (PAN_A + i PAN_B), the horizontally up-sampled bands transformed at their own height (four arrays side by side), one
+// row-stage launch, four inverse column transforms.
+int correlate_units_vup(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, const PcWork &w, const OipResizeTab *tab, RealSrc aA, RealSrc aB,
+                        const IbUnit *const *units, int nunits, int rows, int cols, int band_rows, int band_cols, double *d_resA, double *d_resB)
+{
+    int rc;
+    if ((rc = forward_packed(ctx, pl, w.z[0], aA, nunits > 1 ? aB : src_none(), rows, cols, true))) return rc;
+    const int narr = 2 * nunits;
+    const int N = pl->N, Pn = up.small->P;
+    // z[1] holds the m x (4 N) band array and, behind it, the four raw rows of the four arrays
+    float2 *zn = w.z[1];
+    float2 *raw = zn + (long)up.small->M * Pn;
+    if ((long)up.small->M * Pn + 16L * N > (long)pl->M * pl->P) return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: band array exceeds its slot");
+    HPackJob hj;
+    for (int a = 0; a < 4; ++a) {
+        const IbUnit *u = units[(a < narr ? a : 0) / 2];
+        hj.bx[a] = u->band[2 * (a & 1)]; hj.by[a] = u->band[2 * (a & 1) + 1]; hj.pitch[a] = u->band_pitch;
+    }
+    {
+        OipProfScope prof(ctx, "hpack_bands_kernel");
+        const int gy = band_rows < 256 ? band_rows : 256;
+        hipLaunchKernelGGL(hpack_bands_kernel, dim3((N + 127) / 128, gy, 4), dim3(128), 0, ctx->stream, hj, band_rows, band_cols, cols, N, Pn, tab->d_xofs,
+                           reinterpret_cast<const float4 *>(tab->d_alpha), zn, raw);
+        OIP_HIP(ctx, hipGetLastError());
+    }
+    ctx->prof_tag = "_band";
+    rc = oip_fft2d_exec(ctx, up.small, zn, 0, nullptr, 1);
+    ctx->prof_tag = nullptr;
+    if (rc) return rc;
+    const float2 *twF;
+    if ((rc = oip_fft_table(ctx, N, &twF))) return rc;
+    VRowsJob fj;
+    memset(&fj, 0, sizeof fj);
+    fj.zp = w.z[0];
+    fj.zn = zn;
+    fj.zn_stride = N;
+    fj.Pn = Pn;
+    for (int o = 0; o < 4; ++o) fj.out[o] = w.y[o];
+    fj.nout = narr;
+    fj.vtab = up.vtab;
+    fj.raw = raw;
+    fj.ypos_s = up.small->d_ypos;
+    fj.m = band_rows;
+    { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
+    {
+        OipProfScope prof(ctx, "corr_rows_v_kernel");
+        long grid = ctx->cu_count;
+        if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
+        if (N == 1250)
+            hipLaunchKernelGGL((corr_rows_v_kernel<1250, 512, 5, 5, 5, 5, 2>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF);
+        else
+            return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: no row stage for %d-point rows", N);
+        OIP_HIP(ctx, hipGetLastError());
+    }
+    double *res[4];
+    for (int o = 0; o < narr; ++o) {
+        res[o] = (o < 2 ? d_resA : d_resB) + 6 * (o & 1);
+        if ((rc = inverse_and_peaks(ctx, pl, w, w.y[o], 2, res[o], true, o, true))) return rc;
+    }
+    return peak_windows(ctx, pl, w, w.y, res, narr, 2);
 }
 
 int fetch_results(oip_ctx *ctx, int count, double *host_out)
@@ -2012,7 +2311,7 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     // 3000 columns, on the band spectra in the row stage (corr_rows_up_kernel; OIP_SPECTRAL_UP=0 keeps the loader).
     const OipResizeTab *tab = nullptr;
     if ((rc = resize_tables(ctx, band_cols, band_rows, cols, rows, &tab))) return rc;
-    UpPath up{nullptr, nullptr, nullptr, nullptr};
+    UpPath up{nullptr, nullptr, nullptr, nullptr, false};
     {
         // OIP_SPECTRAL_UP: 0 = image domain, 1 = horizontal axis on the spectra, 2 (default) = both axes
         const char *e = getenv("OIP_SPECTRAL_UP");
@@ -2028,9 +2327,23 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
                 if (up.vtab && (rc = oip_fft2d_plan(ctx, band_rows, cols, &up.small))) return rc;      // four arrays side by side
             }
         }
+        // the reference's own 12288-wide strips: 1228-column slices padded to 1250-point rows.  The horizontal taps stay in
+        // the image domain (1250 is not 4 x the band width); the vertical axis (16000 = 4 x 4000) goes to the spectra
+        // (corr_rows_v_kernel).  OIP_SPECTRAL_V=0 keeps the image-domain route.
+        const char *ev = getenv("OIP_SPECTRAL_V");
+        if (!up.xtab && !(ev && atoi(ev) == 0) && want > 0 && rows == 4 * band_rows && cols == 4 * band_cols && M == rows && N == 1250 &&
+            (cols & 1) == 0 && row_stage(pl).level == 2 && optimal_dft_size(band_rows) == band_rows && band_rows >= 8 && smooth_len(4 * N)) {
+            if ((rc = upsample_spectrum_tables(ctx, tab, 1, &up.vtab))) return rc;
+            if (up.vtab) {
+                if ((rc = oip_fft2d_plan(ctx, band_rows, 4 * N, &up.small))) return rc;
+                up.vonly = (long)up.small->M * up.small->P + 16L * N <= (long)pl->M * pl->P;
+                if (!up.vonly) up.vtab = nullptr;
+            }
+        }
     }
     PcWork w;
-    if ((rc = carve(ctx, pl, rows, band_cols, 0, up.xtab ? 2 : 5, up.xtab ? 4 : 2, 8, &w))) return rc;      // f32 scratch: the V images
+    const bool spectral = up.xtab || up.vonly;
+    if ((rc = carve(ctx, pl, rows, band_cols, 0, spectral ? 2 : 5, spectral ? 4 : 2, 8, &w))) return rc;      // f32 scratch: the V images
     if ((rc = oip_small(ctx, sizeof(double) * 12 * (size_t)(n > 0 ? n : 1)))) return rc;
     double *d_res = (double *)ctx->d_small;
     // vertical passes of all bands of one or two units in one launch
@@ -2050,6 +2363,11 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     for (; k + 1 < n; k += 2) {
         const IbUnit &A = units[k], &B = units[k + 1];
         const IbUnit *two[2] = {&A, &B};
+        if (up.vonly) {
+            if ((rc = correlate_units_vup(ctx, pl, up, w, tab, src_u16(A.pan, A.pan_pitch), src_u16(B.pan, B.pan_pitch), two, 2, rows, cols, band_rows,
+                                          band_cols, d_res + 12 * k, d_res + 12 * (k + 1)))) return rc;
+            continue;
+        }
         if (!up.vtab && (rc = upsample(two, 2, w.fb, sAB))) return rc;
         if (up.xtab) {
             if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_u16(B.pan, B.pan_pitch), sAB, two, 2, rows, cols, band_rows,
@@ -2063,6 +2381,10 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
     if (k < n) {
         const IbUnit &A = units[k];
         const IbUnit *one[1] = {&A};
+        if (up.vonly) {
+            if ((rc = correlate_units_vup(ctx, pl, up, w, tab, src_u16(A.pan, A.pan_pitch), src_none(), one, 1, rows, cols, band_rows, band_cols,
+                                          d_res + 12 * k, nullptr))) return rc;
+        } else {
         if (!up.vtab && (rc = upsample(one, 1, w.fb, sAB))) return rc;
         if (up.xtab) {
             if ((rc = correlate_units_up(ctx, pl, up, w, src_u16(A.pan, A.pan_pitch), src_none(), sAB, one, 1, rows, cols, band_rows, band_cols,
@@ -2070,6 +2392,7 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
         } else {
             const HTaps vt{band_cols, tab->d_xofs, tab->d_alpha, tab->x4h};
             if ((rc = correlate_one_to_four(ctx, pl, w, src_u16(A.pan, A.pan_pitch), sAB, rows, cols, d_res + 12 * k, &vt))) return rc;
+        }
         }
     }
     if (n > 0 && (rc = fetch_results(ctx, 12 * n, host_out))) return rc;

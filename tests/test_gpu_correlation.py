@@ -310,6 +310,50 @@ def test_interband_12288_wide_shape_matches_oracle(ctx, oracle_mod, parity_log):
     _interband_vs_oracle(ctx, parity_log, 4000, 9824, 8, 1, 4000, MASKED["12288_wide"])
 
 
+def test_vertical_spectral_route_of_the_12288_geometry(ctx, oracle_mod, parity_log):
+    """1228-column units (the reference's 12288-wide strips, 1250-point padded rows): the horizontal taps run in the image
+    domain on the band rows, the vertical x4 up-sampling is applied to the column transforms of the bands
+    (corr_rows_v_kernel).  OIP_SPECTRAL_V=0 keeps the image-domain route (vertical kernel + FFT loader): the two routes
+    against each other (rounding only) and the default against the oracle, which up-samples the image first -- on a pair
+    plus a single unit at 64 and 400 lines, and on a pair at the full 16000 lines (oracle on the second unit)."""
+    import os
+    from oracle import phasecorr as pc
+    for rows, nun, check in ((64, 3, (0, 1, 2)), (400, 3, (0, 1, 2)), (16000, 2, (1,))):
+        W = 1228 * nun
+        pan, bands = _synth.pan_mss(rows, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=7 + rows % 5)
+        dpan, dplanes = _cuda(pan), [_cuda(b) for b in bands]
+        pp = [dpan[:, 1228 * u:] for u in range(nun)]
+        bp = [[dplanes[b][:, 307 * u:] for b in range(4)] for u in range(nun)]
+        try:
+            os.environ["OIP_SPECTRAL_V"] = "0"
+            image = ctx.interband_correlate_units(pp, [W] * nun, bp, [W // 4] * nun, rows, 1228)
+        finally:
+            os.environ.pop("OIP_SPECTRAL_V", None)
+        got = ctx.interband_correlate_units(pp, [W] * nun, bp, [W // 4] * nun, rows, 1228)
+        assert np.isfinite(got).all()
+        d = np.abs(got - image)
+        assert d[..., :2].max() < 1e-4 and d[..., 2].max() < 1e-4, (rows, d.max(axis=(0, 1)))
+        assert d.max() > 0, "two routes gave identical bits: the switch did not switch"
+        worst_s = worst_r = 0.0
+        masked = 0
+        for u in check:
+            a = oracle_mod.window_u16_to_f32(pan, 0, 1228 * u, rows, 1228)
+            for b in range(4):
+                small = oracle_mod.window_u16_to_f32(bands[b], 0, 307 * u, rows // 4, 307)
+                (wdx, wdy), wr = pc.phase_correlate(a, oracle_mod.resize_cubic(small, 1228, rows))
+                gdx, gdy, gr = got[u, b]
+                worst_r = max(worst_r, abs(gr - wr))
+                assert abs(gr - wr) < RESP_TOL, (rows, u, b, gr, wr)
+                if wr >= 0.05:
+                    worst_s = max(worst_s, abs(gdx - wdx), abs(gdy - wdy))
+                    assert abs(gdx - wdx) < SHIFT_TOL and abs(gdy - wdy) < SHIFT_TOL, (rows, u, b, (gdx, gdy), (wdx, wdy))
+                else:
+                    masked += 1
+        parity_log(rows=rows, shift_px=worst_s, response=worst_r, units=4 * len(check), masked_out=masked,
+                   routes_px=float(d[..., :2].max()), shift_bar=SHIFT_TOL, response_bar=RESP_TOL)
+        assert masked <= 4 * len(check) // 2
+
+
 def test_vertical_upsampling_kernels_agree(ctx):
     """the sliding-window x4 vertical kernel and the generic one feed the FFT identical images: the whole
     correlation table must come out bit for bit the same"""

@@ -58,6 +58,10 @@ def parse():
                          "PreStitch remap + RAW stitch of two CCD segments")
     ap.add_argument("--fp16-accumulate", action="store_true",
                     help="prestitch: the fp16-accumulate resampling variant (not the parity mode)")
+    ap.add_argument("--fused", action="store_true",
+                    help="prestitch: RRC of CCD 1 and the resampled CCD-2 lines written straight into the stitched raster "
+                         "(oip_rrc_u16_window + oip_remap_shift_bicubic_u16_window; same stitched bits, .RRC.RAW of CCD 1 and "
+                         ".RRC.PRESTT.RAW not materialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive pass from pageable host buffers")
     ap.add_argument("--no-configs", action="store_true",
@@ -104,6 +108,7 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         "remap_shift8_kernel": 4.0 * W * pb,
         "remap_shift8_f16_kernel": 4.0 * W * pb,
         "stitch_rows_kernel": 4.0 * 2 * (W - 100) * pb,       # 2 B read + 2 B written per output pixel
+        "rrc_u16_window_kernel": 4.0 * (W - 100) * pb,        # the left half of the stitched raster straight from raw CCD 1
     }
     return d
 
@@ -428,14 +433,16 @@ def build_workload(env, p):
         def step():
             # main.cpp:270-286 then :177-190: correlation on the raw strips, RRC of both, remap of CCD 2, stitch
             dx, dy, _ = prestitch_stitch_step(backend, cplan, cbufs, d_kb_pan, d_kb2, prestt, stitched, rank,
-                                              threshold=p.threshold, f16acc=p.fp16)
+                                              threshold=p.threshold, f16acc=p.fp16, fused=getattr(p, "fused", False))
             info["dx"], info["dy"] = dx, dy
         d.__dict__.update(step=step, pix_per_rank=2 * W * pb, base_rows=16000, base_cols=OV, M=16000, N=OV, out_local=0,
                           rows_arrays=2.0, prestt=prestt, stitched=stitched, sections=nsec,
                           workload=("prestitch + stitch: 2 CCD segments %dx%d%s, %d x (16000x%d) phase correlations, RRC x2, "
-                                    "constant-shift bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d" %
+                                    "constant-shift bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d%s" %
                                     (W, Lp, " in %d scan-line blocks" % world if world > 1 else "", nsec, OV,
-                                     "fp16" if p.fp16 else "fp32", cplan.fold)))
+                                     "fp16" if p.fp16 else "fp32", cplan.fold,
+                                     "; FUSED: RRC of CCD 1 and the resampled CCD-2 lines written straight into the stitched raster"
+                                     if getattr(p, "fused", False) else "")))
     elif p.workload == "rrc":
         raw_pan = synth.pan_strip(rank * pb, pb, W, kb_pan, device=dev)
         dst = torch.empty_like(raw_pan)
@@ -627,6 +634,21 @@ def config_legs(env, args, line):
                                  "tolerance_asserted_DN": 6, "where": "tests/test_gpu_resample.py::test_remap_f16acc_tolerance"}}
     leg("config5_n1_prestitch_2x30000x100000_fp16acc", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold, fp16=True),
         extra=delta)
+    keep["stitched32"] = None
+
+    def grab_st(d):
+        keep["stitched32"] = d.stitched.clone()
+        return {}
+    leg("config5_n1_prestitch_2x30000x100000_fp32_unfused_again", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold,
+                                                                         fp16=False), steps=2, extra=grab_st)
+    out.pop("config5_n1_prestitch_2x30000x100000_fp32_unfused_again")
+
+    def same(d):
+        ok = bool(torch.equal(keep["stitched32"].view(torch.int16), d.stitched.view(torch.int16)))
+        keep.clear()
+        return {"stitched_equals_the_three_pass_flow": ok}
+    leg("config5_n1_prestitch_2x30000x100000_fp32_fused", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold,
+                                                                 fp16=False, fused=True), extra=same)
     keep.clear()
     leg("reference_geometry_12288x100000", Params(workload="default", width=12288, lines=100000, slices=10, sections=5, threshold=args.ibc_threshold, fp16=False),
         cpu=lambda: cpu_baseline(12288, 100000, 10, 5))
@@ -679,7 +701,7 @@ def main():
     env = Params(torch=torch, dist=dist, synth=synth, ctx=ctx, dev=dev, rank=rank, world=world, barrier=barrier,
                  dist_backend=dist_backend)
     p = Params(workload=args.workload, width=args.width, lines=args.lines, slices=args.slices, sections=args.sections,
-               threshold=args.ibc_threshold, fp16=args.fp16_accumulate)
+               threshold=args.ibc_threshold, fp16=args.fp16_accumulate, fused=args.fused)
     d = build_workload(env, p)
     elapsed, prof_all, prof, dom = measure(env, d, args.steps, args.warmup)
 

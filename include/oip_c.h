@@ -92,6 +92,13 @@ int oip_load_rrc_param_file(const char *path, int expected_lines, double *kb_out
 int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst, int w, long h,
                 const double *d_kb);
 
+/* The same seam on a WINDOW: columns [0, w) of h lines of a raster of pitch src_pitch, written to a raster of pitch
+ * dst_pitch (pitches in pixels; d_kb: the w (k,b) pairs of the window's columns).  With dst = the stitched raster
+ * (pitch 2 (W - fold), w = W - fold) this is the left half of IMO::StitchBigRaw's output line (imageop.h:340-351)
+ * taken straight from the raw CCD-1 strip: prestitch -> stitch without materialising <pan1>.RRC.RAW. */
+int oip_rrc_u16_window(oip_ctx *ctx, const uint16_t *d_src, long src_pitch, uint16_t *d_dst, long dst_pitch,
+                       int w, long h, const double *d_kb);
+
 /* Host-buffer form of the same seam: `buff` is the reference's heap buffer, corrected in
  * place through pinned, double-buffered line blocks (H2D || kernel || D2H). */
 int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *kb);
@@ -237,6 +244,16 @@ int oip_remap_shift_bicubic_u16_f16acc(oip_ctx *ctx, const uint16_t *d_src, long
                                        long src_rows, uint16_t *d_dst, long out_row0, long out_rows,
                                        int W, long L, double dx, double dy, int section_rows,
                                        int row_guard);
+/* The same resampling written into a WINDOW of another raster: column x >= dst_col0 of output line r goes to
+ * d_dst[r * dst_pitch + dst_col_off + (x - dst_col0)], columns below dst_col0 are not stored (d_dst: first output line
+ * of the destination raster, dst_pitch in pixels).  With dst_pitch = 2 (W - fold), dst_col0 = fold, dst_col_off = W - fold
+ * the resampled CCD-2 line lands in the right half of IMO::StitchBigRaw's output line (imageop.h:340-351): prestitch ->
+ * stitch without materialising .RRC.PRESTT.RAW (the fused single-pass pipeline of DOC/sample-task.sh; `oip task`).
+ * f16acc != 0 selects the fp16-accumulate variant.  Pixels are those of the two plain calls, bit for bit. */
+int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows,
+                                       uint16_t *d_dst, long dst_pitch, int dst_col0, long dst_col_off,
+                                       long out_row0, long out_rows, int W, long L, double dx, double dy,
+                                       int section_rows, int row_guard, int f16acc);
 /* source lines [first, last) that output lines [out_row0, out_row0+out_rows) read: the halo
  * a row-block shard has to hold (host arithmetic only) */
 int oip_remap_shift_src_range(long out_row0, long out_rows, long L, double dy,

@@ -60,6 +60,7 @@ _SIGS = {
     "oip_host_free": ([_vp, _vp], _i),
     "oip_load_rrc_param_file": ([_cp, _i, _dp, _cp, _i], _i),
     "oip_rrc_u16": ([_vp, _vp, _vp, _i, _l, _vp], _i),
+    "oip_rrc_u16_window": ([_vp, _vp, _l, _vp, _l, _i, _l, _vp], _i),
     "oip_rrc_u16_host": ([_vp, _vp, _i, _l, _dp], _i),
     "oip_read_file_to_device": ([_vp, _cp, _sz, _sz, _vp, C.POINTER(_sz), _lp], _i),
     "oip_write_device_to_file": ([_vp, _vp, _sz, _cp, _i], _i),
@@ -85,6 +86,7 @@ _SIGS = {
     "oip_upsample_operator": ([_i, C.POINTER(C.c_float)], _i),
     "oip_remap_shift_bicubic_u16": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_bicubic_u16_f16acc": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
+    "oip_remap_shift_bicubic_u16_window": ([_vp, _vp, _l, _l, _vp, _l, _i, _l, _l, _l, _i, _l, _d, _d, _i, _i, _i], _i),
     "oip_remap_shift_src_range": ([_l, _l, _l, _d, _i, _lp, _lp], _i),
     "oip_align_mss_bicubic_u16x4": ([_vp, _vp, _sz, _l, _l, _vp, _l, _l, _i, _l, _dp, _dp, _i, _i, _i, _i, _i, _lp], _i),
     "oip_align_mss_src_range": ([_l, _l, _l, _dp, _i, _i, _i, _i, _i, _i, _lp, _lp], _i),
@@ -271,6 +273,10 @@ class Context:
     def rrc_u16(self, src, dst, w, h, d_kb):
         self._ck(self.lib.oip_rrc_u16(self.h, _ptr(src), _ptr(dst), w, h, _ptr(d_kb)))
 
+    def rrc_u16_window(self, src, src_pitch, dst, dst_pitch, w, h, d_kb):
+        """RRC of columns [0, w) of h lines (pitches in pixels): e.g. straight into the left half of a stitched raster"""
+        self._ck(self.lib.oip_rrc_u16_window(self.h, _ptr(src), src_pitch, _ptr(dst), dst_pitch, w, h, _ptr(d_kb)))
+
     def rrc_u16_host(self, buff: np.ndarray, kb):
         assert buff.dtype == np.uint16 and buff.flags.c_contiguous and buff.ndim == 2
         kb = _dbl(kb, buff.shape[1] * 2)
@@ -369,6 +375,15 @@ class Context:
         fn = self.lib.oip_remap_shift_bicubic_u16_f16acc if f16acc else self.lib.oip_remap_shift_bicubic_u16
         self._ck(fn(self.h, _ptr(src), src_row0, src_rows, _ptr(dst), out_row0, out_rows, W, L, dx, dy,
                     section_rows, row_guard))
+
+    def remap_shift_bicubic_u16_window(self, src, dst, dst_pitch, dst_col0, dst_col_off, W, L, dx, dy, section_rows=30000,
+                                       row_guard=32767, src_row0=0, src_rows=None, out_row0=0, out_rows=None, f16acc=False):
+        """the same resampling written into a window of another raster (columns >= dst_col0 only; see include/oip_c.h)"""
+        src_rows = L if src_rows is None else src_rows
+        out_rows = L if out_rows is None else out_rows
+        self._ck(self.lib.oip_remap_shift_bicubic_u16_window(self.h, _ptr(src), src_row0, src_rows, _ptr(dst), dst_pitch, dst_col0,
+                                                             dst_col_off, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard,
+                                                             1 if f16acc else 0))
 
     def align_mss_bicubic_u16x4(self, planes, plane_stride, dst, Wb, Lm, cx, cy, lines_per_section=20000,
                                 line_offset=0, overlap=520, keep_leading=False, min_lines=1500,

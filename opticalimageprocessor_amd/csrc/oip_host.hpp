@@ -764,6 +764,7 @@ struct TaskOptions {
     bool keepLeading = false;
     int fitMode = OIP_FIT_REFERENCE;
     bool fp16acc = false;
+    bool panOnly = false;       // stitched PAN product only: fused RRC / resampling straight into the stitched raster
 };
 
 inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const std::string &rrc1, const std::string &rrc2,
@@ -783,7 +784,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
     if (L < (long)o.sections * o.sectionLines)
         throw std::invalid_argument("PAN line count less than sections times line-per-section, use smaller -s and/or -l value(s)");
     const size_t npx = (size_t)W * L;
-    DevBuf<uint16_t> p1(npx), p2(npx), p2s(npx);
+    DevBuf<uint16_t> p1(npx), p2(npx), p2s;
     p1.load_file(pan1, npx);
     p2.load_file(pan2, npx);
     // CalcSttParameters on the raw strips (App. B-1), same filter and mean as stitcher.h:181-198
@@ -795,6 +796,33 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         throw std::runtime_error("No valid delta value found for stitching parameter calculating");
     OLOG("Total %d valid delta value pairs found, everage value:", valid);
     OLOG("    dx: %.5f, dy: %.5f, r: %.5f", dx, dy, resp);
+    if (o.panOnly) {
+        // stitched PAN alone: no corrected strip is needed afterwards, so the left half of every stitched line is the RRC of
+        // the raw CCD-1 line (oip_rrc_u16_window) and the right half the resampled CCD-2 line (oip_remap_shift_bicubic_u16_window
+        // on the corrected CCD 2): <pan1>.RRC.RAW and .RRC.PRESTT.RAW are never materialised.  Same bits as the flow below.
+        const int fold = o.foldColsPAN / 2;
+        if (fold < 0 || fold >= W) throw std::invalid_argument("fold columns exceed the image width");
+        const long ow = 2L * (W - fold);
+        const size_t nout = (size_t)ow * L;
+        DevBuf<uint16_t> st(nout);
+        DevBuf<double> kb((size_t)W * 2);
+        std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile(rrc1.c_str(), W));
+        kb.upload((double *)prm.get(), (size_t)W * 2);
+        ck(oip_rrc_u16_window(ctx, p1.p, W, st.p, ow, W - fold, L, kb.p));
+        ck(oip_sync(ctx));
+        p1.release();
+        prm.reset(IMO::LoadRRCParamFile(rrc2.c_str(), W));
+        kb.upload((double *)prm.get(), (size_t)W * 2);
+        ck(oip_rrc_u16(ctx, p2.p, p2.p, W, L, kb.p));
+        ck(oip_remap_shift_bicubic_u16_window(ctx, p2.p, 0, L, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
+                                              OIP_REMAP_ROW_GUARD, o.fp16acc ? 1 : 0));
+        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
+        st.download(h.get(), nout);
+        OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
+        write_tiff_u16(outPAN, h.get(), (int)ow, L, 1, false, tiff_compression(TIFF_NONE));
+        OLOG("Fused task (PAN only) done in %.3f seconds.", total.tick());
+        return;
+    }
     // DoRRC (both strips, in place) + PreStitch of PAN2
     {
         DevBuf<double> kb((size_t)W * 2);
@@ -805,6 +833,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
             ck(oip_sync(ctx));
         }
     }
+    p2s.alloc(npx);
     ck((o.fp16acc ? oip_remap_shift_bicubic_u16_f16acc : oip_remap_shift_bicubic_u16)(ctx, p2.p, 0, L, p2s.p, 0, L, W, L, dx, dy,
                                                                                      OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
     p2.release();

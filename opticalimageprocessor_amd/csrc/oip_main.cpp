@@ -125,7 +125,8 @@ void usage()
          "  stitch     --image1 FILE --image2 FILE -c,--fold-cols N [-o,--out FILE] [-g,--GDAL -m,--band-map a,b,c,d]\n"
          "  --gpus N   (default action and prestitch) scan-line blocks over the N GPUs of the node, RCCL exchanges\n"
          "  plan       strip|ccd --width W --lines L --gpus N ...: print the multi-GPU row plan as JSON\n"
-         "  task       prestitch + stitch + default action x2 + stitch in one process (intermediates stay on the GPU):\n"
+         "  task       prestitch + stitch + default action x2 + stitch in one process (intermediates stay on the GPU;\n"
+         "             --pan-only: the stitched PAN product alone, RRC and resampling written straight into it):\n"
          "             --pan1 --pan2 --rrc1 --rrc2 --mss1 --mss2 --rrc-mss{1,2}-b{1..4} FILE --fold-cols-pan N --fold-cols-mss N\n"
          "             --out-pan FILE.TIFF --out-mss FILE.TIFF [prestitch, default-action and stitch options]");
 }
@@ -288,12 +289,17 @@ int run_task(const std::vector<std::string> &args, int width)
                  "--slices", "--ibc-sections", "--ibc-threshold", "--line-offset", "--lines-section", "--overlap-lines", "--width", "--fit"};
     for (int c = 1; c <= 2; ++c)
         for (int b = 1; b <= MSS_BANDS; ++b) sp.valued.insert("--rrc-mss" + std::to_string(c) + "-b" + std::to_string(b));
-    sp.flags = {"--GDAL", "--keep-leading", "--fp16-accumulate"};
+    sp.flags = {"--GDAL", "--keep-leading", "--fp16-accumulate", "--pan-only"};
     sp.alias = {{"-s", "--sections"}, {"-l", "--section-lines"}, {"-e", "--edge-cols"}, {"-g", "--GDAL"}, {"-m", "--band-map"}, {"-k", "--keep-leading"}};
     Parsed p = parse(sp, args);
     std::string msb[2][MSS_BANDS];
-    for (auto k : {"--pan1", "--pan2", "--rrc1", "--rrc2", "--mss1", "--mss2", "--out-pan", "--out-mss", "--fold-cols-pan", "--fold-cols-mss"}) require(p, k);
-    for (int c = 0; c < 2; ++c)
+    // --pan-only: the stitched PAN product alone (steps 1-2 of DOC/sample-task.sh).  No corrected strip is needed afterwards,
+    // so RRC of CCD 1 and the resampled CCD-2 lines are written straight into the stitched raster (one pass each).
+    const bool panOnly = p.flag.count("--pan-only") != 0;
+    for (auto k : {"--pan1", "--pan2", "--rrc1", "--rrc2", "--out-pan", "--fold-cols-pan"}) require(p, k);
+    if (!panOnly)
+        for (auto k : {"--mss1", "--mss2", "--out-mss", "--fold-cols-mss"}) require(p, k);
+    for (int c = 0; c < 2 && !panOnly; ++c)
         for (int b = 0; b < MSS_BANDS; ++b) {
             const std::string k = "--rrc-mss" + std::to_string(c + 1) + "-b" + std::to_string(b + 1);
             require(p, k);
@@ -311,7 +317,8 @@ int run_task(const std::vector<std::string> &args, int width)
     o.sttThreshold = p.real("--stt-threshold", o.sttThreshold);
     o.sttMaxDeltaY = p.real("--stt-maxdeltay", 0.0);
     o.foldColsPAN = p.integer("--fold-cols-pan", 0);
-    o.foldColsMSS = p.integer("--fold-cols-mss", 0);
+    o.foldColsMSS = p.integer("--fold-cols-mss", panOnly ? 2 : 0);
+    o.panOnly = panOnly;
     if (o.foldColsPAN < 2 || o.foldColsMSS < 2) throw cli_error(105, "--fold-cols: fold column value too small");
     o.useGDAL = p.has("--GDAL");
     if (p.has("--band-map") && !o.useGDAL) throw cli_error(107, "--band-map requires --GDAL");
@@ -334,7 +341,7 @@ int run_task(const std::vector<std::string> &args, int width)
     o.fitMode = fit_mode(p);
     o.fp16acc = p.flag.count("--fp16-accumulate") != 0;
     for (auto k : {"--out-pan", "--out-mss"})
-        if (to_lower(std::filesystem::path(p.str(k)).extension().string()) != ".tiff") throw std::invalid_argument("Output file should be a tiff image");
+        if (p.has(k) && to_lower(std::filesystem::path(p.str(k)).extension().string()) != ".tiff") throw std::invalid_argument("Output file should be a tiff image");
     RunFusedTask(p.str("--pan1"), p.str("--pan2"), p.str("--rrc1"), p.str("--rrc2"), p.str("--mss1"), p.str("--mss2"), msb[0], msb[1],
                  p.str("--out-pan"), p.str("--out-mss"), o);
     return 0;

@@ -1124,30 +1124,36 @@ struct VRowsJob {
 };
 
 template <int F, int NT, int... Rs>
-__global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int P, const int *__restrict__ ypos,
-                                                         const float2 *__restrict__ twF)
+__global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_v_kernel(VRowsJob fj, int a0, int part, int M, int P, const int *__restrict__ ypos,
+                                                                      const float2 *__restrict__ twF)
 {
+    // One launch serves ONE unit: its PAN image (slot `part` of the packed PAN buffer) against band arrays a0, a0 + 1.
+    // Three two-line buffers = 60 KB of LDS and <= 128 VGPRs, so two workgroups share a CU: one computes while the other
+    // waits at a barrier or for its lines.  (All four arrays of a pair in one workgroup -- 105 KB, one workgroup per CU --
+    // was measured first: 0.96 ms per pair against 2 x 0.33 ms for two launches of the image-domain kernel of this shape.)
     constexpr int TWN = oipfft::TwTable<F, Rs...>::value();
-    constexpr int N = F, NARR = 5;
+    constexpr int N = F, NARR = 3, NB = 2;
     constexpr int NIT = (N + NT - 1) / NT;
     static_assert(N % 2 == 0, "two points per lane");
     constexpr int NIT2 = (N / 2 + NT - 1) / NT;
-    constexpr int NQ = 4 * (N / 2);                 // 16-byte pieces of one line of the four band arrays
+    constexpr int NQ = NB * (N / 2);                // 16-byte pieces of one line of the two band arrays
     constexpr int NITN = (NQ + NT - 1) / NT;
-    __shared__ __align__(16) float2 buf[NARR * 2 * F];   // [spectrum][point][line]: line 0 = ky, line 1 = -ky
+    __shared__ __align__(16) float2 buf[NARR * 2 * F];   // [PAN | array a0 | array a0 + 1][point][line]: line 0 = ky, line 1 = -ky
     __shared__ float2 tw[TWN];
     float4 *buf4 = reinterpret_cast<float4 *>(buf);
     const int dbg = fj.dbg;
     const int half = M / 2;
-    const int narr = fj.nout;                       // band arrays in use
     int ky = blockIdx.x;
     if (ky > half) return;
     for (int i = threadIdx.x; i < TWN; i += NT) tw[i] = twF[i];
-    float4 la[NIT2], lb[NIT2];
+    float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
+    float2 vt[5];
     long n1 = ypos[ky], n2 = ypos[ky ? M - ky : 0];
     long m1 = fj.ypos_s[ky % fj.m], m2 = fj.ypos_s[(ky ? M - ky : 0) % fj.m];
-    int kyc = ky;                                   // the frequency line whose PAN loads are in the registers
-    auto fetch = [&](int tid) {                     // the PAN line pair: prefetched one iteration ahead
+    int kyc = ky;                                   // the frequency line whose loads are in the registers
+    const float2 *zn = fj.zn + (long)a0 * fj.zn_stride;
+    const float2 *raw = fj.raw + (long)a0 * fj.zn_stride;
+    auto fetch = [&](int tid) {                     // the PAN line pair, the band lines and their coefficients: one iteration ahead
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
             int q = tid + it * NT;
@@ -1155,6 +1161,17 @@ __global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int
             la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
             lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
         }
+#pragma unroll
+        for (int it = 0; it < NITN; ++it) {
+            int q = tid + it * NT;
+            q = q < NQ ? q : NQ - 1;
+            const int a = q / (N / 2), i = q - a * (N / 2);
+            const float2 *z = zn + a * fj.zn_stride + 2 * i;
+            na[it] = *reinterpret_cast<const float4 *>(z + m1 * fj.Pn);
+            nb[it] = *reinterpret_cast<const float4 *>(z + m2 * fj.Pn);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + kyc];
     };
     auto commit = [&](int tid) {
 #pragma unroll
@@ -1165,30 +1182,22 @@ __global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int
                 buf4[2 * q + 1] = make_float4(la[it].z, la[it].w, lb[it].z, lb[it].w);
             }
         }
-        // The band lines, their coefficients and the raw rows are requested here (L2 / Infinity Cache hits: every line of
-        // a band transform serves four frequency lines, the raw rows serve all): line ky of the vertically up-sampled band
-        // pair is Hv[ky] zn[ky mod m] + sum_i Gv_i[ky] raw_i; Hv and Gv of line -ky are the conjugates.
-        float2 vt[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + kyc];
+        // line ky of the vertically up-sampled band pair: Hv[ky] zn[ky mod m] + sum_i Gv_i[ky] raw_i; Hv and Gv of line
+        // -ky are the conjugates.  The raw rows (160 KB for a pair of units: L2 hits) are read here, not held.
 #pragma unroll
         for (int it = 0; it < NITN; ++it) {
             const int q = tid + it * NT;
+            if (q >= NQ) continue;
             const int a = q / (N / 2), i = q - a * (N / 2);
-            if (q >= NQ || a >= narr) continue;
-            const float2 *z = fj.zn + a * fj.zn_stride + 2 * i;
-            const float4 na = *reinterpret_cast<const float4 *>(z + m1 * fj.Pn), nb = *reinterpret_cast<const float4 *>(z + m2 * fj.Pn);
-            float4 rw[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rw[r] = *reinterpret_cast<const float4 *>(fj.raw + ((long)r * 4 + a) * fj.zn_stride + 2 * i);
             const float2 hv = vt[0];
-            float2 x0 = oipfft::cmul(hv, make_float2(na.x, na.y)), x1 = oipfft::cmul(hv, make_float2(na.z, na.w));
-            float2 y0 = cmulj(hv, make_float2(nb.x, nb.y)), y1 = cmulj(hv, make_float2(nb.z, nb.w));
+            float2 x0 = oipfft::cmul(hv, make_float2(na[it].x, na[it].y)), x1 = oipfft::cmul(hv, make_float2(na[it].z, na[it].w));
+            float2 y0 = cmulj(hv, make_float2(nb[it].x, nb[it].y)), y1 = cmulj(hv, make_float2(nb[it].z, nb[it].w));
             if (!(dbg & 32)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    const float4 rw = *reinterpret_cast<const float4 *>(raw + ((long)r * 4 + a) * fj.zn_stride + 2 * i);
                     const float2 gv = vt[1 + r];
-                    const float2 w0 = make_float2(rw[r].x, rw[r].y), w1 = make_float2(rw[r].z, rw[r].w);
+                    const float2 w0 = make_float2(rw.x, rw.y), w1 = make_float2(rw.z, rw.w);
                     x0 = cfma(gv, w0, x0); x1 = cfma(gv, w1, x1);
                     y0 = cfmaj(gv, w0, y0); y1 = cfmaj(gv, w1, y1);
                 }
@@ -1224,14 +1233,11 @@ __global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int
             const int nkx = kx ? N - kx : 0;
             const bool edge_col = (kx == 0) || (2 * kx == N);
             const bool real_bin = edge_col && (ky == 0 || 2 * ky == M);
-            const float2 zk0 = buf[2 * kx], zm0 = buf[2 * nkx + 1];
-            const float2 Aa = spec_of(0, zk0, zm0), Ab = spec_of(1, zk0, zm0);
+            const float2 A = spec_of(part, buf[2 * kx], buf[2 * nkx + 1]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                if (a >= narr) continue;
+            for (int a = 0; a < NB; ++a) {
                 float2 *b = buf + (1 + a) * 2 * F;
                 const float2 zk = b[2 * kx], zm = b[2 * nkx + 1];
-                const float2 A = a < 2 ? Aa : Ab;
                 const float2 C1 = cross_power_bin_fast(A, spec_of(0, zk, zm), real_bin, edge_col);
                 const float2 C2 = cross_power_bin_fast(A, spec_of(1, zk, zm), real_bin, edge_col);
                 // Y = C1 + i C2 at the bin, conj(C1) + i conj(C2) at its mirror; inverse = conj(forward(conj(.)))
@@ -1241,10 +1247,10 @@ __global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int
         }
         __syncthreads();
         asm volatile("" : "+v"(tid));
-        if (!(dbg & 4)) oipfft::StagesPipe<F, NT, 4, 1, Rs...>::run(buf + 2 * F, tw, tid);
-        float4 ya[4][NIT2], yb[4][NIT2];            // line ky / line -ky, two points each
+        if (!(dbg & 4)) oipfft::StagesPipe<F, NT, NB, 1, Rs...>::run(buf + 2 * F, tw, tid);
+        float4 ya[NB][NIT2], yb[NB][NIT2];          // line ky / line -ky, two points each
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < NB; ++o) {
 #pragma unroll
             for (int it = 0; it < NIT2; ++it) {
                 const int q = tid + it * NT;
@@ -1260,9 +1266,8 @@ __global__ __launch_bounds__(NT) void corr_rows_v_kernel(VRowsJob fj, int M, int
         __builtin_amdgcn_sched_barrier(0);
         if (!(dbg & 16)) {
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                if (o >= narr) continue;
-                float2 *out = fj.out[o];
+            for (int o = 0; o < NB; ++o) {
+                float2 *out = fj.out[a0 + o];
 #pragma unroll
                 for (int it = 0; it < NIT2; ++it) {
                     const int q = tid + it * NT;
@@ -2122,10 +2127,10 @@ int correlate_units_vup(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, 
     if ((rc = forward_packed(ctx, pl, w.z[0], aA, nunits > 1 ? aB : src_none(), rows, cols, true))) return rc;
     const int narr = 2 * nunits;
     const int N = pl->N, Pn = up.small->P;
-    // z[1] holds the m x (4 N) band array and, behind it, the four raw rows of the four arrays
+    // z[1] holds the m x (4 N) band array; the four raw rows of the four arrays live in the small scratch (carve: 32 N floats)
     float2 *zn = w.z[1];
-    float2 *raw = zn + (long)up.small->M * Pn;
-    if ((long)up.small->M * Pn + 16L * N > (long)pl->M * pl->P) return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: band array exceeds its slot");
+    float2 *raw = reinterpret_cast<float2 *>(w.fsmall);
+    if ((long)up.small->M * Pn > (long)pl->M * pl->P) return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: band array exceeds its slot");
     HPackJob hj;
     for (int a = 0; a < 4; ++a) {
         const IbUnit *u = units[(a < narr ? a : 0) / 2];
@@ -2159,12 +2164,12 @@ int correlate_units_vup(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, 
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
     {
         OipProfScope prof(ctx, "corr_rows_v_kernel");
-        long grid = ctx->cu_count;
+        long grid = 2L * ctx->cu_count;                     // two workgroups per CU (60 KB of LDS, <= 128 VGPRs each)
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
-        if (N == 1250)
-            hipLaunchKernelGGL((corr_rows_v_kernel<1250, 512, 5, 5, 5, 5, 2>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, pl->M, pl->P, pl->d_ypos, twF);
-        else
-            return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: no row stage for %d-point rows", N);
+        if (N != 1250) return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: no row stage for %d-point rows", N);
+        for (int u = 0; u < nunits; ++u)
+            hipLaunchKernelGGL((corr_rows_v_kernel<1250, 512, 5, 5, 5, 5, 2>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P,
+                               pl->d_ypos, twF);
         OIP_HIP(ctx, hipGetLastError());
     }
     double *res[4];
@@ -2336,14 +2341,14 @@ static int interband_units(oip_ctx *ctx, const IbUnit *units, int n, int rows, i
             if ((rc = upsample_spectrum_tables(ctx, tab, 1, &up.vtab))) return rc;
             if (up.vtab) {
                 if ((rc = oip_fft2d_plan(ctx, band_rows, 4 * N, &up.small))) return rc;
-                up.vonly = (long)up.small->M * up.small->P + 16L * N <= (long)pl->M * pl->P;
+                up.vonly = (long)up.small->M * up.small->P <= (long)pl->M * pl->P;
                 if (!up.vonly) up.vtab = nullptr;
             }
         }
     }
     PcWork w;
     const bool spectral = up.xtab || up.vonly;
-    if ((rc = carve(ctx, pl, rows, band_cols, 0, spectral ? 2 : 5, spectral ? 4 : 2, 8, &w))) return rc;      // f32 scratch: the V images
+    if ((rc = carve(ctx, pl, rows, band_cols, up.vonly ? 32 * N : 0, spectral ? 2 : 5, spectral ? 4 : 2, 8, &w))) return rc;      // f32 scratch: the V images
     if ((rc = oip_small(ctx, sizeof(double) * 12 * (size_t)(n > 0 ? n : 1)))) return rc;
     double *d_res = (double *)ctx->d_small;
     // vertical passes of all bands of one or two units in one launch

@@ -21,6 +21,17 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Where output pixel (line r of the call's window, column x of the strip geometry) goes: dst[r * pitch + x + shift], and
+// only columns x >= col0 are stored.  The plain call is {W, 0, 0, vec}; the fused prestitch -> stitch form writes the
+// columns [fold, W) of the resampled CCD-2 line straight into the right half of the stitched raster (pitch 2 (W - fold),
+// shift W - 2 fold): .RRC.PRESTT.RAW is never materialised.  vec: 16-byte stores are aligned (host-checked).
+struct DstWin {
+    long pitch;
+    int col0;
+    long shift;
+    int vec;
+};
+
 struct RowInfo {
     int src[4];     // source line of each vertical tap relative to d_src, -1 = constant border
     int fy;         // y phase
@@ -73,10 +84,11 @@ __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, i
 
 // one output column over a run of output lines (4x4 register window, one new source line per
 // output line): the general path -- any width, any alignment, every border case
-__device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+__device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                              const RowInfo *__restrict__ rows, int W, double dx, const float *__restrict__ tab1d,
                              int x, long r0, long r1)
 {
+    if (x < dw.col0) return;
     // stitcher.h:96  mapx = (float)(x + mDeltaX); imgwarp.cpp: sx = cvRound(mapx*32)
     const float mapx = (float)((double)x + dx);
     const int sx = oip_cvround(mapx * 32.0f);
@@ -132,13 +144,13 @@ __device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, u
                 if (ri.src[t] >= 0) ymask |= 1u << t;
             sum = oip_bicubic_border(v, wx, wy, xmask, ymask);
         }
-        dst[r * (long)W + x] = (uint16_t)oip_sat_u16(sum);
+        dst[r * dw.pitch + x + dw.shift] = (uint16_t)oip_sat_u16(sum);
     }
 }
 
 
 __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__restrict__ src,
-                                                             uint16_t *__restrict__ dst,
+                                                             uint16_t *__restrict__ dst, DstWin dw,
                                                              const RowInfo *__restrict__ rows, int W, long out_rows,
                                                              double dx, const float *__restrict__ tab1d,
                                                              int rows_per_block)
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__r
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
-    remap_column(src, dst, rows, W, dx, tab1d, x, r0, r1);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
 }
 
 // ---- v2: 8 output pixels per lane ------------------------------------------------------------------
@@ -218,13 +230,13 @@ __device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src
     expand_f32(w, c0, g);
 }
 
-__global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+__global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                  const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                  long src_elems, double dx, const float *__restrict__ tab1d,
                                                                  int rows_per_block)
 {
     const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
-    if (x0 >= W) return;
+    if (x0 >= W || x0 + 8 <= dw.col0) return;
     int c0, fx0;
     if (!shift_group_regular(x0, W, dx, &c0, &fx0)) return;        // fix-up launch A
     const long r0 = (long)blockIdx.y * rows_per_block;
@@ -288,7 +300,15 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
             uint4 o;
             o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
             o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
-            *reinterpret_cast<uint4 *>(dst + r * (long)W + x0) = o;
+            uint16_t *drow = dst + r * dw.pitch + x0 + dw.shift;
+            if (x0 >= dw.col0 && dw.vec) {
+                *reinterpret_cast<uint4 *>(drow) = o;
+            } else {
+                // the group that straddles col0, or a destination whose 16-byte stores would be misaligned
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+            }
         }
     }
 }
@@ -356,13 +376,13 @@ __device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ s
     expand_h(w, c0, E, O);
 }
 
-__global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+__global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                      const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                      long src_elems, double dx, const float *__restrict__ tab1d,
                                                                      int rows_per_block)
 {
     const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
-    if (x0 >= W) return;
+    if (x0 >= W || x0 + 8 <= dw.col0) return;
     int c0, fx0;
     if (!shift_group_regular(x0, W, dx, &c0, &fx0)) return;        // fix-up launch A (f32)
     const long r0 = (long)blockIdx.y * rows_per_block;
@@ -431,14 +451,22 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
             uint4 o;
             o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
             o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
-            *reinterpret_cast<uint4 *>(dst + r * (long)W + x0) = o;
+            uint16_t *drow = dst + r * dw.pitch + x0 + dw.shift;
+            if (x0 >= dw.col0 && dw.vec) {
+                *reinterpret_cast<uint4 *>(drow) = o;
+            } else {
+                // the group that straddles col0, or a destination whose 16-byte stores would be misaligned
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+            }
         }
     }
 }
 
 // fix-up A: irregular 8-column groups, all lines.  blockIdx.x = index into `groups`; the 256
 // lanes are 8 columns x 32 line sub-ranges.
-__global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+__global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                 const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                 double dx, const float *__restrict__ tab1d,
                                                                 const int *__restrict__ groups, int rows_per_block)
@@ -452,11 +480,11 @@ __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *
     const long rend = (long)(blockIdx.y + 1) * rows_per_block;
     if (r1 > rend) r1 = rend;
     if (r1 > out_rows) r1 = out_rows;
-    if (r0 < r1) remap_column(src, dst, rows, W, dx, tab1d, x, r0, r1);
+    if (r0 < r1) remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
 }
 
 // fix-up B: lines whose window touches a section border, all columns
-__global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst,
+__global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                 const RowInfo *__restrict__ rows, int W, double dx,
                                                                 const float *__restrict__ tab1d,
                                                                 const int *__restrict__ bad_count,
@@ -467,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if ((int)blockIdx.y >= n || x >= W) return;
     const long r = bad_rows[blockIdx.y];
-    remap_column(src, dst, rows, W, dx, tab1d, x, r, r + 1);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r, r + 1);
 }
 
 }  // namespace
@@ -524,9 +552,17 @@ extern "C" int oip_remap_shift_src_range(long out_row0, long out_rows, long L, d
 
 static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows, uint16_t *d_dst,
                             long out_row0, long out_rows, int W, long L, double dx, double dy, int section_rows,
-                            int row_guard, bool f16acc)
+                            int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0)
 {
     OIP_CHECK_CTX(ctx);
+    if (dst_pitch <= 0) { dst_pitch = W; dst_col0 = 0; dst_col_off = 0; }
+    if (dst_col0 < 0 || dst_col0 >= W || dst_col_off < 0 || dst_col_off + (W - dst_col0) > dst_pitch)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_bicubic_u16: destination window outside its raster");
+    DstWin dw;
+    dw.pitch = dst_pitch;
+    dw.col0 = dst_col0;
+    dw.shift = dst_col_off - dst_col0;
+    dw.vec = (dw.shift % 8 == 0) && (dst_pitch % 8 == 0) && ((((uintptr_t)d_dst) & 15) == 0);
     if (!d_src || !d_dst || W <= 0 || L <= 0 || section_rows <= 3)
         return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_bicubic_u16: bad argument");
     if (L <= row_guard) return oip_fail(ctx, OIP_E_INVALID, "too few data rows, please use cv::remap()");   // imageop.h:242-244
@@ -548,7 +584,8 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
                             "oip_remap_shift_bicubic_u16: source window [%ld,%ld) lacks halo lines, need [%ld,%ld)",
                             src_row0, src_row0 + src_rows, first, last);
     }
-    const bool v8 = W % 8 == 0 && (((uintptr_t)d_dst) & 15) == 0 && (((uintptr_t)d_src) & 3) == 0 && src_rows * (long)W >= 16;
+    const bool v8 = W % 8 == 0 && (((uintptr_t)d_dst) & 1) == 0 && (((uintptr_t)d_src) & 3) == 0 && src_rows * (long)W >= 16 &&
+                    (dw.vec || dst_pitch != W);       // the plain call keeps its rule: misaligned destination -> generic kernel
     // irregular 8-column groups (host arithmetic identical to the kernel's)
     std::vector<int> bad_groups;
     if (v8)
@@ -591,7 +628,7 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         {
             OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel");
             hipLaunchKernelGGL(f16acc ? remap_shift8_f16_kernel : remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0,
-                               ctx->stream, d_src, d_dst, rows, W, out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
+                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
         }
         if (!bad_groups.empty()) {
             OipProfScope prof(ctx, "remap_fix_cols_kernel");
@@ -599,13 +636,13 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
             long gy2 = (out_rows + rpb2 - 1) / rpb2;
             if (gy2 > 65535) { gy2 = 65535; rpb2 = (out_rows + gy2 - 1) / gy2; gy2 = (out_rows + rpb2 - 1) / rpb2; }
             hipLaunchKernelGGL(remap_fix_cols_kernel, dim3((unsigned)bad_groups.size(), (unsigned)gy2), dim3(kBlock), 0,
-                               ctx->stream, d_src, d_dst, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2);
+                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2);
         }
         {
             OipProfScope prof(ctx, "remap_fix_rows_kernel");
             const long nb = (long)g.nsec * 8 + g.ucut + g.bcut + 16;      // upper bound on listed lines
             hipLaunchKernelGGL(remap_fix_rows_kernel, dim3((W + kBlock - 1) / kBlock, (unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                               d_src, d_dst, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows);
+                               d_src, d_dst, dw, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows);
         }
     } else {
         OipProfScope prof(ctx, "remap_shift_kernel");
@@ -616,7 +653,7 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         if (rpb < 32) rpb = 32;
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
-        hipLaunchKernelGGL(remap_shift_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, rows,
+        hipLaunchKernelGGL(remap_shift_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows,
                            W, out_rows, dx, ctx->d_tab1d, (int)rpb);
     }
     OIP_HIP(ctx, hipGetLastError());
@@ -635,4 +672,18 @@ extern "C" int oip_remap_shift_bicubic_u16_f16acc(oip_ctx *ctx, const uint16_t *
                                                   double dy, int section_rows, int row_guard)
 {
     return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, true);
+}
+
+// PreStitch's resampled CCD-2 lines written into a window of another raster: column x >= dst_col0 of output line r goes to
+// d_dst[r * dst_pitch + dst_col_off + (x - dst_col0)], columns below dst_col0 are not stored.  With dst_pitch = 2 (W - fold),
+// dst_col0 = fold, dst_col_off = W - fold this is the right half of IMO::StitchBigRaw's output line (imageop.h:340-351):
+// prestitch -> stitch without materialising .RRC.PRESTT.RAW (the fused single-pass pipeline).
+extern "C" int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows,
+                                                  uint16_t *d_dst, long dst_pitch, int dst_col0, long dst_col_off, long out_row0,
+                                                  long out_rows, int W, long L, double dx, double dy, int section_rows, int row_guard,
+                                                  int f16acc)
+{
+    if (ctx && dst_pitch <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_bicubic_u16_window: bad destination pitch");
+    return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, f16acc != 0,
+                            dst_pitch, dst_col0, dst_col_off);
 }

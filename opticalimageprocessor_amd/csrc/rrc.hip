@@ -234,6 +234,67 @@ __global__ __launch_bounds__(kBlock) void mss_split_rrc_scalar_kernel(const uint
     }
 }
 
+// RRC of a w-column window of one raster into a window of another (separate pitches): the fused prestitch -> stitch
+// form writes RRC(PAN1)[:, 0 : W - fold] straight into the left half of the stitched raster (imageop.h:340-351), so
+// .RRC.RAW of CCD 1 is never materialised.  A lane owns 8 columns (LUT in registers) and walks a block of lines, four
+// lines in flight; the last group of a window whose width is not a multiple of 8 stores its pixels one by one.
+__global__ __launch_bounds__(kBlock) void rrc_u16_window_kernel(const uint16_t *__restrict__ src, long src_pitch, uint16_t *__restrict__ dst,
+                                                                long dst_pitch, int w, long h, const double2 *__restrict__ kb,
+                                                                long rows_per_block)
+{
+    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (x0 >= w) return;
+    double k[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 p = kb[x0 + i < w ? x0 + i : w - 1];
+        k[i] = p.x;
+        b[i] = p.y;
+    }
+    const bool whole = x0 + 8 <= w;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > h) r1 = h;
+    const uint16_t *s = src + r0 * src_pitch + x0;
+    uint16_t *d = dst + r0 * dst_pitch + x0;
+    auto put = [&](uint16_t *q, uint4 o) {
+        if (whole) { *reinterpret_cast<uint4 *>(q) = o; return; }
+        const unsigned wv[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (x0 + j < w) q[j] = (uint16_t)((wv[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+    };
+    // (a partial group still loads 16 bytes: the source window is followed by the rest of its line -- host-checked)
+    long r = r0;
+    for (; r + kRowsInFlight <= r1; r += kRowsInFlight) {
+        uint4 v[kRowsInFlight];
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) v[u] = *reinterpret_cast<const uint4 *>(s + (long)u * src_pitch);
+#pragma unroll
+        for (int u = 0; u < kRowsInFlight; ++u) put(d + (long)u * dst_pitch, rrc_vec<8>(v[u], k, b));
+        s += (long)kRowsInFlight * src_pitch;
+        d += (long)kRowsInFlight * dst_pitch;
+    }
+    for (; r < r1; ++r) {
+        put(d, rrc_vec<8>(*reinterpret_cast<const uint4 *>(s), k, b));
+        s += src_pitch;
+        d += dst_pitch;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void rrc_u16_window_scalar_kernel(const uint16_t *__restrict__ src, long src_pitch, uint16_t *__restrict__ dst,
+                                                                       long dst_pitch, int w, long n, const double2 *__restrict__ kb)
+{
+    long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    const long stride = (long)gridDim.x * kBlock;
+    for (; i < n; i += stride) {
+        const long r = i / w;
+        const int x = (int)(i - r * w);
+        const double2 p = kb[x];
+        dst[r * dst_pitch + x] = (uint16_t)rrc_px(p.x, p.y, src[r * src_pitch + x]);
+    }
+}
+
 // grid.y so that the launch has ~16 blocks per CU while each block keeps >= 64 rows
 inline void row_blocks(const oip_ctx *ctx, int gx, long h, long *rows_per_block, int *gy)
 {
@@ -297,6 +358,37 @@ extern "C" int oip_rrc_u16(oip_ctx *ctx, const uint16_t *d_src, uint16_t *d_dst,
     const uintptr_t align = (uintptr_t)d_src | (uintptr_t)d_dst;
     OipProfScope prof(ctx, (w % 8 == 0 && (align & 15) == 0) ? "rrc_u16_flat_kernel" : "rrc_u16_kernel");
     return oip_rrc_launch(ctx, ctx->stream, d_src, d_dst, w, h, d_kb);
+}
+
+// IMO::InplaceRRC (imageop.h:129-138) on a window: columns [0, w) of h lines of a raster of pitch src_pitch, written to a
+// raster of pitch dst_pitch (pitches in pixels; d_kb: the w (k, b) pairs of the window's columns).
+extern "C" int oip_rrc_u16_window(oip_ctx *ctx, const uint16_t *d_src, long src_pitch, uint16_t *d_dst, long dst_pitch, int w, long h,
+                                  const double *d_kb)
+{
+    OIP_CHECK_CTX(ctx);
+    if (w <= 0 || h < 0 || !d_src || !d_dst || !d_kb || src_pitch < w || dst_pitch < w)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_rrc_u16_window: bad argument");
+    if (h == 0) return OIP_OK;
+    const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
+    OipProfScope prof(ctx, "rrc_u16_window_kernel");
+    // vector form: 16-byte loads and stores on both sides, and a partial last group may read up to 7 pixels past the window
+    const bool vec = src_pitch % 8 == 0 && dst_pitch % 8 == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0 &&
+                     (w % 8 == 0 || src_pitch >= (long)(w + 7) / 8 * 8);
+    if (vec) {
+        int gx = ((w + 7) / 8 + kBlock - 1) / kBlock, gy;
+        long rpb;
+        row_blocks(ctx, gx, h, &rpb, &gy);
+        hipLaunchKernelGGL(rrc_u16_window_kernel, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, src_pitch, d_dst, dst_pitch, w, h, kb, rpb);
+    } else {
+        const long n = (long)w * h;
+        long blocks = (n + kBlock - 1) / kBlock;
+        const long cap = (long)ctx->cu_count * 32;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(rrc_u16_window_scalar_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_src, src_pitch, d_dst, dst_pitch, w,
+                           n, kb);
+    }
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
 }
 
 extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16_t *d_planes, size_t plane_stride,

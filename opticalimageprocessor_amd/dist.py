@@ -529,7 +529,7 @@ class CcdBuffers:
 
 
 def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, prestt, stitched, rank: int,
-                          threshold=0.4, max_delta_y=0.0, f16acc=False, group=None):
+                          threshold=0.4, max_delta_y=0.0, f16acc=False, group=None, fused=False):
     """One pass of the sharded cross-CCD path on this rank: CalcSttParameters on the RAW lines (App. B-1) ->
     RRC of both CCDs -> constant-shift bicubic remap of CCD 2 with row halo -> RAW stitch.
 
@@ -538,6 +538,11 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
       rrc(src, dst, w, h, kb);  remap_src_range(out_row0, out_rows, dy)
       remap(src, src_row0, src_rows, dst, out_row0, out_rows, dx, dy, f16acc);  stitch(left, right, out, rows)
     prestt: pb x W (the rank's block of .RRC.PRESTT.RAW); stitched: pb x 2(W - fold).  Returns (dx, dy, table).
+
+    fused=True (the single-pass form of `oip task`, when .RRC.RAW / .RRC.PRESTT.RAW are not requested products): the RRC of
+    CCD 1 writes straight into the left half of `stitched` (backend.rrc_window) and the resampled CCD-2 lines straight into
+    its right half (backend.remap_window) -- three full passes over the strips become one each; `prestt` and bufs.rrc1 are
+    not touched and `stitched` holds the same bits.
     """
     W = plan.W
     multi = plan.world > 1
@@ -555,7 +560,10 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
         table = gather_table(table, bufs.pan1.device if bufs.pan1.is_cuda else "cpu", group)
     dx, dy, _, _ = backend.stt_mean(table, threshold, max_delta_y)       # identical on every rank
     # DoRRC (stitcher.h:141-146): own lines of both CCDs; CCD 2 lands in the halo-capable buffer
-    backend.rrc(bufs.pan1, bufs.rrc1, W, plan.pb, kb1)
+    if fused:
+        backend.rrc_window(bufs.pan1, W, stitched, 2 * (W - plan.fold), W - plan.fold, plan.pb, kb1)
+    else:
+        backend.rrc(bufs.pan1, bufs.rrc1, W, plan.pb, kb1)
     transfers, need = plan.remap_transfers(lambda a, n: backend.remap_src_range(a, n, dy))
     f, l = need[rank]
     bufs.alloc_rrc2(f, l)
@@ -563,6 +571,10 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
     if multi:
         backend.sync()
         run_transfers(transfers, bufs, rank, group)
+    if fused:
+        backend.remap_window(bufs.rrc2, bufs.r2_first, bufs.rrc2.shape[0], stitched, 2 * (W - plan.fold), plan.fold, W - plan.fold, b0,
+                             plan.pb, dx, dy, f16acc)
+        return dx, dy, table
     backend.remap(bufs.rrc2, bufs.r2_first, bufs.rrc2.shape[0], prestt, b0, plan.pb, dx, dy, f16acc)
     backend.stitch(bufs.rrc1, prestt, stitched, plan.pb)
     return dx, dy, table
@@ -630,3 +642,12 @@ class HipBackend:
 
     def stitch(self, left, right, out, rows):
         self.ctx.stitch_rows_u16(left, right, out, self.plan.W, rows, self.plan.fold)
+
+    def rrc_window(self, src, src_pitch, dst, dst_pitch, w, h, kb):
+        self.ctx.rrc_u16_window(src, src_pitch, dst, dst_pitch, w, h, kb)
+
+    def remap_window(self, src, src_row0, src_rows, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc):
+        p = self.plan
+        self.ctx.remap_shift_bicubic_u16_window(src, dst, dst_pitch, dst_col0, dst_col_off, p.W, p.L, dx, dy, p.section_rows,
+                                                p.row_guard, src_row0=src_row0, src_rows=src_rows, out_row0=out_row0,
+                                                out_rows=out_rows, f16acc=f16acc)

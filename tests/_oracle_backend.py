@@ -83,3 +83,15 @@ class OracleBackend:
 
     def stitch(self, left, right, out, rows):
         out.copy_(torch.from_numpy(oracle.stitch_raw(left.numpy(), right.numpy(), self.plan.fold)))
+
+    # fused prestitch -> stitch (dist.prestitch_stitch_step(fused=True)): the same oracle calls, written into the halves
+    def rrc_window(self, src, src_pitch, dst, dst_pitch, w, h, kb):
+        res = oracle.rrc(np.ascontiguousarray(src.numpy()[:h, :w]), np.asarray(kb)[:w])
+        dst[:h, :w] = torch.from_numpy(res)
+
+    def remap_window(self, src, src_row0, src_rows, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc):
+        p = self.plan
+        full = np.zeros((p.L, p.W), np.uint16)
+        full[src_row0:src_row0 + src_rows] = src.numpy()
+        res, _ = oracle.prestitch(full, dx, dy, p.section_rows, p.row_guard)
+        dst[:out_rows, dst_col_off:dst_col_off + p.W - dst_col0] = torch.from_numpy(res[out_row0:out_row0 + out_rows, dst_col0:])

@@ -100,6 +100,10 @@ def _run_ccd_rank(rank, world, port, tmp, shift):
     stitched = torch.zeros(plan.pb, 2 * (CW - plan.fold), dtype=torch.uint16)
     dx, dy, table = prestitch_stitch_step(OracleBackend(plan), plan, bufs, kb1, kb2, prestt, stitched, rank,
                                           threshold=-1.0, group=None)
+    # the fused single-pass form: RRC of CCD 1 and the resampled CCD-2 lines written straight into the stitched raster
+    fused = torch.zeros_like(stitched)
+    prestitch_stitch_step(OracleBackend(plan), plan, bufs, kb1, kb2, None, fused, rank, threshold=-1.0, group=None, fused=True)
+    assert torch.equal(fused, stitched), "fused prestitch -> stitch differs from the three-pass flow"
     np.savez(os.path.join(tmp, "c%d_r%d.npz" % (world, rank)), prestt=prestt.numpy(), stitched=stitched.numpy(),
              shift=np.array([dx, dy]), table=table, halo=np.array([bufs.r2_first, bufs.rrc2.shape[0]]),
              remote=np.array([u for u in plan.units_of(rank) if not plan.unit_is_local(u)]))

@@ -225,6 +225,12 @@ def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
         assert ta[262] == tb[262] and ta[277] == tb[277]
     assert ia.any()                                    # not trivially empty
     print("five commands %.2f s, fused task %.2f s" % (t_ref, t_fused))
+    # --pan-only: the stitched PAN product alone, RRC of CCD 1 and the resampled CCD-2 lines written straight into the
+    # stitched raster (oip_rrc_u16_window + oip_remap_shift_bicubic_u16_window): the same file, byte for byte
+    pan_only = ["task", "--pan-only", "--width", str(W), "--pan1", "A_PAN-1.RAW", "--pan2", "A_PAN-2.RAW", "--rrc1", "P1.csv", "--rrc2", "P2.csv",
+                "--fold-cols-pan", "40", "--out-pan", "fused-PAN-only.TIFF"] + stt + plain
+    run(pan_only)
+    assert open(os.path.join(d, "fused-PAN-only.TIFF"), "rb").read() == open(os.path.join(d, "fused-PAN.TIFF"), "rb").read()
     # argument errors keep the CLI's codes
     r = subprocess.run([OIP, "task", "--pan1", "A_PAN-1.RAW"], cwd=d, env=env, capture_output=True, text=True)
     assert r.returncode == 106

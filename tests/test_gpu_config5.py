@@ -210,6 +210,12 @@ def _rank_main(rank, world, port, tmp, what):
         dx, dy, table = prestitch_stitch_step(HipBackend(ctx, plan), plan, bufs, ctx.upload_kb(kb1), ctx.upload_kb(kb2),
                                               prestt, stitched, rank, threshold=0.05, f16acc=(what == "ccd16"))
         ctx.sync()
+        # the fused single-pass form (oip_rrc_u16_window + oip_remap_shift_bicubic_u16_window): same bits in `stitched`
+        fused = torch.zeros_like(stitched)
+        prestitch_stitch_step(HipBackend(ctx, plan), plan, bufs, ctx.upload_kb(kb1), ctx.upload_kb(kb2), None, fused, rank,
+                              threshold=0.05, f16acc=(what == "ccd16"), fused=True)
+        ctx.sync()
+        assert torch.equal(fused, stitched), "fused prestitch -> stitch differs from the three-pass flow"
         np.savez(os.path.join(tmp, "%s%d_r%d.npz" % (what, world, rank)), prestt=prestt.cpu().numpy(),
                  stitched=stitched.cpu().numpy(), shift=np.array([dx, dy]), table=table)
     torch.cuda.synchronize()

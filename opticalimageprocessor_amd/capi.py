@@ -70,6 +70,7 @@ _SIGS = {
     "oip_stage_sync": ([_vp], _i),
     "oip_stage_order_after_compute": ([_vp], _i),
     "oip_stage_threads": ([], _i),
+    "oip_stage_stats": ([_vp, _dp, _i], _i),
     "oip_mss_split_rrc_u16": ([_vp, _vp, _vp, _sz, _i, _l, _vp], _i),
     "oip_phase_correlate_f32": ([_vp, _vp, _vp, _i, _i, _dp, _dp, _dp], _i),
     "oip_window_u16_to_f32": ([_vp, _vp, _sz, _l, _i, _i, _i, _vp], _i),
@@ -306,6 +307,12 @@ class Context:
 
     def stage_wait(self, ticket):
         self._ck(self.lib.oip_stage_wait(self.h, ticket))
+
+    def stage_stats(self, reset=False):
+        """(seconds in pageable -> pinned copies, seconds waiting for a ring slot, bytes, calls) of the upload lane"""
+        out = (C.c_double * 4)()
+        self._ck(self.lib.oip_stage_stats(self.h, out, 1 if reset else 0))
+        return tuple(out)
 
     def stage_order_after_compute(self):
         self._ck(self.lib.oip_stage_order_after_compute(self.h))

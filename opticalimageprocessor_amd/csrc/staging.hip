@@ -25,6 +25,7 @@
 #include "oip_internal.h"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -131,6 +132,9 @@ struct oip_stage_state {
     int dnext = 0;
     hipEvent_t down_compute_ev = nullptr;
     std::atomic<long> ticket{0};
+    // where the host side of the ring lane spends its time (oip_stage_stats): pageable <-> pinned copies on the pool, and
+    // waiting for a slot whose DMA has not finished (the link is the limit then)
+    std::atomic<long> copy_ns{0}, wait_ns{0}, ring_bytes{0}, ring_calls{0};
     // LUT cache of oip_rrc_u16_host
     double *d_kb = nullptr;
     std::vector<double> kb_host;
@@ -191,8 +195,33 @@ static int slot_acquire(oip_ctx *ctx, oip_stage_state *s, int *out)
 {
     const int i = s->next;
     s->next = (s->next + 1) % kSlots;
-    if (s->slot_used[i]) OIP_HIP(ctx, hipEventSynchronize(s->slot_free[i]));
+    if (s->slot_used[i]) {
+        const auto t0 = std::chrono::steady_clock::now();
+        OIP_HIP(ctx, hipEventSynchronize(s->slot_free[i]));
+        s->wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
     *out = i;
+    return OIP_OK;
+}
+
+// pool copy with its time booked to the lane's statistics
+static void timed_copy(oip_stage_state *s, void *dst, const void *src, size_t bytes)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    CopyPool::get().copy(dst, src, bytes);
+    s->copy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    s->ring_bytes += (long)bytes;
+}
+
+extern "C" int oip_stage_stats(oip_ctx *ctx, double *out, int reset)
+{
+    if (!ctx || !out) return OIP_E_INVALID;
+    oip_stage_state *s = ctx->stage;
+    out[0] = s ? s->copy_ns.load() * 1e-9 : 0.0;
+    out[1] = s ? s->wait_ns.load() * 1e-9 : 0.0;
+    out[2] = s ? (double)s->ring_bytes.load() : 0.0;
+    out[3] = s ? (double)s->ring_calls.load() : 0.0;
+    if (s && reset) { s->copy_ns = 0; s->wait_ns = 0; s->ring_bytes = 0; s->ring_calls = 0; }
     return OIP_OK;
 }
 
@@ -347,12 +376,13 @@ extern "C" int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, si
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
     std::lock_guard<std::mutex> lane(s->ring_mu);
+    ++s->ring_calls;
     size_t done = 0;
     while (done < bytes) {
         int i;
         if ((rc = slot_acquire(ctx, s, &i))) return rc;
         const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
-        CopyPool::get().copy(s->slot[i], (const char *)host + done, n);
+        timed_copy(s, s->slot[i], (const char *)host + done, n);
         OIP_HIP(ctx, hipMemcpyAsync((char *)d_dst + done, s->slot[i], n, hipMemcpyHostToDevice, s->stream));
         hipEventRecord(s->slot_free[i], s->stream);
         s->slot_used[i] = true;

@@ -342,10 +342,11 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
             prev = e
         prev = max(prev, b)
     nblk = len(blocks)
-    times = []
+    times, lane = [], []
     for rep in range(reps):
         raw_pan.zero_(); raw_mss.zero_(); out.zero_()
         torch.cuda.synchronize()
+        ctx.stage_stats(reset=True)
         t0 = time.perf_counter()
         q = queue.Queue()
 
@@ -388,11 +389,16 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
         th.join()
         ctx.sync()
         times.append(time.perf_counter() - t0)
+        lane.append(ctx.stage_stats())
     best = min(times)
+    cs, ws, nb, _ = lane[times.index(best)]
     pix = 1.25 * W * pb
     return {"value": pix / best / 1e6, "unit": "Mpix/s", "ms_per_pass": best * 1e3, "passes": reps,
             "bytes_up": int(host_pan.nbytes + host_mss.nbytes), "bytes_down": int(host_out.nbytes),
             "host_copy_threads": oip.load_library().oip_stage_threads(),
+            "upload_lane": {"seconds_in_pageable_to_pinned_copies": cs, "seconds_waiting_for_a_ring_slot": ws, "GB": nb / 1e9,
+                            "note": "the uploader thread's own time (oip_stage_stats): copies into the pinned ring vs waiting for a "
+                                    "slot whose DMA has not finished -- the second is the link's share of the pass"},
             "what": "pageable host rasters -> pinned staging ring -> H2D (PAN in %d line blocks on a second thread: the lines of "
                     "the correlation sections first, the lines between them last) || RRC per block || correlation per section "
                     "as its lines land -> fit -> align -> staged D2H of the aligned image into pageable memory, under the rest of "

@@ -2164,7 +2164,8 @@ int correlate_units_vup(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, 
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
     {
         OipProfScope prof(ctx, "corr_rows_v_kernel");
-        long grid = 2L * ctx->cu_count;                     // two workgroups per CU (60 KB of LDS, <= 128 VGPRs each)
+        const char *eg = getenv("OIP_VROWS_WG_PER_CU");        // experiment knob: 1 = one workgroup per CU (what co-residency buys)
+        long grid = (eg && atoi(eg) == 1 ? 1L : 2L) * ctx->cu_count;   // two workgroups per CU (60 KB of LDS, <= 128 VGPRs each)
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
         if (N != 1250) return oip_fail(ctx, OIP_E_RUNTIME, "correlate_units_vup: no row stage for %d-point rows", N);
         for (int u = 0; u < nunits; ++u)

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
 // hides the line loads.  Price: the packed PAN line pair is read and transformed by both launches of a pair of units
 // (7 instead of 6 two-line transforms per pair, 2.7 instead of 2.3 GB).  Same arithmetic per bin as corr_rows_up_kernel
 // (same helpers, same order), so results agree to the last bits the pairing leaves.
-template <int NT>
+template <int NT, int PF>      // PF 1: the next PAN line pair is requested before the second output round (registers permitting)
 __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJob fj, int a0, int part, int M, int P, const int *__restrict__ ypos,
                                                                         const float2 *__restrict__ twF, const float2 *__restrict__ twS)
 {
@@ -1131,12 +1131,9 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
     const float2 *znb = fj.zn + (long)a0 * fj.zn_stride;
     const uint2 *rawb = fj.raw16 + (long)a0 * (S / 2);
     // line pair ky / -ky: PAN lines into the full-width buffer, the two narrow arrays (vertical expansion on the way) into theirs
-    auto load_lines = [&](int tid, int k) {
+    float4 la[NIT2], lb[NIT2];
+    auto fetch_pan = [&](int tid, int k) {
         const long n1 = ypos[k], n2 = ypos[k ? M - k : 0];
-        const long m1 = fj.ypos_s[k % fj.m], m2 = fj.ypos_s[(k ? M - k : 0) % fj.m];
-        float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
-        uint2 rawreg[NITN][4];
-        float2 vt[5];
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
             int q = tid + it * NT;
@@ -1144,6 +1141,13 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
             lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
         }
+    };
+    auto load_lines = [&](int tid, int k, bool pan_fetched) {
+        const long m1 = fj.ypos_s[k % fj.m], m2 = fj.ypos_s[(k ? M - k : 0) % fj.m];
+        float4 na[NITN], nb[NITN];
+        uint2 rawreg[NITN][4];
+        float2 vt[5];
+        if (!pan_fetched) fetch_pan(tid, k);
 #pragma unroll
         for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + k];
 #pragma unroll
@@ -1195,7 +1199,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             }
         }
     };
-    load_lines(threadIdx.x, ky);
+    load_lines(threadIdx.x, ky, false);
     __syncthreads();
     for (; ky <= half; ky += gridDim.x) {
         int tid = threadIdx.x;
@@ -1215,9 +1219,11 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             }
         }
         __syncthreads();                        // every reader of the PAN lines is done: the buffer takes the outputs
+        const int kn = ky + gridDim.x;
 #pragma unroll 1
         for (int h = 0; h < 2; ++h) {
             const float2 *zn = bufN + h * 2 * S;
+            if (PF && h == 1 && kn <= half && !(dbg & 8)) fetch_pan(tid, kn);       // in flight under the second round
             if (!(dbg & 2)) {
                 float2 e0[4], e1[4];
 #pragma unroll
@@ -1301,8 +1307,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
                 }
             }
         }
-        const int kn = ky + gridDim.x;
-        if (kn <= half) load_lines(tid, kn);
+        if (kn <= half) load_lines(tid, kn, PF && !(dbg & 8));
         __syncthreads();
     }
 }
@@ -2308,8 +2313,15 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
         OipProfScope prof(ctx, "corr_rows_up1_kernel");
         long grid = 2L * ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
-        for (int u = 0; u < nunits; ++u)
-            hipLaunchKernelGGL((corr_rows_up1_kernel<512>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
+        const char *ev = getenv("OIP_UP1");                             // experiment knob: threads * 10 + prefetch (5120, 5121, 3840, 3841)
+        const int variant = ev ? atoi(ev) : 5120;
+        for (int u = 0; u < nunits; ++u) {
+            const dim3 g((unsigned)grid);
+            if (variant == 5121) hipLaunchKernelGGL((corr_rows_up1_kernel<512, 1>), g, dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
+            else if (variant == 3840) hipLaunchKernelGGL((corr_rows_up1_kernel<384, 0>), g, dim3(384), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
+            else if (variant == 3841) hipLaunchKernelGGL((corr_rows_up1_kernel<384, 1>), g, dim3(384), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
+            else hipLaunchKernelGGL((corr_rows_up1_kernel<512, 0>), g, dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
+        }
         OIP_HIP(ctx, hipGetLastError());
     } else {
         OipProfScope prof(ctx, "corr_rows_up_kernel");

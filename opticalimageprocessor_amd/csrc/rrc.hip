@@ -240,10 +240,17 @@ __global__ __launch_bounds__(kBlock) void mss_split_rrc_scalar_kernel(const uint
 // lines in flight; the last group of a window whose width is not a multiple of 8 stores its pixels one by one.
 __global__ __launch_bounds__(kBlock) void rrc_u16_window_kernel(const uint16_t *__restrict__ src, long src_pitch, uint16_t *__restrict__ dst,
                                                                 long dst_pitch, int w, long h, const double2 *__restrict__ kb,
-                                                                long rows_per_block)
+                                                                long rows_per_block, int period)
 {
-    const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
-    if (x0 >= w) return;
+    // Store alignment decides the bandwidth (see the header of this file): a destination line pitch that is not a multiple
+    // of 128 bytes shifts every line against the cache lines.  Lines r = rho (mod period) share one shift
+    // (period = 128 / gcd(128, pitch bytes mod 128)), so blockIdx.z = rho owns those lines and starts its 8-column groups
+    // where THEIR cache lines start: every wave then stores one aligned KiB per line, while a lane still owns 8 fixed
+    // columns (LUT in registers).
+    const int rho = blockIdx.z;
+    const int shift = (int)(((128u - (unsigned)(((uintptr_t)dst + (size_t)rho * (size_t)dst_pitch * 2) & 127u)) & 127u) >> 1);    // columns, multiple of 8
+    const int x0 = shift - 64 + (blockIdx.x * kBlock + threadIdx.x) * 8;
+    if (x0 < 0 || x0 >= w) return;
     double k[8], b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -252,11 +259,12 @@ __global__ __launch_bounds__(kBlock) void rrc_u16_window_kernel(const uint16_t *
         b[i] = p.y;
     }
     const bool whole = x0 + 8 <= w;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
+    const long r0 = (long)blockIdx.y * rows_per_block + rho;         // rows_per_block is a multiple of period
+    long r1 = (long)(blockIdx.y + 1) * rows_per_block;
     if (r1 > h) r1 = h;
     const uint16_t *s = src + r0 * src_pitch + x0;
     uint16_t *d = dst + r0 * dst_pitch + x0;
+    const long sstep = (long)period * src_pitch, dstep = (long)period * dst_pitch;
     auto put = [&](uint16_t *q, uint4 o) {
         if (whole) { *reinterpret_cast<uint4 *>(q) = o; return; }
         const unsigned wv[4] = {o.x, o.y, o.z, o.w};
@@ -266,19 +274,19 @@ __global__ __launch_bounds__(kBlock) void rrc_u16_window_kernel(const uint16_t *
     };
     // (a partial group still loads 16 bytes: the source window is followed by the rest of its line -- host-checked)
     long r = r0;
-    for (; r + kRowsInFlight <= r1; r += kRowsInFlight) {
+    for (; r + (long)(kRowsInFlight - 1) * period < r1; r += (long)kRowsInFlight * period) {
         uint4 v[kRowsInFlight];
 #pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u) v[u] = *reinterpret_cast<const uint4 *>(s + (long)u * src_pitch);
+        for (int u = 0; u < kRowsInFlight; ++u) v[u] = *reinterpret_cast<const uint4 *>(s + u * sstep);
 #pragma unroll
-        for (int u = 0; u < kRowsInFlight; ++u) put(d + (long)u * dst_pitch, rrc_vec<8>(v[u], k, b));
-        s += (long)kRowsInFlight * src_pitch;
-        d += (long)kRowsInFlight * dst_pitch;
+        for (int u = 0; u < kRowsInFlight; ++u) put(d + u * dstep, rrc_vec<8>(v[u], k, b));
+        s += kRowsInFlight * sstep;
+        d += kRowsInFlight * dstep;
     }
-    for (; r < r1; ++r) {
+    for (; r < r1; r += period) {
         put(d, rrc_vec<8>(*reinterpret_cast<const uint4 *>(s), k, b));
-        s += src_pitch;
-        d += dst_pitch;
+        s += sstep;
+        d += dstep;
     }
 }
 
@@ -375,10 +383,16 @@ extern "C" int oip_rrc_u16_window(oip_ctx *ctx, const uint16_t *d_src, long src_
     const bool vec = src_pitch % 8 == 0 && dst_pitch % 8 == 0 && (((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0 &&
                      (w % 8 == 0 || src_pitch >= (long)(w + 7) / 8 * 8);
     if (vec) {
-        int gx = ((w + 7) / 8 + kBlock - 1) / kBlock, gy;
+        long g = (dst_pitch * 2) % 128, t = 128;
+        while (g) { const long r = t % g; t = g; g = r; }
+        const int period = (int)(128 / t);                             // lines with the same shift against the cache lines
+        int gx = ((w + 7) / 8 + 8 + kBlock - 1) / kBlock, gy;          // + 8 groups: the shifted column origin
         long rpb;
-        row_blocks(ctx, gx, h, &rpb, &gy);
-        hipLaunchKernelGGL(rrc_u16_window_kernel, dim3(gx, gy), dim3(kBlock), 0, ctx->stream, d_src, src_pitch, d_dst, dst_pitch, w, h, kb, rpb);
+        row_blocks(ctx, gx * period, h, &rpb, &gy);
+        rpb = (rpb + period - 1) / period * period;
+        gy = (int)((h + rpb - 1) / rpb);
+        hipLaunchKernelGGL(rrc_u16_window_kernel, dim3(gx, gy, period), dim3(kBlock), 0, ctx->stream, d_src, src_pitch, d_dst, dst_pitch, w, h, kb,
+                           rpb, period);
     } else {
         const long n = (long)w * h;
         long blocks = (n + kBlock - 1) / kBlock;

@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
 // hides the line loads.  Price: the packed PAN line pair is read and transformed by both launches of a pair of units
 // (7 instead of 6 two-line transforms per pair, 2.7 instead of 2.3 GB).  Same arithmetic per bin as corr_rows_up_kernel
 // (same helpers, same order), so results agree to the last bits the pairing leaves.
-template <int NT, int PF>      // PF 1: the next PAN line pair is requested before the second output round (registers permitting)
+template <int NT, int PF>      // PF 1: experiment (the next PAN line pair requested before the second output round; spills at 512 threads)
 __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJob fj, int a0, int part, int M, int P, const int *__restrict__ ypos,
                                                                         const float2 *__restrict__ twF, const float2 *__restrict__ twS)
 {
@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
     __shared__ float2 edgeT[2][5];                                 // H, G_0..3 at kx = 0 and N/2
     float2 *bufN = buf + 2 * F;
     float4 *buf4 = reinterpret_cast<float4 *>(buf), *buf4N = reinterpret_cast<float4 *>(bufN);
-    const int dbg = fj.dbg;
+    const int dbg = fj.dbg & 255;
     const int half = M / 2;
     int ky = blockIdx.x;
     if (ky > half) return;
@@ -1130,10 +1130,23 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
     constexpr int NITN = (NQ + NT - 1) / NT;
     const float2 *znb = fj.zn + (long)a0 * fj.zn_stride;
     const uint2 *rawb = fj.raw16 + (long)a0 * (S / 2);
-    // line pair ky / -ky: PAN lines into the full-width buffer, the two narrow arrays (vertical expansion on the way) into theirs
-    float4 la[NIT2], lb[NIT2];
-    auto fetch_pan = [&](int tid, int k) {
+    // The two workgroups of a CU start together and run the same phases: left alone they load together and compute together
+    // (measured: the kernel's time was the SUM of its memory-only and compute-only times).  The second half of the grid -- the
+    // workgroups that take the CUs' second slots -- starts half an iteration late, so one workgroup's line traffic runs under
+    // the other's butterflies.  (Placement is not guaranteed; a different placement only loses the benefit.)
+    {
+        const int naps = (fj.dbg >> 8) & 255;
+        if (blockIdx.x >= gridDim.x / 2)
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    // Vector-memory operations complete in order, so a load waits for every older store: the loads of the NEXT line pair are
+    // issued before the stores of the last output, and the tables of the second round before the stores of the first.
+    float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
+    uint2 rawreg[NITN][4];
+    float2 vt[5];
+    auto fetch = [&](int tid, int k) __attribute__((always_inline)) {
         const long n1 = ypos[k], n2 = ypos[k ? M - k : 0];
+        const long m1 = fj.ypos_s[k % fj.m], m2 = fj.ypos_s[(k ? M - k : 0) % fj.m];
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
             int q = tid + it * NT;
@@ -1141,13 +1154,6 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
             lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
         }
-    };
-    auto load_lines = [&](int tid, int k, bool pan_fetched) {
-        const long m1 = fj.ypos_s[k % fj.m], m2 = fj.ypos_s[(k ? M - k : 0) % fj.m];
-        float4 na[NITN], nb[NITN];
-        uint2 rawreg[NITN][4];
-        float2 vt[5];
-        if (!pan_fetched) fetch_pan(tid, k);
 #pragma unroll
         for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + k];
 #pragma unroll
@@ -1161,6 +1167,8 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
 #pragma unroll
             for (int r = 0; r < 4; ++r) rawreg[it][r] = rawb[(long)r * (4 * (S / 2)) + q];
         }
+    };
+    auto commit = [&](int tid) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < NIT2; ++it) {
             const int q = tid + it * NT;
@@ -1199,13 +1207,16 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             }
         }
     };
-    load_lines(threadIdx.x, ky, false);
+    fetch(threadIdx.x, ky);
+    commit(threadIdx.x);
     __syncthreads();
     for (; ky <= half; ky += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const long s1 = ypos[ky], s2 = ypos[ky ? M - ky : 0];
         const bool pair = s1 != s2;
+        const int kn = ky + gridDim.x;
+        const bool more = kn <= half;
         if (!(dbg & 1)) oipfft::StagesDual3<F, 1, S, 2, NT, 25, 15, 8, 2>::run(buf, tw, bufN, tws, tid);
         // this unit's PAN spectrum at the thread's bins ([2 r]: bin kx, [2 r + 1]: bin N - kx); edge columns also to edgeA
         float2 A[2 * NB];
@@ -1219,72 +1230,70 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
             }
         }
         __syncthreads();                        // every reader of the PAN lines is done: the buffer takes the outputs
-        const int kn = ky + gridDim.x;
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
+        float4 ya[NIT2], yb[NIT2];
+        auto xround = [&](int h) __attribute__((always_inline)) {
             const float2 *zn = bufN + h * 2 * S;
-            if (PF && h == 1 && kn <= half && !(dbg & 8)) fetch_pan(tid, kn);       // in flight under the second round
-            if (!(dbg & 2)) {
-                float2 e0[4], e1[4];
+            if (dbg & 2) return;
+            float2 e0[4], e1[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { e0[j] = edge[h][0][j]; e1[j] = edge[h][1][j]; }
+            for (int j = 0; j < 4; ++j) { e0[j] = edge[h][0][j]; e1[j] = edge[h][1][j]; }
 #pragma unroll
-                for (int r = 0; r < NB; ++r) {
-                    const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
-                    if (kx > F / 2) continue;
-                    const int kc = kx <= F / 2 ? kx : 0;
-                    const float2 Hr = fj.xtab[kc];
-                    float2 Gr[4];
+            for (int r = 0; r < NB; ++r) {
+                const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
+                if (kx > F / 2) continue;
+                const int c = kx % S, cm = c ? S - c : 0;
+                // H and G of this bin from the L2-resident table (no store is pending when a round starts: see the order below)
+                const float2 Hr = fj.xtab[kx];
+                float2 Gr[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Gr[j] = fj.xtab[(1 + j) * F + kc];
-                    const int c = kx % S, cm = c ? S - c : 0;
-                    float2 S0 = make_float2(0.f, 0.f), T0 = S0, S1 = S0, T1 = S0;
+                for (int j = 0; j < 4; ++j) Gr[j] = fj.xtab[(1 + j) * F + kx];
+                float2 S0 = make_float2(0.f, 0.f), T0 = S0, S1 = S0, T1 = S0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        S0 = sfma(Gr[j].x, e0[j], S0); T0 = sfma(Gr[j].y, e0[j], T0);
-                        S1 = sfma(Gr[j].x, e1[j], S1); T1 = sfma(Gr[j].y, e1[j], T1);
-                    }
-                    {
-                        const float2 Z0 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c]), S0), T0);
-                        const float2 Z1 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm + 1]), S1), T1);
-                        const float2 C1 = cross_power_bin_fast(A[2 * r], spec2_of(0, Z0, Z1), false, false);
-                        const float2 C2 = cross_power_bin_fast(A[2 * r], spec2_of(1, Z0, Z1), false, false);
-                        buf[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                        buf[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
-                    }
-                    if (kx != 0 && 2 * kx != F) {
-                        const float2 Z0 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm]), S0), T0);
-                        const float2 Z1 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c + 1]), S1), T1);
-                        const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec2_of(0, Z0, Z1), false, false);
-                        const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec2_of(1, Z0, Z1), false, false);
-                        buf[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                        buf[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 4; ++j) {
+                    S0 = sfma(Gr[j].x, e0[j], S0); T0 = sfma(Gr[j].y, e0[j], T0);
+                    S1 = sfma(Gr[j].x, e1[j], S1); T1 = sfma(Gr[j].y, e1[j], T1);
                 }
-                // the two edge columns again with divSpectrums' own formulas (two threads of the block)
-#pragma unroll 1
-                for (int r = 0; r < NB; ++r) {
-                    const int kx = tid + NT * r;
-                    if (kx != 0 && 2 * kx != F) continue;
-                    const bool real_bin = ky == 0 || 2 * ky == M;
-                    const float2 Ae = edgeA[kx ? 1 : 0];
-                    float2 He = edgeT[kx ? 1 : 0][0], Ge[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) Ge[j] = edgeT[kx ? 1 : 0][1 + j];
-                    float2 Z0 = oipfft::cmul(He, zn[0]), Z1 = cmulj(He, zn[1]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { Z0 = cfma(Ge[j], edge[h][0][j], Z0); Z1 = cfmaj(Ge[j], edge[h][1][j], Z1); }
-                    const float2 C1 = cross_power_bin(Ae, spec2_of(0, Z0, Z1), real_bin, true);
-                    const float2 C2 = cross_power_bin(Ae, spec2_of(1, Z0, Z1), real_bin, true);
+                {
+                    const float2 Z0 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c]), S0), T0);
+                    const float2 Z1 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm + 1]), S1), T1);
+                    const float2 C1 = cross_power_bin_fast(A[2 * r], spec2_of(0, Z0, Z1), false, false);
+                    const float2 C2 = cross_power_bin_fast(A[2 * r], spec2_of(1, Z0, Z1), false, false);
                     buf[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                    buf[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+                }
+                if (kx != 0 && 2 * kx != F) {
+                    const float2 Z0 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm]), S0), T0);
+                    const float2 Z1 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c + 1]), S1), T1);
+                    const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec2_of(0, Z0, Z1), false, false);
+                    const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec2_of(1, Z0, Z1), false, false);
+                    buf[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
                     buf[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // the two edge columns again with divSpectrums' own formulas (two threads of the block)
+#pragma unroll 1
+            for (int r = 0; r < NB; ++r) {
+                const int kx = tid + NT * r;
+                if (kx != 0 && 2 * kx != F) continue;
+                const bool real_bin = ky == 0 || 2 * ky == M;
+                const float2 Ae = edgeA[kx ? 1 : 0];
+                float2 He = edgeT[kx ? 1 : 0][0], Ge[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Ge[j] = edgeT[kx ? 1 : 0][1 + j];
+                float2 Z0 = oipfft::cmul(He, zn[0]), Z1 = cmulj(He, zn[1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { Z0 = cfma(Ge[j], edge[h][0][j], Z0); Z1 = cfmaj(Ge[j], edge[h][1][j], Z1); }
+                const float2 C1 = cross_power_bin(Ae, spec2_of(0, Z0, Z1), real_bin, true);
+                const float2 C2 = cross_power_bin(Ae, spec2_of(1, Z0, Z1), real_bin, true);
+                buf[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
+                buf[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
+            }
+        };
+        auto finish = [&]() __attribute__((always_inline)) {                   // inverse row transform of the buffer; results to registers
             __syncthreads();
             asm volatile("" : "+v"(tid));
             if (!(dbg & 4)) oipfft::StagesAll<F, NT, 1, 1, 25, 15, 8>::run(buf, tw, tid);
-            float4 ya[NIT2], yb[NIT2];
 #pragma unroll
             for (int it = 0; it < NIT2; ++it) {
                 const int q = tid + it * NT;
@@ -1295,19 +1304,51 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
                 }
             }
             __syncthreads();                    // the buffer is free for the next output (or the next line pair)
-            if (!(dbg & 16)) {
-                float2 *out = fj.out[a0 + h];
+        };
+        auto store = [&](int h) __attribute__((always_inline)) {
+            if (dbg & 16) return;
+            float2 *out = fj.out[a0 + h];
 #pragma unroll
-                for (int it = 0; it < NIT2; ++it) {
-                    const int q = tid + it * NT;
-                    if (q < F / 2) {
-                        *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = ya[it];
-                        if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = yb[it];
-                    }
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < F / 2) {
+                    *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = ya[it];
+                    if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = yb[it];
+                }
+            }
+        };
+        // Order of the memory operations (they complete in order: a load waits for every older store).  The first output's
+        // lines stay in registers while the second output is formed -- its table loads then find no store pending -- and
+        // are stored before the second inverse transform, which covers their drain; the NEXT line pair is requested before
+        // the second output's stores.
+        xround(0);
+        finish();
+        float4 y0a[NIT2], y0b[NIT2];
+#pragma unroll
+        for (int it = 0; it < NIT2; ++it) { y0a[it] = ya[it]; y0b[it] = yb[it]; }
+        xround(1);
+        if (!(dbg & 16)) {
+            float2 *out = fj.out[a0];
+#pragma unroll
+            for (int it = 0; it < NIT2; ++it) {
+                const int q = tid + it * NT;
+                if (q < F / 2) {
+                    *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = y0a[it];
+                    if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = y0b[it];
                 }
             }
         }
-        if (kn <= half) load_lines(tid, kn, PF && !(dbg & 8));
+        finish();
+        // (one branch around fetch AND commit: under two separate tests of `more` the compiler keeps the line registers
+        // alive around the whole loop -- 155 spilled registers)
+        if (more) {
+            fetch(tid, kn);
+            __builtin_amdgcn_sched_barrier(0);
+            store(1);
+            commit(tid);
+        } else {
+            store(1);
+        }
         __syncthreads();
     }
 }

@@ -757,6 +757,7 @@ struct UpRowsJob {
     const uint2 *raw16;     // [4 rows][4 arrays x n / 2]: (bX | bY << 16) of two neighbouring points
     const int *ypos_s;      // row position of frequency line k in zn, k in [0, m)
     int m;
+    int *cu_slots;          // corr_rows_up1_kernel, experiment: zeroed [2048] arrival counters, one per CU (which of a CU's workgroups am I?)
 };
 
 // conj(a) b, acc + a b, acc + conj(a) b on packed-f32 instructions (two each; operand selection as in oipfft::cmul).
@@ -1136,8 +1137,18 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJ
     // the other's butterflies.  (Placement is not guaranteed; a different placement only loses the benefit.)
     {
         const int naps = (fj.dbg >> 8) & 255;
-        if (blockIdx.x >= gridDim.x / 2)
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        if (naps && fj.cu_slots) {
+            // which CU is this?  HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
+            __shared__ int my_slot;
+            if (threadIdx.x == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
+                const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
+                my_slot = atomicAdd(&fj.cu_slots[key], 1);
+            }
+            __syncthreads();
+            if (my_slot & 1)
+                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
     }
     // Vector-memory operations complete in order, so a load waits for every older store: the loads of the NEXT line pair are
     // issued before the stores of the last output, and the tables of the second round before the stores of the first.
@@ -2348,12 +2359,18 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
     fj.ypos_s = ypos_s;
     fj.m = band_rows;
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
-    const char *es = getenv("OIP_UP_SPLIT");                            // experiment knob: 0 = one launch per pair (corr_rows_up_kernel)
-    if (up.vtab && !(es && atoi(es) == 0)) {
+    const char *es = getenv("OIP_UP_SPLIT");                            // experiment knob: 1 = one launch per unit, two workgroups per CU
+    if (up.vtab && es && atoi(es) == 1) {
         // one launch per unit, two workgroups per CU (see corr_rows_up1_kernel)
         OipProfScope prof(ctx, "corr_rows_up1_kernel");
         long grid = 2L * ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
+        if ((fj.dbg >> 8) & 255) {
+            // the stagger experiment: per-CU arrival counters in the (otherwise unused) f32 scratch of the image-domain route
+            fj.cu_slots = reinterpret_cast<int *>(w.fa);
+            ctx->prof_chain = nullptr;
+            OIP_HIP(ctx, hipMemsetAsync(fj.cu_slots, 0, 2048 * sizeof(int), ctx->stream));
+        }
         const char *ev = getenv("OIP_UP1");                             // experiment knob: threads * 10 + prefetch (5120, 5121, 3840, 3841)
         const int variant = ev ? atoi(ev) : 5120;
         for (int u = 0; u < nunits; ++u) {

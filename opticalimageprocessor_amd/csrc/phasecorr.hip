@@ -757,7 +757,6 @@ struct UpRowsJob {
     const uint2 *raw16;     // [4 rows][4 arrays x n / 2]: (bX | bY << 16) of two neighbouring points
     const int *ypos_s;      // row position of frequency line k in zn, k in [0, m)
     int m;
-    int *cu_slots;          // corr_rows_up1_kernel, experiment: zeroed [2048] arrival counters, one per CU (which of a CU's workgroups am I?)
 };
 
 // conj(a) b, acc + a b, acc + conj(a) b on packed-f32 instructions (two each; operand selection as in oipfft::cmul).
@@ -1089,277 +1088,6 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         __builtin_amdgcn_sched_barrier(0);
         if (fj.nout == 4) store(2);
         s1 = n1; s2 = n2;
-        __syncthreads();
-    }
-}
-
-// ---- the same row stage, ONE unit per launch, two workgroups per CU ------------------------------------------------
-// corr_rows_up_kernel holds 150 KB of LDS, so one workgroup owns a CU and every barrier, every LDS round trip and every
-// wait for a line is idle time of the whole CU (40 % of its wave cycles).  The 1250-point kernel of the 12288-wide geometry
-// showed what co-residency buys: the same launch with two workgroups per CU instead of one runs 1.45 x faster
-// (profiles/experiments/r03_sweep5_vrows_wg_per_cu.txt).  This variant makes room for that at 3000 points: a launch serves
-// ONE unit (its PAN image = slot `part` of the packed PAN line pair, its two band-pair arrays a0, a0 + 1), the PAN spectra of
-// the thread's bins go to registers after the forward transforms, and the two outputs are formed, inverse-transformed and
-// stored ONE AFTER THE OTHER in the PAN buffer: 48 KB + 24 KB of narrow lines = 72 KB + tables, <= 128 VGPRs -> two
-// workgroups of 512 threads per CU, four waves per SIMD.  Nothing is prefetched into registers: the other workgroup's work
-// hides the line loads.  Price: the packed PAN line pair is read and transformed by both launches of a pair of units
-// (7 instead of 6 two-line transforms per pair, 2.7 instead of 2.3 GB).  Same arithmetic per bin as corr_rows_up_kernel
-// (same helpers, same order), so results agree to the last bits the pairing leaves.
-template <int NT, int PF>      // PF 1: experiment (the next PAN line pair requested before the second output round; spills at 512 threads)
-__global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_up1_kernel(UpRowsJob fj, int a0, int part, int M, int P, const int *__restrict__ ypos,
-                                                                        const float2 *__restrict__ twF, const float2 *__restrict__ twS)
-{
-    constexpr int F = 3000, S = F / 4;
-    constexpr int TWF = oipfft::TwTable<F, 25, 15, 8>::value(), TWS = oipfft::TwTable<S, 25, 15, 2>::value();
-    constexpr int NB = (F / 2 + 1 + NT - 1) / NT;
-    __shared__ __align__(16) float2 buf[2 * F + 2 * 2 * S];        // PAN line pair / the output being formed | two narrow arrays; [point][line]
-    __shared__ float2 tw[TWF], tws[TWS];
-    __shared__ float2 edge[2][2][4];                               // [array][line][j]: narrow line samples 0, 1, S-2, S-1
-    __shared__ float2 edgeA[2];                                    // this unit's PAN spectrum at kx = 0 and N/2
-    __shared__ float2 edgeT[2][5];                                 // H, G_0..3 at kx = 0 and N/2
-    float2 *bufN = buf + 2 * F;
-    float4 *buf4 = reinterpret_cast<float4 *>(buf), *buf4N = reinterpret_cast<float4 *>(bufN);
-    const int dbg = fj.dbg & 255;
-    const int half = M / 2;
-    int ky = blockIdx.x;
-    if (ky > half) return;
-    for (int i = threadIdx.x; i < TWF; i += NT) tw[i] = twF[i];
-    for (int i = threadIdx.x; i < TWS; i += NT) tws[i] = twS[i];
-    if (threadIdx.x < 10) edgeT[threadIdx.x / 5][threadIdx.x % 5] = fj.xtab[(threadIdx.x % 5) * F + (threadIdx.x / 5) * (F / 2)];
-    constexpr int NIT2 = (F / 2 + NT - 1) / NT;
-    constexpr int NQ = 2 * (S / 2);                 // 16-byte pieces of one line of the two narrow arrays
-    constexpr int NITN = (NQ + NT - 1) / NT;
-    const float2 *znb = fj.zn + (long)a0 * fj.zn_stride;
-    const uint2 *rawb = fj.raw16 + (long)a0 * (S / 2);
-    // The two workgroups of a CU start together and run the same phases: left alone they load together and compute together
-    // (measured: the kernel's time was the SUM of its memory-only and compute-only times).  The second half of the grid -- the
-    // workgroups that take the CUs' second slots -- starts half an iteration late, so one workgroup's line traffic runs under
-    // the other's butterflies.  (Placement is not guaranteed; a different placement only loses the benefit.)
-    {
-        const int naps = (fj.dbg >> 8) & 255;
-        if (naps && fj.cu_slots) {
-            // which CU is this?  HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]; XCC_ID [3:0]
-            __shared__ int my_slot;
-            if (threadIdx.x == 0) {
-                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;
-                const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);
-                my_slot = atomicAdd(&fj.cu_slots[key], 1);
-            }
-            __syncthreads();
-            if (my_slot & 1)
-                for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-    // Vector-memory operations complete in order, so a load waits for every older store: the loads of the NEXT line pair are
-    // issued before the stores of the last output, and the tables of the second round before the stores of the first.
-    float4 la[NIT2], lb[NIT2], na[NITN], nb[NITN];
-    uint2 rawreg[NITN][4];
-    float2 vt[5];
-    auto fetch = [&](int tid, int k) __attribute__((always_inline)) {
-        const long n1 = ypos[k], n2 = ypos[k ? M - k : 0];
-        const long m1 = fj.ypos_s[k % fj.m], m2 = fj.ypos_s[(k ? M - k : 0) % fj.m];
-#pragma unroll
-        for (int it = 0; it < NIT2; ++it) {
-            int q = tid + it * NT;
-            q = q < F / 2 ? q : F / 2 - 1;
-            la[it] = *reinterpret_cast<const float4 *>(fj.zp + n1 * P + 2 * q);
-            lb[it] = *reinterpret_cast<const float4 *>(fj.zp + n2 * P + 2 * q);
-        }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) vt[r] = fj.vtab[r * M + k];
-#pragma unroll
-        for (int it = 0; it < NITN; ++it) {
-            int q = tid + it * NT;
-            q = q < NQ ? q : NQ - 1;
-            const int a = q / (S / 2), i = q - a * (S / 2);
-            const float2 *z = znb + a * fj.zn_stride + 2 * i;
-            na[it] = *reinterpret_cast<const float4 *>(z + m1 * fj.Pn);
-            nb[it] = *reinterpret_cast<const float4 *>(z + m2 * fj.Pn);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rawreg[it][r] = rawb[(long)r * (4 * (S / 2)) + q];
-        }
-    };
-    auto commit = [&](int tid) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < NIT2; ++it) {
-            const int q = tid + it * NT;
-            if (q < F / 2) {
-                buf4[2 * q] = make_float4(la[it].x, la[it].y, lb[it].x, lb[it].y);
-                buf4[2 * q + 1] = make_float4(la[it].z, la[it].w, lb[it].z, lb[it].w);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NITN; ++it) {
-            const int q = tid + it * NT;
-            if (q < NQ) {
-                const int a = q / (S / 2), i = q - a * (S / 2);
-                if (!(dbg & 32)) {
-                    const float2 hv = vt[0];
-                    float2 x0 = oipfft::cmul(hv, make_float2(na[it].x, na[it].y)), x1 = oipfft::cmul(hv, make_float2(na[it].z, na[it].w));
-                    float2 y0 = cmulj(hv, make_float2(nb[it].x, nb[it].y)), y1 = cmulj(hv, make_float2(nb[it].z, nb[it].w));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float2 gv = vt[1 + r];
-                        const uint2 u = rawreg[it][r];
-                        const float2 w0 = make_float2((float)(u.x & 0xffffu), (float)(u.x >> 16)), w1 = make_float2((float)(u.y & 0xffffu), (float)(u.y >> 16));
-                        x0 = cfma(gv, w0, x0); x1 = cfma(gv, w1, x1);
-                        y0 = cfmaj(gv, w0, y0); y1 = cfmaj(gv, w1, y1);
-                    }
-                    na[it] = make_float4(x0.x, x0.y, x1.x, x1.y);
-                    nb[it] = make_float4(y0.x, y0.y, y1.x, y1.y);
-                }
-                buf4N[a * S + 2 * i] = make_float4(na[it].x, na[it].y, nb[it].x, nb[it].y);
-                buf4N[a * S + 2 * i + 1] = make_float4(na[it].z, na[it].w, nb[it].z, nb[it].w);
-                if (i == 0 || i == S / 2 - 1) {
-                    const int j = i ? 2 : 0;
-                    edge[a][0][j] = make_float2(na[it].x, na[it].y); edge[a][0][j + 1] = make_float2(na[it].z, na[it].w);
-                    edge[a][1][j] = make_float2(nb[it].x, nb[it].y); edge[a][1][j + 1] = make_float2(nb[it].z, nb[it].w);
-                }
-            }
-        }
-    };
-    fetch(threadIdx.x, ky);
-    commit(threadIdx.x);
-    __syncthreads();
-    for (; ky <= half; ky += gridDim.x) {
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const long s1 = ypos[ky], s2 = ypos[ky ? M - ky : 0];
-        const bool pair = s1 != s2;
-        const int kn = ky + gridDim.x;
-        const bool more = kn <= half;
-        if (!(dbg & 1)) oipfft::StagesDual3<F, 1, S, 2, NT, 25, 15, 8, 2>::run(buf, tw, bufN, tws, tid);
-        // this unit's PAN spectrum at the thread's bins ([2 r]: bin kx, [2 r + 1]: bin N - kx); edge columns also to edgeA
-        float2 A[2 * NB];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) {
-            const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
-            if (kx <= F / 2) {
-                A[2 * r] = spec_of(part, buf[2 * kx], buf[2 * nkx + 1]);
-                A[2 * r + 1] = spec_of(part, buf[2 * nkx], buf[2 * kx + 1]);
-                if (kx == 0 || 2 * kx == F) edgeA[kx ? 1 : 0] = A[2 * r];
-            }
-        }
-        __syncthreads();                        // every reader of the PAN lines is done: the buffer takes the outputs
-        float4 ya[NIT2], yb[NIT2];
-        auto xround = [&](int h) __attribute__((always_inline)) {
-            const float2 *zn = bufN + h * 2 * S;
-            if (dbg & 2) return;
-            float2 e0[4], e1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { e0[j] = edge[h][0][j]; e1[j] = edge[h][1][j]; }
-#pragma unroll
-            for (int r = 0; r < NB; ++r) {
-                const int kx = tid + NT * r, nkx = kx ? F - kx : 0;
-                if (kx > F / 2) continue;
-                const int c = kx % S, cm = c ? S - c : 0;
-                // H and G of this bin from the L2-resident table (no store is pending when a round starts: see the order below)
-                const float2 Hr = fj.xtab[kx];
-                float2 Gr[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Gr[j] = fj.xtab[(1 + j) * F + kx];
-                float2 S0 = make_float2(0.f, 0.f), T0 = S0, S1 = S0, T1 = S0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    S0 = sfma(Gr[j].x, e0[j], S0); T0 = sfma(Gr[j].y, e0[j], T0);
-                    S1 = sfma(Gr[j].x, e1[j], S1); T1 = sfma(Gr[j].y, e1[j], T1);
-                }
-                {
-                    const float2 Z0 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c]), S0), T0);
-                    const float2 Z1 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm + 1]), S1), T1);
-                    const float2 C1 = cross_power_bin_fast(A[2 * r], spec2_of(0, Z0, Z1), false, false);
-                    const float2 C2 = cross_power_bin_fast(A[2 * r], spec2_of(1, Z0, Z1), false, false);
-                    buf[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                    buf[2 * nkx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
-                }
-                if (kx != 0 && 2 * kx != F) {
-                    const float2 Z0 = oipfft::cadd_rot(oipfft::cadd(cmulj(Hr, zn[2 * cm]), S0), T0);
-                    const float2 Z1 = oipfft::csub_rot(oipfft::cadd(oipfft::cmul(Hr, zn[2 * c + 1]), S1), T1);
-                    const float2 C1 = cross_power_bin_fast(A[2 * r + 1], spec2_of(0, Z0, Z1), false, false);
-                    const float2 C2 = cross_power_bin_fast(A[2 * r + 1], spec2_of(1, Z0, Z1), false, false);
-                    buf[2 * nkx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                    buf[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the two edge columns again with divSpectrums' own formulas (two threads of the block)
-#pragma unroll 1
-            for (int r = 0; r < NB; ++r) {
-                const int kx = tid + NT * r;
-                if (kx != 0 && 2 * kx != F) continue;
-                const bool real_bin = ky == 0 || 2 * ky == M;
-                const float2 Ae = edgeA[kx ? 1 : 0];
-                float2 He = edgeT[kx ? 1 : 0][0], Ge[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Ge[j] = edgeT[kx ? 1 : 0][1 + j];
-                float2 Z0 = oipfft::cmul(He, zn[0]), Z1 = cmulj(He, zn[1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { Z0 = cfma(Ge[j], edge[h][0][j], Z0); Z1 = cfmaj(Ge[j], edge[h][1][j], Z1); }
-                const float2 C1 = cross_power_bin(Ae, spec2_of(0, Z0, Z1), real_bin, true);
-                const float2 C2 = cross_power_bin(Ae, spec2_of(1, Z0, Z1), real_bin, true);
-                buf[2 * kx] = make_float2(C1.x - C2.y, -(C1.y + C2.x));
-                buf[2 * kx + 1] = pair ? make_float2(C1.x + C2.y, -(C2.x - C1.y)) : make_float2(0.f, 0.f);
-            }
-        };
-        auto finish = [&]() __attribute__((always_inline)) {                   // inverse row transform of the buffer; results to registers
-            __syncthreads();
-            asm volatile("" : "+v"(tid));
-            if (!(dbg & 4)) oipfft::StagesAll<F, NT, 1, 1, 25, 15, 8>::run(buf, tw, tid);
-#pragma unroll
-            for (int it = 0; it < NIT2; ++it) {
-                const int q = tid + it * NT;
-                if (q < F / 2) {
-                    const float4 u = buf4[2 * q], v = buf4[2 * q + 1];
-                    ya[it] = make_float4(u.x, -u.y, v.x, -v.y);
-                    yb[it] = make_float4(u.z, -u.w, v.z, -v.w);
-                }
-            }
-            __syncthreads();                    // the buffer is free for the next output (or the next line pair)
-        };
-        auto store = [&](int h) __attribute__((always_inline)) {
-            if (dbg & 16) return;
-            float2 *out = fj.out[a0 + h];
-#pragma unroll
-            for (int it = 0; it < NIT2; ++it) {
-                const int q = tid + it * NT;
-                if (q < F / 2) {
-                    *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = ya[it];
-                    if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = yb[it];
-                }
-            }
-        };
-        // Order of the memory operations (they complete in order: a load waits for every older store).  The first output's
-        // lines stay in registers while the second output is formed -- its table loads then find no store pending -- and
-        // are stored before the second inverse transform, which covers their drain; the NEXT line pair is requested before
-        // the second output's stores.
-        xround(0);
-        finish();
-        float4 y0a[NIT2], y0b[NIT2];
-#pragma unroll
-        for (int it = 0; it < NIT2; ++it) { y0a[it] = ya[it]; y0b[it] = yb[it]; }
-        xround(1);
-        if (!(dbg & 16)) {
-            float2 *out = fj.out[a0];
-#pragma unroll
-            for (int it = 0; it < NIT2; ++it) {
-                const int q = tid + it * NT;
-                if (q < F / 2) {
-                    *reinterpret_cast<float4 *>(out + s1 * P + 2 * q) = y0a[it];
-                    if (pair) *reinterpret_cast<float4 *>(out + s2 * P + 2 * q) = y0b[it];
-                }
-            }
-        }
-        finish();
-        // (one branch around fetch AND commit: under two separate tests of `more` the compiler keeps the line registers
-        // alive around the whole loop -- 155 spilled registers)
-        if (more) {
-            fetch(tid, kn);
-            __builtin_amdgcn_sched_barrier(0);
-            store(1);
-            commit(tid);
-        } else {
-            store(1);
-        }
         __syncthreads();
     }
 }
@@ -2359,29 +2087,7 @@ int correlate_units_up(oip_ctx *ctx, const OipFft2dPlan *pl, const UpPath &up, c
     fj.ypos_s = ypos_s;
     fj.m = band_rows;
     { const char *e = getenv("OIP_ROWS_DBG"); fj.dbg = e ? atoi(e) : 0; }
-    const char *es = getenv("OIP_UP_SPLIT");                            // experiment knob: 1 = one launch per unit, two workgroups per CU
-    if (up.vtab && es && atoi(es) == 1) {
-        // one launch per unit, two workgroups per CU (see corr_rows_up1_kernel)
-        OipProfScope prof(ctx, "corr_rows_up1_kernel");
-        long grid = 2L * ctx->cu_count;
-        if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;
-        if ((fj.dbg >> 8) & 255) {
-            // the stagger experiment: per-CU arrival counters in the (otherwise unused) f32 scratch of the image-domain route
-            fj.cu_slots = reinterpret_cast<int *>(w.fa);
-            ctx->prof_chain = nullptr;
-            OIP_HIP(ctx, hipMemsetAsync(fj.cu_slots, 0, 2048 * sizeof(int), ctx->stream));
-        }
-        const char *ev = getenv("OIP_UP1");                             // experiment knob: threads * 10 + prefetch (5120, 5121, 3840, 3841)
-        const int variant = ev ? atoi(ev) : 5120;
-        for (int u = 0; u < nunits; ++u) {
-            const dim3 g((unsigned)grid);
-            if (variant == 5121) hipLaunchKernelGGL((corr_rows_up1_kernel<512, 1>), g, dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
-            else if (variant == 3840) hipLaunchKernelGGL((corr_rows_up1_kernel<384, 0>), g, dim3(384), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
-            else if (variant == 3841) hipLaunchKernelGGL((corr_rows_up1_kernel<384, 1>), g, dim3(384), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
-            else hipLaunchKernelGGL((corr_rows_up1_kernel<512, 0>), g, dim3(512), 0, ctx->stream, fj, 2 * u, u, pl->M, pl->P, pl->d_ypos, twF, twS);
-        }
-        OIP_HIP(ctx, hipGetLastError());
-    } else {
+    {
         OipProfScope prof(ctx, "corr_rows_up_kernel");
         long grid = ctx->cu_count;
         if (grid > pl->M / 2 + 1) grid = pl->M / 2 + 1;

@@ -70,10 +70,8 @@ __global__ void shift_rows_kernel(RowInfo *rows, OipShiftGeom g, long out_row0, 
     }
 }
 
-// kb != nullptr: the source is the RAW strip and every sample is corrected on load (IMO::InplaceRRC's pixel, exact) -- the
-// fused prestitch -> stitch form, where .RRC.RAW of CCD 2 is not materialised either
 __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, int row, int W, const int c[4],
-                                             unsigned xmask, float out[4], const double2 *__restrict__ kb)
+                                             unsigned xmask, float out[4])
 {
     if (row < 0) {
         out[0] = out[1] = out[2] = out[3] = 0.f;
@@ -81,18 +79,14 @@ __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, i
     }
     const uint16_t *p = src + (long)row * W;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned v = (xmask & (1u << j)) ? (unsigned)p[c[j]] : 0u;
-        if (kb && (xmask & (1u << j))) { const double2 q = kb[c[j]]; v = oip_rrc_px(q.x, q.y, v); }
-        out[j] = (float)v;
-    }
+    for (int j = 0; j < 4; ++j) out[j] = (xmask & (1u << j)) ? (float)p[c[j]] : 0.f;
 }
 
 // one output column over a run of output lines (4x4 register window, one new source line per
 // output line): the general path -- any width, any alignment, every border case
 __device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                              const RowInfo *__restrict__ rows, int W, double dx, const float *__restrict__ tab1d,
-                             int x, long r0, long r1, const double2 *__restrict__ kb = nullptr)
+                             int x, long r0, long r1)
 {
     if (x < dw.col0) return;
     // stitcher.h:96  mapx = (float)(x + mDeltaX); imgwarp.cpp: sx = cvRound(mapx*32)
@@ -126,10 +120,10 @@ __device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, u
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[t][j] = v[t + 1][j];
             }
-            load_tap_row(src, ri.src[3], W, c, xmask, v[3], kb);
+            load_tap_row(src, ri.src[3], W, c, xmask, v[3]);
         } else if (!(ri.src[0] == cur[0] && ri.src[1] == cur[1] && ri.src[2] == cur[2] && ri.src[3] == cur[3])) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) load_tap_row(src, ri.src[t], W, c, xmask, v[t], kb);
+            for (int t = 0; t < 4; ++t) load_tap_row(src, ri.src[t], W, c, xmask, v[t]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) cur[t] = ri.src[t];
@@ -159,14 +153,14 @@ __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__r
                                                              uint16_t *__restrict__ dst, DstWin dw,
                                                              const RowInfo *__restrict__ rows, int W, long out_rows,
                                                              double dx, const float *__restrict__ tab1d,
-                                                             int rows_per_block, const double2 *__restrict__ kb)
+                                                             int rows_per_block)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if (x >= W) return;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
-    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1, kb);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
 }
 
 // ---- v2: 8 output pixels per lane ------------------------------------------------------------------
@@ -236,31 +230,15 @@ __device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src
     expand_f32(w, c0, g);
 }
 
-// RRC: the source is the raw strip; the 11 samples of every new source line are corrected on load.  The (k, b) pairs of the
-// block's source columns sit in LDS (33 KB: the lane's own 11 pairs in registers cost 44 VGPRs and spilled 61)
-template <bool RRC>
 __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                  const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                  long src_elems, double dx, const float *__restrict__ tab1d,
-                                                                 int rows_per_block, const double2 *__restrict__ kb)
+                                                                 int rows_per_block)
 {
-    constexpr int kLut = RRC ? kBlock * 8 + 32 : 1;
-    __shared__ double2 lut[kLut];
-    // source columns of the block: x + dx - 1 .. with a margin for the rounding of the map; clamped into the strip
-    const int cbase = blockIdx.x * kBlock * 8 + (int)floor(dx) - 8;
-    if (RRC) {
-        for (int i = threadIdx.x; i < kLut; i += kBlock) {
-            int c = cbase + i;
-            c = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
-            lut[i] = kb[c];
-        }
-        __syncthreads();
-    }
     const int x0 = (blockIdx.x * kBlock + threadIdx.x) * 8;
     if (x0 >= W || x0 + 8 <= dw.col0) return;
     int c0, fx0;
     if (!shift_group_regular(x0, W, dx, &c0, &fx0)) return;        // fix-up launch A
-    const int li = c0 - cbase;                                      // 0 <= li, li + 10 < kLut for every regular group
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
@@ -268,21 +246,6 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
-    auto expand = [&](const uint32_t w[6], float g[11]) __attribute__((always_inline)) {
-        expand_f32(w, c0, g);
-        if (RRC) {
-#pragma unroll
-            for (int q = 0; q < 11; ++q) {
-                const double2 p = lut[li + q];
-                g[q] = (float)oip_rrc_px(p.x, p.y, (unsigned)g[q]);
-            }
-        }
-    };
-    auto load_line = [&](int row, float g[11]) __attribute__((always_inline)) {
-        uint32_t w[6];
-        load_raw6(src, row, W, c0, src_elems, w);
-        expand(w, g);
-    };
     float win[4][11];                             // tap line t at unrolled step k lives in win[(k+t)&3]
     float w2d[16];
     int cur1 = -2, cur2 = -2, cur3 = -2;
@@ -298,11 +261,11 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
             if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B
             const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
             if (slide) {
-                if (ri.src[3] == nline) expand(nraw, win[(k + 3) & 3]);
-                else load_line(ri.src[3], win[(k + 3) & 3]);
+                if (ri.src[3] == nline) expand_f32(nraw, c0, win[(k + 3) & 3]);
+                else load_src_line11(src, ri.src[3], W, c0, src_elems, win[(k + 3) & 3]);
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) load_line(ri.src[t], win[(k + t) & 3]);
+                for (int t = 0; t < 4; ++t) load_src_line11(src, ri.src[t], W, c0, src_elems, win[(k + t) & 3]);
             }
             cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
             // the line the next output line will add in the regular case (its taps one line further down)
@@ -506,8 +469,7 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
 __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                 const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                 double dx, const float *__restrict__ tab1d,
-                                                                const int *__restrict__ groups, int rows_per_block,
-                                                                const double2 *__restrict__ kb)
+                                                                const int *__restrict__ groups, int rows_per_block)
 {
     const int x = groups[blockIdx.x] * 8 + (threadIdx.x & 7);
     if (x >= W) return;
@@ -518,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *
     const long rend = (long)(blockIdx.y + 1) * rows_per_block;
     if (r1 > rend) r1 = rend;
     if (r1 > out_rows) r1 = out_rows;
-    if (r0 < r1) remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1, kb);
+    if (r0 < r1) remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
 }
 
 // fix-up B: lines whose window touches a section border, all columns
@@ -526,14 +488,14 @@ __global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *
                                                                 const RowInfo *__restrict__ rows, int W, double dx,
                                                                 const float *__restrict__ tab1d,
                                                                 const int *__restrict__ bad_count,
-                                                                const int *__restrict__ bad_rows, const double2 *__restrict__ kb)
+                                                                const int *__restrict__ bad_rows)
 {
     int n = *bad_count;
     if (n > kMaxBadRows) n = kMaxBadRows;
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if ((int)blockIdx.y >= n || x >= W) return;
     const long r = bad_rows[blockIdx.y];
-    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r, r + 1, kb);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r, r + 1);
 }
 
 }  // namespace
@@ -590,10 +552,8 @@ extern "C" int oip_remap_shift_src_range(long out_row0, long out_rows, long L, d
 
 static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows, uint16_t *d_dst,
                             long out_row0, long out_rows, int W, long L, double dx, double dy, int section_rows,
-                            int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0, const double *d_kb = nullptr)
+                            int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0)
 {
-    const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
-    if (ctx && kb && f16acc) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_rrc_bicubic_u16_window: RRC on load is an fp32 form");
     OIP_CHECK_CTX(ctx);
     if (dst_pitch <= 0) { dst_pitch = W; dst_col0 = 0; dst_col_off = 0; }
     if (dst_col0 < 0 || dst_col0 >= W || dst_col_off < 0 || dst_col_off + (W - dst_col0) > dst_pitch)
@@ -666,16 +626,9 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
         {
-            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : (kb ? "remap_shift8_rrc_kernel" : "remap_shift8_kernel"));
-            if (f16acc)
-                hipLaunchKernelGGL(remap_shift8_f16_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
-                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
-            else if (kb)
-                hipLaunchKernelGGL(remap_shift8_kernel<true>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
-                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb);
-            else
-                hipLaunchKernelGGL(remap_shift8_kernel<false>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
-                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb);
+            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel");
+            hipLaunchKernelGGL(f16acc ? remap_shift8_f16_kernel : remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0,
+                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
         }
         if (!bad_groups.empty()) {
             OipProfScope prof(ctx, "remap_fix_cols_kernel");
@@ -683,13 +636,13 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
             long gy2 = (out_rows + rpb2 - 1) / rpb2;
             if (gy2 > 65535) { gy2 = 65535; rpb2 = (out_rows + gy2 - 1) / gy2; gy2 = (out_rows + rpb2 - 1) / rpb2; }
             hipLaunchKernelGGL(remap_fix_cols_kernel, dim3((unsigned)bad_groups.size(), (unsigned)gy2), dim3(kBlock), 0,
-                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2, kb);
+                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2);
         }
         {
             OipProfScope prof(ctx, "remap_fix_rows_kernel");
             const long nb = (long)g.nsec * 8 + g.ucut + g.bcut + 16;      // upper bound on listed lines
             hipLaunchKernelGGL(remap_fix_rows_kernel, dim3((W + kBlock - 1) / kBlock, (unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                               d_src, d_dst, dw, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows, kb);
+                               d_src, d_dst, dw, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows);
         }
     } else {
         OipProfScope prof(ctx, "remap_shift_kernel");
@@ -701,7 +654,7 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
         hipLaunchKernelGGL(remap_shift_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows,
-                           W, out_rows, dx, ctx->d_tab1d, (int)rpb, kb);
+                           W, out_rows, dx, ctx->d_tab1d, (int)rpb);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
@@ -733,16 +686,4 @@ extern "C" int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *
     if (ctx && dst_pitch <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_bicubic_u16_window: bad destination pitch");
     return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, f16acc != 0,
                             dst_pitch, dst_col0, dst_col_off);
-}
-
-// The same with the source being the RAW CCD-2 strip: every sample is corrected on load (IMO::InplaceRRC's pixel, exact;
-// d_kb: the W (k, b) pairs), so Stitcher::DoRRC of CCD 2, PreStitch and the right half of StitchBigRaw are ONE pass over the
-// strip and <pan2>.RRC.RAW is not materialised either.  fp32 only.  Bits are those of RRC followed by the plain call.
-extern "C" int oip_remap_shift_rrc_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src_raw, long src_row0, long src_rows, const double *d_kb,
-                                                      uint16_t *d_dst, long dst_pitch, int dst_col0, long dst_col_off, long out_row0,
-                                                      long out_rows, int W, long L, double dx, double dy, int section_rows, int row_guard)
-{
-    if (ctx && (dst_pitch <= 0 || !d_kb)) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_rrc_bicubic_u16_window: bad argument");
-    return remap_shift_impl(ctx, d_src_raw, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, false,
-                            dst_pitch, dst_col0, dst_col_off, d_kb);
 }

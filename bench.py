@@ -553,6 +553,8 @@ def summarise(env, d, p, elapsed, steps, prof_all, prof, dom):
             traffic = tsrc = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             tkey = "default" if p.workload == "weak5n" else p.workload
+            if p.workload == "prestitch" and getattr(p, "fused", False):
+                tkey = "prestitch_fused"
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 traffic = tj.get(tkey, {}).get(dom)

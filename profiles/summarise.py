@@ -35,12 +35,12 @@ def bench_name(kernel):
 
 
 for extra, dst in (("host_rrc.json", "%s_host_rrc.json"), ("staging_probe.txt", "%s_staging_probe.txt"),
-                   ("bench_prestitch_f16.json", "%s_bench_prestitch_f16.json")):
+                   ("bench_prestitch_f16.json", "%s_bench_prestitch_f16.json"), ("bench_w12288.json", "%s_bench_w12288.json")):
     h = os.path.join(out, extra)
     if os.path.exists(h) and os.path.getsize(h):
         shutil.copy(h, os.path.join(prof, dst % tag))
 raw, traffic = {}, {}
-for w in ("default", "prestitch", "rrc"):
+for w in ("default", "prestitch", "prestitch_fused", "rrc"):
     b = os.path.join(out, "bench_%s.json" % w)
     if os.path.exists(b):
         shutil.copy(b, os.path.join(prof, "%s_bench_%s.json" % (tag, w)))
@@ -88,7 +88,7 @@ about = ("HBM bytes per launch from rocprofv3 PMC counters on MI355X (gfx950, RO
          "(align, mss_split, the 2-byte PAN reads of the first FFT pass) are uncalibrated on the read side.  "
          "Raw: profiles/%s_pmc_raw.json" % tag)
 json.dump(raw, open(os.path.join(prof, "%s_pmc_raw.json" % tag), "w"), indent=1, sort_keys=True)
-t = {"_about": about}
+t = {"_about": about, "_source": {w: "profiles/%s_pmc_raw.json" % tag for w in traffic}}
 t.update(traffic)
 json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1, sort_keys=True)
 print("summaries written for", tag, {w: len(v) for w, v in traffic.items()})

@@ -410,19 +410,26 @@ template <int F, int NT, int NA, int Ns, int R, int... Rest> struct StagesPipe<F
 // as w^(n1) (w^A)^(n2) for composite radices so the chain stays four deep.
 template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
     static constexpr int NB = F / R;
-    static constexpr int ITEMS = NA * 2 * NB;
+    static constexpr bool POW2 = (NA & (NA - 1)) == 0;
+    // power-of-two buffer counts: item bits are  line | butterfly low 3 bits | buffer | butterfly high bits  (no division: a
+    // quarter of the row stage's vector instructions was integer arithmetic).  The 16 lanes that share a ds_write_b64 group
+    // then belong to ONE buffer: their stores (8 consecutive butterflies x 2 lines) hit 16 different even banks.  With the
+    // buffer bit below the butterfly bits (round 2) the two buffers of a group -- 2 F float2 = a multiple of 32 dwords apart --
+    // collided on every store (SQ_LDS_BANK_CONFLICT 37 % of the LDS cycles, profiles/r03_pmc_passes.json).  The 32 lanes of a
+    // ds_read_b64 group cover both buffers, which sit half the 64 banks apart.  Butterflies are dealt in blocks of 8, so a
+    // butterfly count that is not a multiple of 8 leaves a few slots empty.
+    static constexpr int NB8 = (NB + 7) / 8 * 8;
+    static constexpr int ITEMS = POW2 ? NA * 2 * NB8 : NA * 2 * NB;
     static constexpr int PER = (ITEMS + NT - 1) / NT;
     static constexpr int TWSTEP = F / (Ns * R);
     static constexpr int A = R == 15 ? 3 : (R == 25 ? 5 : 1);       // composite split R = A * B (1: plain radix)
+    static constexpr bool GUARD = POW2 && NB8 != NB;                // some slots hold no butterfly
     static __device__ __forceinline__ void decode(int item, int *base, int *b)
     {
-        if ((NA & (NA - 1)) == 0) {
-            // item bits: line | buffer | butterfly -- no division (a quarter of the row stage's vector instructions was
-            // integer arithmetic); a wave's accesses stay conflict-free: the two lines of a point are adjacent, the
-            // buffers half the banks apart (2 F float2 = 12000 dwords for F = 3000)
+        if (POW2) {
             constexpr int LA = NA == 1 ? 0 : (NA == 2 ? 1 : (NA == 4 ? 2 : 3));
-            *b = item >> (1 + LA);
-            *base = ((item >> 1) & (NA - 1)) * 2 * F + (item & 1);
+            *b = ((item >> 1) & 7) | ((item >> (4 + LA)) << 3);
+            *base = ((item >> 4) & (NA - 1)) * 2 * F + (item & 1);
             return;
         }
         const int a = item / (2 * NB), rem = item - a * (2 * NB);
@@ -437,6 +444,7 @@ template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
             if (ITEMS % NT == 0 || item < ITEMS) {
                 int base, b;
                 decode(item, &base, &b);
+                if (GUARD && b >= NB) continue;
 #pragma unroll
                 for (int m = 0; m < R; ++m) x[i][m] = buf[base + 2 * (b + m * NB)];
             }
@@ -450,6 +458,7 @@ template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
             if (ITEMS % NT == 0 || item < ITEMS) {
                 int base, b;
                 decode(item, &base, &b);
+                if (GUARD && b >= NB) continue;
                 const int k = b % Ns;
                 if (Ns > 1) {
                     const float2 w1 = tw[k * TWSTEP];

@@ -109,6 +109,9 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         "remap_shift8_f16_kernel": 4.0 * W * pb,
         "stitch_rows_kernel": 4.0 * 2 * (W - 100) * pb,       # 2 B read + 2 B written per output pixel
         "rrc_u16_window_kernel": 4.0 * (W - 100) * pb,        # the left half of the stitched raster straight from raw CCD 1
+        # raw CCD 2 in (corrected on load), the right half of the stitched raster out: 2 B read per source pixel of the columns
+        # that are stored + 2 B written
+        "remap_shift8_rrc_kernel": 4.0 * (W - 100) * pb,
     }
     return d
 

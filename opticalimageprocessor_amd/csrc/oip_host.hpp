@@ -798,8 +798,8 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
     OLOG("    dx: %.5f, dy: %.5f, r: %.5f", dx, dy, resp);
     if (o.panOnly) {
         // stitched PAN alone: no corrected strip is needed afterwards, so the left half of every stitched line is the RRC of
-        // the raw CCD-1 line (oip_rrc_u16_window) and the right half the resampled CCD-2 line (oip_remap_shift_bicubic_u16_window
-        // on the corrected CCD 2): <pan1>.RRC.RAW and .RRC.PRESTT.RAW are never materialised.  Same bits as the flow below.
+        // the raw CCD-1 line (oip_rrc_u16_window) and the right half the resampled CCD-2 line, corrected on load
+        // (oip_remap_shift_rrc_bicubic_u16_window): neither .RRC.RAW nor .RRC.PRESTT.RAW is materialised.  Same bits as the flow below.
         const int fold = o.foldColsPAN / 2;
         if (fold < 0 || fold >= W) throw std::invalid_argument("fold columns exceed the image width");
         const long ow = 2L * (W - fold);
@@ -813,9 +813,15 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         p1.release();
         prm.reset(IMO::LoadRRCParamFile(rrc2.c_str(), W));
         kb.upload((double *)prm.get(), (size_t)W * 2);
-        ck(oip_rrc_u16(ctx, p2.p, p2.p, W, L, kb.p));
-        ck(oip_remap_shift_bicubic_u16_window(ctx, p2.p, 0, L, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
-                                              OIP_REMAP_ROW_GUARD, o.fp16acc ? 1 : 0));
+        if (o.fp16acc) {
+            ck(oip_rrc_u16(ctx, p2.p, p2.p, W, L, kb.p));
+            ck(oip_remap_shift_bicubic_u16_window(ctx, p2.p, 0, L, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
+                                                  OIP_REMAP_ROW_GUARD, 1));
+        } else {
+            // the raw CCD-2 samples are corrected on load by the resampling kernel itself: one pass over the strip
+            ck(oip_remap_shift_rrc_bicubic_u16_window(ctx, p2.p, 0, L, kb.p, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
+                                                      OIP_REMAP_ROW_GUARD));
+        }
         std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
         st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());

@@ -137,3 +137,14 @@ __device__ __forceinline__ unsigned oip_sat_u16(float v)
     iv = iv < 0 ? 0 : (iv > 65535 ? 65535 : iv);
     return (unsigned)iv;
 }
+
+// IMO::InplaceRRC's pixel (imageop.h:134): (uint16_t)(k * s + b) in fp64, two roundings, then what x86-64 compilers emit for
+// the double -> uint16_t cast: cvttsd2si (32-bit, truncating; 0x80000000 when out of range or NaN) followed by a 16-bit
+// truncation.  Both bounds explicit: (int)v is only evaluated where the C++ conversion is defined.  (rrc.hip; also the
+// RRC-on-load form of the resampling kernel, remap.hip)
+__device__ __forceinline__ unsigned oip_rrc_px(double k, double b, unsigned s)
+{
+    double v = __dadd_rn(__dmul_rn(k, (double)s), b);
+    int t = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : 0;
+    return (unsigned)t & 0xffffu;
+}

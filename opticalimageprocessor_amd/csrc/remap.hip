@@ -70,8 +70,10 @@ __global__ void shift_rows_kernel(RowInfo *rows, OipShiftGeom g, long out_row0, 
     }
 }
 
+// kb != nullptr: the source is the RAW strip and every sample is corrected on load (IMO::InplaceRRC's pixel, exact) -- the
+// fused prestitch -> stitch form, where .RRC.RAW of CCD 2 is not materialised either
 __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, int row, int W, const int c[4],
-                                             unsigned xmask, float out[4])
+                                             unsigned xmask, float out[4], const double2 *__restrict__ kb)
 {
     if (row < 0) {
         out[0] = out[1] = out[2] = out[3] = 0.f;
@@ -79,14 +81,18 @@ __device__ __forceinline__ void load_tap_row(const uint16_t *__restrict__ src, i
     }
     const uint16_t *p = src + (long)row * W;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = (xmask & (1u << j)) ? (float)p[c[j]] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+        unsigned v = (xmask & (1u << j)) ? (unsigned)p[c[j]] : 0u;
+        if (kb && (xmask & (1u << j))) { const double2 q = kb[c[j]]; v = oip_rrc_px(q.x, q.y, v); }
+        out[j] = (float)v;
+    }
 }
 
 // one output column over a run of output lines (4x4 register window, one new source line per
 // output line): the general path -- any width, any alignment, every border case
 __device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                              const RowInfo *__restrict__ rows, int W, double dx, const float *__restrict__ tab1d,
-                             int x, long r0, long r1)
+                             int x, long r0, long r1, const double2 *__restrict__ kb = nullptr)
 {
     if (x < dw.col0) return;
     // stitcher.h:96  mapx = (float)(x + mDeltaX); imgwarp.cpp: sx = cvRound(mapx*32)
@@ -120,10 +126,10 @@ __device__ __forceinline__ void remap_column(const uint16_t *__restrict__ src, u
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[t][j] = v[t + 1][j];
             }
-            load_tap_row(src, ri.src[3], W, c, xmask, v[3]);
+            load_tap_row(src, ri.src[3], W, c, xmask, v[3], kb);
         } else if (!(ri.src[0] == cur[0] && ri.src[1] == cur[1] && ri.src[2] == cur[2] && ri.src[3] == cur[3])) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) load_tap_row(src, ri.src[t], W, c, xmask, v[t]);
+            for (int t = 0; t < 4; ++t) load_tap_row(src, ri.src[t], W, c, xmask, v[t], kb);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) cur[t] = ri.src[t];
@@ -153,14 +159,14 @@ __global__ __launch_bounds__(kBlock) void remap_shift_kernel(const uint16_t *__r
                                                              uint16_t *__restrict__ dst, DstWin dw,
                                                              const RowInfo *__restrict__ rows, int W, long out_rows,
                                                              double dx, const float *__restrict__ tab1d,
-                                                             int rows_per_block)
+                                                             int rows_per_block, const double2 *__restrict__ kb)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if (x >= W) return;
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > out_rows) r1 = out_rows;
-    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1, kb);
 }
 
 // ---- v2: 8 output pixels per lane ------------------------------------------------------------------
@@ -308,6 +314,142 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+            }
+        }
+    }
+}
+
+// ---- RRC on load: the RAW strip goes through the workgroup's LDS once -------------------------------------
+// The source is CCD 2's RAW strip.  The block's 256 lanes fetch one aligned 16-byte chunk each of every new source line
+// (2048 consecutive columns from cbase = 2032 * blockIdx.x + ixmin8, ixmin8 = 8 * floor((floor(dx) - 2) / 8): the taps of
+// the block's 254 output groups lie inside whatever the rounding of x + dx does; the host checks it), correct its 8 samples
+// with the (k, b) pairs of the lane's own columns held in registers (IMO::InplaceRRC's pixel, exact) and write them to LDS;
+// after one barrier the 254 output lanes read their 11 samples from there.  Every sample is corrected ONCE (the register
+// form would correct 11 per 8 output pixels and needs the pairs of 11 columns per lane: 6.0 ms with the pairs in LDS,
+// profiles/experiments/remap_rrc_on_load.diff.txt), so Stitcher::DoRRC of CCD 2 rides PreStitch's pass and <pan2>.RRC.RAW
+// is never written.  Lines are double-buffered in LDS (a write to buffer p follows the barrier of buffer p ^ 1, which
+// every reader of the previous use of p has passed); chunks are requested two output lines ahead.  Everything that decides
+// a barrier is uniform over the block (the row table and blockIdx); arithmetic per pixel is remap_shift8_kernel's.
+// The same staging WITHOUT the correction is slower than remap_shift8_kernel's register window (3.47 against 3.19 ms on
+// two 30000 x 100000 segments, at 3 or 4 workgroups per CU): the plain call keeps the register form.
+constexpr int kLdsOut = kBlock - 2;
+
+__global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
+                                                                     const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                                     long src_elems, double dx, const float *__restrict__ tab1d,
+                                                                     int rows_per_block, const double2 *__restrict__ kb, int ixmin8)
+{
+    __shared__ uint32_t lds[2][kBlock * 4];
+    const int X0 = blockIdx.x * kLdsOut * 8;
+    if (X0 + kLdsOut * 8 <= dw.col0) return;                         // nothing of this block is stored (uniform)
+    const int cbase = X0 + ixmin8;
+    const int cc = cbase + (int)threadIdx.x * 8;                     // the lane's chunk of source columns
+    const bool chunk_ok = cc >= 0 && cc + 8 <= W;                    // W % 8 == 0: a chunk is inside the line or outside it
+    double2 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
+    const int x0 = X0 + (int)threadIdx.x * 8;
+    int c0 = 0, fx0 = 0;
+    const bool active = (int)threadIdx.x < kLdsOut && x0 < W && x0 + 8 > dw.col0 && shift_group_regular(x0, W, dx, &c0, &fx0);
+    const int d0 = active ? (c0 - cbase) >> 1 : 0;                   // host: 0 <= c0 - cbase, c0 - cbase + 10 < 2048
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    const long src_lines = src_elems / W;
+    float wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
+
+    int p = 0;
+    auto fetch = [&](long row) __attribute__((always_inline)) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (chunk_ok && row >= 0 && row < src_lines) v = *reinterpret_cast<const uint4 *>(src + row * W + cc);
+        return v;
+    };
+    auto stage = [&](uint4 v, float g[11]) __attribute__((always_inline)) {
+        v.x = oip_rrc_px(q[0].x, q[0].y, v.x & 0xffffu) | (oip_rrc_px(q[1].x, q[1].y, v.x >> 16) << 16);
+        v.y = oip_rrc_px(q[2].x, q[2].y, v.y & 0xffffu) | (oip_rrc_px(q[3].x, q[3].y, v.y >> 16) << 16);
+        v.z = oip_rrc_px(q[4].x, q[4].y, v.z & 0xffffu) | (oip_rrc_px(q[5].x, q[5].y, v.z >> 16) << 16);
+        v.w = oip_rrc_px(q[6].x, q[6].y, v.w & 0xffffu) | (oip_rrc_px(q[7].x, q[7].y, v.w >> 16) << 16);
+        reinterpret_cast<uint4 *>(lds[p])[threadIdx.x] = v;
+        __syncthreads();
+        if (active) {
+            uint32_t w[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = lds[p][d0 + i];
+            expand_f32(w, c0, g);
+        }
+        p ^= 1;
+    };
+    float win[4][11];                             // tap line t at unrolled step k lives in win[(k+t)&3]
+    float w2d[16];
+    int cur_fy = -1;
+    // A run = consecutive regular output lines whose 4-line windows slide by one source line.  Its first three tap lines
+    // are staged at the run's start (k = 0 again), after that every output line stages exactly one new line.
+    long r = r0;
+    while (r < r1) {
+        const RowInfo h = rows[r];
+        if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
+        long qline = h.src[3];                    // chunks of source lines qline and qline + 1 are requested ahead (four
+        uint4 qa, qb;                             // ahead: the same 4.35 ms; as an array instead of named registers: spills)
+        {
+            const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
+            qa = fetch(qline);
+            qb = fetch(qline + 1);
+            stage(f0, win[0]);
+            stage(f1, win[1]);
+            stage(f2, win[2]);
+        }
+        int cur1 = h.src[0], cur2 = h.src[1], cur3 = h.src[2];
+        bool run = true;
+        while (run) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (r >= r1) { run = false; break; }
+                const RowInfo ri = rows[r];
+                if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
+                stage(qa, win[(k + 3) & 3]);
+                qa = qb;
+                qline += 1;
+                qb = fetch(qline + 1);
+                cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+                const long rr_ = r;
+                ++r;
+                if (!active) continue;
+                if (ri.fy != cur_fy) {
+                    cur_fy = ri.fy;
+    #pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const float wy = tab1d[cur_fy * 4 + ky];
+    #pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
+                    }
+                }
+                unsigned out[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float sum = 0.f;
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float *L = win[(k + t) & 3];
+                        float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
+                        rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
+                        rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
+                        sum = t == 0 ? rr : __fadd_rn(sum, rr);
+                    }
+                    out[j] = oip_sat_u16(sum);
+                }
+                uint4 o;
+                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+                uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
+                if (x0 >= dw.col0 && dw.vec) {
+                    *reinterpret_cast<uint4 *>(drow) = o;
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+                }
             }
         }
     }
@@ -469,7 +611,8 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
 __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                 const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                 double dx, const float *__restrict__ tab1d,
-                                                                const int *__restrict__ groups, int rows_per_block)
+                                                                const int *__restrict__ groups, int rows_per_block,
+                                                                const double2 *__restrict__ kb)
 {
     const int x = groups[blockIdx.x] * 8 + (threadIdx.x & 7);
     if (x >= W) return;
@@ -480,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *
     const long rend = (long)(blockIdx.y + 1) * rows_per_block;
     if (r1 > rend) r1 = rend;
     if (r1 > out_rows) r1 = out_rows;
-    if (r0 < r1) remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1);
+    if (r0 < r1) remap_column(src, dst, dw, rows, W, dx, tab1d, x, r0, r1, kb);
 }
 
 // fix-up B: lines whose window touches a section border, all columns
@@ -488,14 +631,14 @@ __global__ __launch_bounds__(kBlock) void remap_fix_rows_kernel(const uint16_t *
                                                                 const RowInfo *__restrict__ rows, int W, double dx,
                                                                 const float *__restrict__ tab1d,
                                                                 const int *__restrict__ bad_count,
-                                                                const int *__restrict__ bad_rows)
+                                                                const int *__restrict__ bad_rows, const double2 *__restrict__ kb)
 {
     int n = *bad_count;
     if (n > kMaxBadRows) n = kMaxBadRows;
     const int x = blockIdx.x * kBlock + threadIdx.x;
     if ((int)blockIdx.y >= n || x >= W) return;
     const long r = bad_rows[blockIdx.y];
-    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r, r + 1);
+    remap_column(src, dst, dw, rows, W, dx, tab1d, x, r, r + 1, kb);
 }
 
 }  // namespace
@@ -552,8 +695,10 @@ extern "C" int oip_remap_shift_src_range(long out_row0, long out_rows, long L, d
 
 static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, long src_rows, uint16_t *d_dst,
                             long out_row0, long out_rows, int W, long L, double dx, double dy, int section_rows,
-                            int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0)
+                            int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0, const double *d_kb = nullptr)
 {
+    const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
+    if (ctx && kb && f16acc) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_rrc_bicubic_u16_window: RRC on load is an fp32 form");
     OIP_CHECK_CTX(ctx);
     if (dst_pitch <= 0) { dst_pitch = W; dst_col0 = 0; dst_col_off = 0; }
     if (dst_col0 < 0 || dst_col0 >= W || dst_col_off < 0 || dst_col_off + (W - dst_col0) > dst_pitch)
@@ -584,14 +729,24 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
                             "oip_remap_shift_bicubic_u16: source window [%ld,%ld) lacks halo lines, need [%ld,%ld)",
                             src_row0, src_row0 + src_rows, first, last);
     }
-    const bool v8 = W % 8 == 0 && (((uintptr_t)d_dst) & 1) == 0 && (((uintptr_t)d_src) & 3) == 0 && src_rows * (long)W >= 16 &&
-                    (dw.vec || dst_pitch != W);       // the plain call keeps its rule: misaligned destination -> generic kernel
+    bool v8 = W % 8 == 0 && (((uintptr_t)d_dst) & 1) == 0 && (((uintptr_t)d_src) & 3) == 0 && src_rows * (long)W >= 16 &&
+              (dw.vec || dst_pitch != W);             // the plain call keeps its rule: misaligned destination -> generic kernel
+    // RRC on load: the LDS-staged kernel fetches 16-byte chunks of the source lines; otherwise the general kernel (it
+    // corrects on load as well)
+    const bool lds = v8 && kb && (((uintptr_t)d_src) & 15) == 0;
+    if (kb && !lds) v8 = false;
+    const long fl = (long)floor(dx);
+    const int ixmin8 = (int)(8 * ((fl - 2 >= 0 ? fl - 2 : fl - 2 - 7) / 8));
     // irregular 8-column groups (host arithmetic identical to the kernel's)
     std::vector<int> bad_groups;
     if (v8)
         for (int gidx = 0; gidx < W / 8; ++gidx) {
             int a0, f0;
-            if (!shift_group_regular(gidx * 8, W, dx, &a0, &f0)) bad_groups.push_back(gidx);
+            if (!shift_group_regular(gidx * 8, W, dx, &a0, &f0)) { bad_groups.push_back(gidx); continue; }
+            if (lds) {                                // the taps of a regular group lie inside its block's 2048 staged columns
+                const int li = a0 - (gidx / kLdsOut * kLdsOut * 8 + ixmin8);
+                if (li < 0 || li + 10 >= kBlock * 8) return oip_fail(ctx, OIP_E_RUNTIME, "remap: staged columns do not cover group %d", gidx);
+            }
         }
     const size_t rows_bytes = ((size_t)out_rows * sizeof(RowInfo) + 255) / 256 * 256;
     const size_t list_bytes = 256 + sizeof(int) * (size_t)kMaxBadRows + sizeof(int) * (bad_groups.size() + 64);
@@ -617,8 +772,8 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
     if (v8 && (long)g.nsec * 8 + g.ucut + g.bcut + 16 > kMaxBadRows)
         return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_bicubic_u16: too many section-border lines");
     if (v8) {
-        int gx = (W / 8 + kBlock - 1) / kBlock;
-        long want = (long)ctx->cu_count * 16 / gx;
+        int gx = lds ? (W / 8 + kLdsOut - 1) / kLdsOut : (W / 8 + kBlock - 1) / kBlock;
+        long want = (long)ctx->cu_count * (lds ? 12 : 16) / gx;      // 12..96 (RRC form), 16..48 (plain): the step takes the same time
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
         if (rpb < 32) rpb = 32;
@@ -626,9 +781,16 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
         {
-            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel");
-            hipLaunchKernelGGL(f16acc ? remap_shift8_f16_kernel : remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0,
-                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
+            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : (lds ? "remap_shift8_rrc_kernel" : "remap_shift8_kernel"));
+            if (f16acc)
+                hipLaunchKernelGGL(remap_shift8_f16_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
+                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
+            else if (lds)
+                hipLaunchKernelGGL(remap_shift8_rrc_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
+                                   out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
+            else
+                hipLaunchKernelGGL(remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
+                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
         }
         if (!bad_groups.empty()) {
             OipProfScope prof(ctx, "remap_fix_cols_kernel");
@@ -636,13 +798,13 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
             long gy2 = (out_rows + rpb2 - 1) / rpb2;
             if (gy2 > 65535) { gy2 = 65535; rpb2 = (out_rows + gy2 - 1) / gy2; gy2 = (out_rows + rpb2 - 1) / rpb2; }
             hipLaunchKernelGGL(remap_fix_cols_kernel, dim3((unsigned)bad_groups.size(), (unsigned)gy2), dim3(kBlock), 0,
-                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2);
+                               ctx->stream, d_src, d_dst, dw, rows, W, out_rows, dx, ctx->d_tab1d, d_bad_groups, (int)rpb2, kb);
         }
         {
             OipProfScope prof(ctx, "remap_fix_rows_kernel");
             const long nb = (long)g.nsec * 8 + g.ucut + g.bcut + 16;      // upper bound on listed lines
             hipLaunchKernelGGL(remap_fix_rows_kernel, dim3((W + kBlock - 1) / kBlock, (unsigned)nb), dim3(kBlock), 0, ctx->stream,
-                               d_src, d_dst, dw, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows);
+                               d_src, d_dst, dw, rows, W, dx, ctx->d_tab1d, d_bad_count, d_bad_rows, kb);
         }
     } else {
         OipProfScope prof(ctx, "remap_shift_kernel");
@@ -654,7 +816,7 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = (out_rows + gy - 1) / gy; gy = (out_rows + rpb - 1) / rpb; }
         hipLaunchKernelGGL(remap_shift_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows,
-                           W, out_rows, dx, ctx->d_tab1d, (int)rpb);
+                           W, out_rows, dx, ctx->d_tab1d, (int)rpb, kb);
     }
     OIP_HIP(ctx, hipGetLastError());
     return OIP_OK;
@@ -686,4 +848,16 @@ extern "C" int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *
     if (ctx && dst_pitch <= 0) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_bicubic_u16_window: bad destination pitch");
     return remap_shift_impl(ctx, d_src, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, f16acc != 0,
                             dst_pitch, dst_col0, dst_col_off);
+}
+
+// The same with the source being the RAW CCD-2 strip: every sample is corrected on load (IMO::InplaceRRC's pixel, exact;
+// d_kb: the W (k, b) pairs), so Stitcher::DoRRC of CCD 2, PreStitch and the right half of StitchBigRaw are ONE pass over the
+// strip and <pan2>.RRC.RAW is not materialised either.  fp32 only.  Bits are those of RRC followed by the plain call.
+extern "C" int oip_remap_shift_rrc_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src_raw, long src_row0, long src_rows, const double *d_kb,
+                                                      uint16_t *d_dst, long dst_pitch, int dst_col0, long dst_col_off, long out_row0,
+                                                      long out_rows, int W, long L, double dx, double dy, int section_rows, int row_guard)
+{
+    if (ctx && (dst_pitch <= 0 || !d_kb)) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_rrc_bicubic_u16_window: bad argument");
+    return remap_shift_impl(ctx, d_src_raw, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, false,
+                            dst_pitch, dst_col0, dst_col_off, d_kb);
 }

@@ -30,15 +30,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kRowsInFlight = 4;
 
-__device__ __forceinline__ unsigned rrc_px(double k, double b, unsigned s)
-{
-    double v = __dadd_rn(__dmul_rn(k, (double)s), b);
-    // both bounds explicit: (int)v is only evaluated where the C++ conversion is defined (trunc(v) fits
-    // int32); everything else -- negative or positive overflow, NaN -- gives low half 0 like cvttsd2si's
-    // 0x80000000
-    int t = (v > -2147483649.0 && v < 2147483648.0) ? (int)v : 0;
-    return (unsigned)t & 0xffffu;
-}
+__device__ __forceinline__ unsigned rrc_px(double k, double b, unsigned s) { return oip_rrc_px(k, b, s); }
 
 template <int V> struct Vec;
 template <> struct Vec<8> { using type = uint4; };

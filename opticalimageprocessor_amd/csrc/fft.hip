@@ -631,7 +631,7 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 
     {
         if (tile_tw) {
-            for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = twT[(long)t.o1 * i];
+            for (int i = threadIdx.x; i < F; i += kFftBlock) twj[i] = p.tw_rows ? twT[(long)t.o1 * F + i] : twT[(long)t.o1 * i];
             if (p.inverse) __syncthreads();
         }
         // commit the prefetched tile to LDS
@@ -689,11 +689,34 @@ __global__ __launch_bounds__(NT) void fft_pass_ct_kernel(float2 *__restrict__ da
 // a fixed m a wave covers four 128-byte row segments) -- exactly the inputs of its radix-8 butterfly of the
 // first Stockham stage -- and the outputs of the last radix-4 stage are scanned in registers: two LDS round
 // trips and four barriers instead of five and nine.  The tile maximum is folded into the arg-max slots per
-// WAVE (a value reduction with shuffles, then an atomicMax by the lanes that hold the maximum -- one lane
+// WAVE (a value reduction on the DPP path, then an atomicMax by the lanes that hold the maximum -- one lane
 // unless values tie, and atomicMax orders ties by key itself): no LDS hand-off between the waves.
-// Measured 0.128 -> 0.104 ms per launch (3.7 TB/s).  Walking several tile rows per workgroup with the next
-// tile's loads in flight (OIP_PEAK_TILES) changes nothing: what is left is the cost of reading 128-byte
-// segments 125 lines (3 MB) apart, the same 0.03-0.04 ms the first forward pass pays for its strided stores.
+// Round 2: 0.128 -> 0.104 ms per launch.  Round 3 took the pass apart (profiles/experiments/peak_dbg.sh,
+// strided_rows_read.hip): its loads alone take 0.064 ms (the bare pattern reads at 6 TB/s), its arithmetic alone 0.069,
+// loads + first stage 0.0955 -- and 19 % of the bare pattern's time came back when the tile's 128 inter-pass twiddles
+// were GATHERED from table T at a stride of 8 o bytes: 128 more cache lines per tile, requested behind the data and
+// requested behind the data.  They are now one contiguous 1 KiB row per tile row (get_pass_table): 0.104 -> 0.088 ms.
+// Walking several tile rows per workgroup with the next tile's loads in flight (OIP_PEAK_TILES), or fetching two or three
+// tiles up front, changes nothing.
+//
+// maximum over the 64 lanes of a wave on the DPP path (no LDS traffic): quad swaps, the two row mirrors, then the row
+// broadcasts of gfx9 bring the maximum of everything to lane 63.  fmaxf semantics per step (a NaN loses against a number);
+// the callers compare their own value with the result.
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#define OIP_DPP_MAX(ctrl, rmask)                                                                                         \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), \
+                                                                        ctrl, rmask, 0xf, false)))
+    OIP_DPP_MAX(0xB1, 0xf);       // quad_perm [1,0,3,2]
+    OIP_DPP_MAX(0x4E, 0xf);       // quad_perm [2,3,0,1]
+    OIP_DPP_MAX(0x141, 0xf);      // row_half_mirror
+    OIP_DPP_MAX(0x140, 0xf);      // row_mirror
+    OIP_DPP_MAX(0x142, 0xa);      // row_bcast15 into rows 1 and 3
+    OIP_DPP_MAX(0x143, 0xc);      // row_bcast31 into rows 2 and 3
+#undef OIP_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int VS>
 __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 *__restrict__ data, OipFftPass p, OipFftIo io,
                                                               const float2 *__restrict__ twF, const float2 *__restrict__ twT)
@@ -722,14 +745,19 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
     if (o1 >= p.O1) return;
     float2 x[8];
     float2 rtw = make_float2(1.f, 0.f);
+    // Loads: a uniform 64-bit base per (tile row, m) plus ONE 32-bit byte offset per thread (the host checks that the array
+    // is smaller than 2 GiB), so a load costs no vector arithmetic; lanes past the last column re-read the last valid one
+    // (their values never reach the scan) instead of branching around every load.  The tile's 128 inter-pass twiddles are
+    // one contiguous row of the [O1][F] table (get_pass_table), read by the first 128 threads and passed through LDS: one
+    // coalesced KiB -- gathered from table T at o n they were 128 more cache lines per tile (0.103 -> 0.088 ms); a thread
+    // loading its own eight straight from the row, without the LDS hop, was SLOWER (0.106 ms).
+    const int vc = lane_ok ? v : nv - 1;
     auto fetch = [&](int o, int tid) {
-        const long base = (long)o * p.o1_stride + lane0;
+        const unsigned voff = (unsigned)((tid >> VS) * (int)p.nstride + lane0 + vc) * 8u;
+        const char *tb = reinterpret_cast<const char *>(data) + (long)o * p.o1_stride * 8;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            x[m] = make_float2(0.f, 0.f);
-            if (lane_ok) x[m] = data[base + (long)((tid >> VS) + 16 * m) * p.nstride + v];
-        }
-        if (tid < F) rtw = twT[(long)o * tid];
+        for (int m = 0; m < 8; ++m) x[m] = *reinterpret_cast<const float2 *>(tb + (long)m * 16 * p.nstride * 8 + voff);
+        if (tid < F) rtw = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(twT) + (unsigned)(p.tw_rows ? o * F + tid : o * tid) * 8u);
     };
     // inverse = conj(forward(conj(.))); the inter-pass twiddle of point n multiplies the conjugated input
     auto stage1 = [&](int tid) {
@@ -810,9 +838,7 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
         for (int part = 0; part < 2; ++part) {
             const float mine = part ? bv1 : bv0;
             const int bn = part ? bn1 : bn0;
-            float wmax = mine;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+            const float wmax = wave_max_f32(mine);
             // the generic kernel publishes (-inf, none) for a tile without any comparable value: keep that (lane 0 only)
             const bool holder = mine == wmax && (mine > -INFINITY || (tid & 63) == 0);
             if (holder) {
@@ -922,7 +948,7 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
                 rv[sl][i] = *reinterpret_cast<const float2 *>(Vs + (size_t)y * io.v_cols + c);
             }
         }
-        if (tid < F) rtw = twT[(long)o1 * tid];
+        if (tid < F) rtw = p.tw_rows ? twT[(long)o1 * F + tid] : twT[(long)o1 * tid];
     };
     float2 zz[NLD];
     auto expand = [&](int o1, int tid) {
@@ -1178,6 +1204,7 @@ void choose_kernel(OipFftPass *p, int want_v)
 
 struct oip_fft_state {
     std::map<int, float2 *> tables;       // exp(-2 pi i t / T), t in [0, T)
+    std::map<std::pair<int, int>, float2 *> pass_tables;   // (T, F): [T / F][F], row o = exp(-2 pi i o n / T), n in [0, F)
     std::map<std::pair<int, int>, OipFft2dPlan> plans;
 };
 
@@ -1200,10 +1227,39 @@ static int get_table(oip_ctx *ctx, int T, const float2 **out)
     return OIP_OK;
 }
 
+// The inter-pass twiddles of a tw_mode 2 pass, one contiguous row of F values per tile row o (the same values as
+// table T at o n, computed the same way).  A tile used to gather its F values from table T at a stride of 8 o bytes:
+// F different cache lines per tile -- as many line requests as the tile's data (128 rows of one line each), on the
+// dependent end of the tile's loads; the bare access pattern of the last inverse pass lost 19 % to that gather alone
+// (profiles/experiments/strided_rows_read.hip, "pass-like 1").
+static int get_pass_table(oip_ctx *ctx, int T, int F, const float2 **out)
+{
+    if (!ctx->fft) ctx->fft = new oip_fft_state();
+    auto key = std::make_pair(T, F);
+    auto it = ctx->fft->pass_tables.find(key);
+    if (it == ctx->fft->pass_tables.end()) {
+        const int O = T / F;
+        std::vector<float2> h((size_t)O * F);
+        for (int o = 0; o < O; ++o)
+            for (int n = 0; n < F; ++n) {
+                const long t = ((long)o * n) % T;
+                double a = -2.0 * M_PI * (double)t / (double)T;
+                h[(size_t)o * F + n] = make_float2((float)cos(a), (float)sin(a));
+            }
+        float2 *d = nullptr;
+        OIP_HIP(ctx, hipMalloc((void **)&d, sizeof(float2) * h.size()));
+        OIP_HIP(ctx, hipMemcpy(d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+        it = ctx->fft->pass_tables.emplace(key, d).first;
+    }
+    *out = it->second;
+    return OIP_OK;
+}
+
 void oip_fft_destroy(oip_ctx *ctx)
 {
     if (!ctx->fft) return;
     for (auto &kv : ctx->fft->tables) hipFree(kv.second);
+    for (auto &kv : ctx->fft->pass_tables) hipFree(kv.second);
     for (auto &kv : ctx->fft->plans) hipFree(const_cast<int *>(kv.second.d_ypos));
     delete ctx->fft;
     ctx->fft = nullptr;
@@ -1333,6 +1389,18 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     int rc = get_table(ctx, p.F, &twF);
     if (rc) return rc;
     if (p.tw_mode) { rc = get_table(ctx, p.T, &twT); if (rc) return rc; }
+    // the specialised kernels of a tw_mode 2 pass read their F inter-pass twiddles as one contiguous row (get_pass_table)
+    const float2 *twR = twT;
+    bool rows_ok = false;
+    p.tw_rows = 0;
+    if (p.tw_mode == 2 && p.F > 0 && p.T % p.F == 0 && p.O1 == p.T / p.F && (long)p.T * 8 <= (16L << 20)) {
+        static const char *envr = getenv("OIP_TW_ROWS");                 // experiment knob: 0 = gather from table T as before
+        if (!(envr && atoi(envr) == 0)) {
+            rc = get_pass_table(ctx, p.T, p.F, &twR);
+            if (rc) return rc;
+            rows_ok = true;
+        }
+    }
     {
         OipFftPass whole = p;
         whole.ltn = 0;
@@ -1371,15 +1439,16 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
                 const int ltn = p.ltn > 0 ? p.ltn : p.lane_tiles;
                 p.xcd_chunk = (ltn + 7) / 8;
                 const int gy = (p.O1 + tiles - 1) / tiles;
+                p.tw_rows = rows_ok;
                 hipLaunchKernelGGL(k.fn, dim3((unsigned)(8 * p.xcd_chunk), (unsigned)gy, (unsigned)p.O2), dim3(k.threads), 0, ctx->stream,
-                                   data, p, io, twF, twT);
+                                   data, p, io, twF, twR);
                 OIP_HIP(ctx, hipGetLastError());
                 return OIP_OK;
             }
     }
     // the register-staged peak pass for the 128-point inverse column pass (see the kernel)
     if (blocks_override <= 0 && inverse && io.store_kind == 1 && p.mode == 0 && p.axis == 1 && p.F == 128 && (p.vshift == 4 || p.vshift == 5) &&
-        p.tw_mode == 2 && p.grid3) {
+        p.tw_mode == 2 && p.grid3 && (16 * p.nstride + p.lanes) * 8 < (1L << 31)) {       // 32-bit byte offsets inside a tile row block
         static const char *envk = getenv("OIP_PEAK_V2");                  // experiment knob: 0 = generic pass kernel
         if (!(envk && atoi(envk) == 0)) {
             static const char *envt = getenv("OIP_PEAK_TILES");             // experiment knob: tile rows per workgroup
@@ -1395,8 +1464,9 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
                 grid3.x = (unsigned)(8 * p.xcd_chunk);
             }
             grid3.y = (unsigned)((p.O1 + tiles - 1) / tiles);
-            if (p.vshift == 4) hipLaunchKernelGGL(fft_col128_peak_kernel<4>, grid3, dim3(256), 0, ctx->stream, data, p, io, twF, twT);
-            else hipLaunchKernelGGL(fft_col128_peak_kernel<5>, grid3, dim3(512), 0, ctx->stream, data, p, io, twF, twT);
+            p.tw_rows = rows_ok;
+            if (p.vshift == 4) hipLaunchKernelGGL(fft_col128_peak_kernel<4>, grid3, dim3(256), 0, ctx->stream, data, p, io, twF, twR);
+            else hipLaunchKernelGGL(fft_col128_peak_kernel<5>, grid3, dim3(512), 0, ctx->stream, data, p, io, twF, twR);
             OIP_HIP(ctx, hipGetLastError());
             return OIP_OK;
         }
@@ -1404,7 +1474,8 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     if (p.fast >= 0 && kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)]) {
         p.ntiles = blocks;
         long grid = blocks;
-        hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, twT);
+        p.tw_rows = rows_ok && p.mode == 0;
+        hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, p.tw_rows ? twR : twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);
         hipLaunchKernelGGL(fft_pass_kernel, p.grid3 ? grid3 : dim3((unsigned)blocks), dim3(kFftBlock), lds, ctx->stream, data, p, io, twF, twT);

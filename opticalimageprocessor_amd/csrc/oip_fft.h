@@ -85,6 +85,7 @@ struct OipFftPass {
     int grid3;          // mode 0 launched as a (lane tile, o1, o2) grid: the tile needs no divisions to decode
     int dbg;            // experiment mask for the fused-loader kernels (OIP_PACK_DBG): 1 no loads, 2 no stages, 4 no stores
     int xcd_chunk;      // grid3: lane tiles per XCD (grid x = 8 * xcd_chunk >= lane tiles); see decode_tile
+    int tw_rows;        // tw_mode 2, specialised kernels: the inter-pass table is [O1][F] (row o1 contiguous) instead of table T gathered at o1 * n
 };
 
 struct OipFft2dPlan {

@@ -1474,7 +1474,10 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     if (p.fast >= 0 && kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)]) {
         p.ntiles = blocks;
         long grid = blocks;
-        p.tw_rows = rows_ok && p.mode == 0;
+        // the LDS-staged pass kernels keep the gather: with rows the 125-point passes were 1.4 % SLOWER (0.1328 -> 0.1347 ms, A/B twice on
+        // one box), OIP_TW_ROWS=2 turns the rows on for them too
+        static const char *envr2 = getenv("OIP_TW_ROWS");
+        p.tw_rows = rows_ok && p.mode == 0 && envr2 && atoi(envr2) == 2;
         hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, p.tw_rows ? twR : twT);
     } else {
         size_t lds = sizeof(float2) * ((size_t)2 * p.F * p.Vp + p.F);

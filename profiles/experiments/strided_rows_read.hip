@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void read_kernel(const float2 *__restrict__ da
 //   STEP 1  + the inter-pass twiddle gather  twT[o * tid]  (128 threads, stride 8 o bytes in a 128 KB table) -> LDS, barrier
 //   STEP 2  + the first stage's data flow: x[m] *= twj[q + 16 m] (LDS reads), 8 stores of 8 bytes into the padded tile, barrier
 //   STEP 3  + a second barrier-separated LDS round trip (what stages 2 and 3 do), nothing computed
-template <int STEP>
+// VEC4: the tile's data through four 16-byte loads per thread (two neighbouring columns of rows q + 16 (2 j + h), h = v >> 3)
+// instead of eight 8-byte loads -- half the vector-memory instructions for the same bytes; TWROW: the twiddles as one
+// contiguous row (twT + 128 o) instead of the gather
+template <int STEP, bool VEC4 = false, bool TWROW = false>
 __global__ __launch_bounds__(256) void pass_like_kernel(const float2 *__restrict__ data, const float2 *__restrict__ twT, float *__restrict__ sink)
 {
     __shared__ float2 buf[128 * 17];
@@ -62,10 +65,20 @@ __global__ __launch_bounds__(256) void pass_like_kernel(const float2 *__restrict
     if (lt >= LT) return;
     const int q = threadIdx.x >> 4, v = threadIdx.x & 15;
     float2 x[8];
+    if (VEC4) {
+        const int h = v >> 3, c = 2 * (v & 7);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) x[m] = data[(o + 125L * (q + 16 * m)) * P + lt * 16 + v];
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = *reinterpret_cast<const float4 *>(data + (o + 125L * (q + 16 * (2 * j + h))) * P + lt * 16 + c);
+            x[2 * j] = make_float2(t.x, t.y);
+            x[2 * j + 1] = make_float2(t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m] = data[(o + 125L * (q + 16 * m)) * P + lt * 16 + v];
+    }
     float2 rtw = make_float2(1.f, 0.f);
-    if (threadIdx.x < 128) rtw = twT[o * (int)threadIdx.x];
+    if (threadIdx.x < 128) rtw = TWROW ? twT[(o * 128 + (int)threadIdx.x) % 16000] : twT[o * (int)threadIdx.x];
     if (threadIdx.x < 128) twj[threadIdx.x] = rtw;
     __syncthreads();
     float s = 0.f;
@@ -157,5 +170,8 @@ int main(int argc, char **)
     time_kernel("pass-like 1: + twiddle gather -> LDS, barrier", [&] { hipLaunchKernelGGL((pass_like_kernel<1>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
     time_kernel("pass-like 2: + first-stage data flow (LDS tile), barrier", [&] { hipLaunchKernelGGL((pass_like_kernel<2>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
     time_kernel("pass-like 3: + one more barrier-separated LDS round trip", [&] { hipLaunchKernelGGL((pass_like_kernel<3>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
+    time_kernel("pass-like 3, twiddles as a contiguous row", [&] { hipLaunchKernelGGL((pass_like_kernel<3, false, true>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
+    time_kernel("pass-like 3, contiguous row, 16-byte data loads", [&] { hipLaunchKernelGGL((pass_like_kernel<3, true, true>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
+    time_kernel("pass-like 3, gather, 16-byte data loads", [&] { hipLaunchKernelGGL((pass_like_kernel<3, true, false>), dim3(GX, 125), dim3(256), 0, 0, d, tw, sink); });
     return 0;
 }

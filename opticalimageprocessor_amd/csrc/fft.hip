@@ -725,7 +725,7 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
     // (q, v) = (tid >> VS, tid & (V - 1)), q < 16, owns the points q + 16 m of lane v either way.
     constexpr int F = 128, V = 1 << VS, Vp = V + 1;
     __shared__ float2 buf[F * Vp];
-    __shared__ float2 tw[32];
+    __shared__ float2 tw[96];                  // w_128^i, i < 96: the stage twiddles w, w^2, w^3 of both radix-4 stages are table entries
     __shared__ float2 twj[F];
     // lane tile: contiguous chunks per XCD (see decode_tile); the workgroup keeps it and walks the row offsets
     // o1 = blockIdx.y, + gridDim.y, ...: the loads of the next tile are issued before the later stages of the current one
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
         for (int m = 0; m < 8; ++m) buf[(qq * 8 + m) * Vp + v] = x[m];
     };
     fetch(o1, threadIdx.x);
-    if (threadIdx.x < 32) tw[threadIdx.x] = twF[threadIdx.x];
+    if (threadIdx.x < 96) tw[threadIdx.x] = twF[threadIdx.x];
     if (threadIdx.x < F) twj[threadIdx.x] = rtw;
     __syncthreads();
     stage1(threadIdx.x);
@@ -794,8 +794,7 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int b = qq + 16 * i, k = b & 7;
-            const float2 w1 = tw[k * 4];
-            const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            const float2 w1 = tw[k * 4], w2 = tw[k * 8], w3 = tw[k * 12];
             y[i][1] = cmul(y[i][1], w1);
             y[i][2] = cmul(y[i][2], w2);
             y[i][3] = cmul(y[i][3], w3);
@@ -811,8 +810,7 @@ __global__ __launch_bounds__(16 << VS) void fft_col128_peak_kernel(const float2 
             const int b = qq + 16 * i;
 #pragma unroll
             for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
-            const float2 w1 = tw[b];
-            const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+            const float2 w1 = tw[b], w2 = tw[2 * b], w3 = tw[3 * b];
             y[i][1] = cmul(y[i][1], w1);
             y[i][2] = cmul(y[i][2], w2);
             y[i][3] = cmul(y[i][3], w3);
@@ -875,7 +873,8 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
                                                               const float2 *__restrict__ twF, const float2 *__restrict__ twT)
 {
     constexpr int VS = 4, V = 16, Vp = V + 1, kSeg = 8;
-    constexpr int TWN = TwTable<F, Rs...>::value();
+    constexpr int TWN0 = TwTable<F, Rs...>::value();
+    constexpr int TWN = (F == 128 && NT == 256 && TWN0 < 96) ? 96 : TWN0;       // the register-staged form reads w, w^2, w^3 of both radix-4 stages from the table
     constexpr int NLD = F * V / NT;                     // tile elements per thread
     constexpr int NRV = F * kSeg / 2 / NT;              // 8-byte tap-run loads per thread and band
     static_assert(F * V % NT == 0 && F * kSeg / 2 % NT == 0 && 2 * F <= NT && F <= NT && NT % V == 0, "tile / block shape");
@@ -1031,8 +1030,7 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
 #pragma unroll
             for (int i = 0; i < 2; ++i) {            // radix 4, Ns = 8
                 const int b = qq + 16 * i, k = b & 7;
-                const float2 w1 = tw[k * 4];
-                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                const float2 w1 = tw[k * 4], w2 = tw[k * 8], w3 = tw[k * 12];
                 y[i][1] = cmul(y[i][1], w1);
                 y[i][2] = cmul(y[i][2], w2);
                 y[i][3] = cmul(y[i][3], w3);
@@ -1047,8 +1045,7 @@ __global__ __launch_bounds__(NT) void fft_first_pass_up_kernel(float2 *__restric
                 const int b = qq + 16 * i;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) y[i][m] = buf[(b + 32 * m) * Vp + v];
-                const float2 w1 = tw[b];
-                const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                const float2 w1 = tw[b], w2 = tw[2 * b], w3 = tw[3 * b];
                 y[i][1] = cmul(y[i][1], w1);
                 y[i][2] = cmul(y[i][2], w2);
                 y[i][3] = cmul(y[i][3], w3);

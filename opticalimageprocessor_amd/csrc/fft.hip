@@ -1391,7 +1391,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
     bool rows_ok = false;
     p.tw_rows = 0;
     if (p.tw_mode == 2 && p.F > 0 && p.T % p.F == 0 && p.O1 == p.T / p.F && (long)p.T * 8 <= (16L << 20)) {
-        static const char *envr = getenv("OIP_TW_ROWS");                 // experiment knob: 0 = gather from table T as before
+        const char *envr = getenv("OIP_TW_ROWS");                        // read per call (a test compares the forms): 0 = gather from table T
         if (!(envr && atoi(envr) == 0)) {
             rc = get_pass_table(ctx, p.T, p.F, &twR);
             if (rc) return rc;
@@ -1473,7 +1473,7 @@ static int launch_pass(oip_ctx *ctx, float2 *data, OipFftPass p, int inverse, co
         long grid = blocks;
         // the LDS-staged pass kernels keep the gather: with rows the 125-point passes were 1.4 % SLOWER (0.1328 -> 0.1347 ms, A/B twice on
         // one box), OIP_TW_ROWS=2 turns the rows on for them too
-        static const char *envr2 = getenv("OIP_TW_ROWS");
+        const char *envr2 = getenv("OIP_TW_ROWS");
         p.tw_rows = rows_ok && p.mode == 0 && envr2 && atoi(envr2) == 2;
         hipLaunchKernelGGL(kFast[p.fast].fn[io.load_kind ? 1 : (io.store_kind ? 2 : 0)], p.grid3 ? grid3 : dim3((unsigned)grid), dim3(kFast[p.fast].threads), 0, ctx->stream, data, p, io, twF, p.tw_rows ? twR : twT);
     } else {

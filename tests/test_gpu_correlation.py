@@ -236,6 +236,28 @@ def test_interband_reference_unit_shape_matches_oracle(ctx, oracle_mod, parity_l
     assert masked <= MASKED["reference_unit_shape"]
 
 
+def test_twiddle_rows_equal_the_gather(ctx):
+    """The column passes of a 16000-line unit read their inter-pass twiddles either gathered from table T (OIP_TW_ROWS=0) or as
+    one contiguous row per tile row of a [T/F][F] table (1, default: the two register-staged passes; 2: the LDS-staged passes
+    too).  Same values, same arithmetic: the results must be the same bits."""
+    import os
+    rows, W = 16000, 6000
+    pan, bands = _synth.pan_mss(rows, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=11)
+    dpan, dplanes = _cuda(pan), [_cuda(b) for b in bands]
+    pp = [dpan[:, 3000 * u:] for u in range(2)]
+    bp = [[dplanes[b][:, 750 * u:] for b in range(4)] for u in range(2)]
+    res = {}
+    try:
+        for mode in ("0", "1", "2"):
+            os.environ["OIP_TW_ROWS"] = mode
+            res[mode] = ctx.interband_correlate_units(pp, [W] * 2, bp, [W // 4] * 2, rows, 3000)
+    finally:
+        os.environ.pop("OIP_TW_ROWS", None)
+    assert np.isfinite(res["0"]).all()
+    assert np.array_equal(res["0"], res["1"]) and np.array_equal(res["0"], res["2"])
+    assert np.array_equal(res["1"], ctx.interband_correlate_units(pp, [W] * 2, bp, [W // 4] * 2, rows, 3000))
+
+
 def test_spectral_upsampling_route_equals_the_image_route(ctx, oracle_mod, parity_log):
     """3000-column units take the x4 cubic up-sampling of the bands on their spectra (DFT_N(R s) = H DFT_n(s) + sum
     G_j s_j along an axis, exact): OIP_SPECTRAL_UP=2 (default) on both axes, =1 on the horizontal axis only (vertical

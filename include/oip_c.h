@@ -259,12 +259,13 @@ int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src, long
                                        int section_rows, int row_guard, int f16acc);
 /* The same with the source being the RAW CCD-2 strip: every sample is corrected on load (IMO::InplaceRRC's pixel, exact;
  * d_kb: the W (k,b) pairs in HBM), so Stitcher::DoRRC of CCD 2, PreStitch and the right half of StitchBigRaw are ONE pass
- * over the strip and <pan2>.RRC.RAW is not materialised either.  fp32 only; bits are those of oip_rrc_u16 followed by
- * oip_remap_shift_bicubic_u16_window. */
+ * over the strip and <pan2>.RRC.RAW is not materialised either.  Bits are those of oip_rrc_u16 followed by
+ * oip_remap_shift_bicubic_u16_window with the same f16acc (f16acc != 0 needs W % 8 == 0 and a 16-byte aligned source:
+ * OIP_E_UNSUPPORTED otherwise). */
 int oip_remap_shift_rrc_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src_raw, long src_row0, long src_rows,
                                            const double *d_kb, uint16_t *d_dst, long dst_pitch, int dst_col0,
                                            long dst_col_off, long out_row0, long out_rows, int W, long L, double dx,
-                                           double dy, int section_rows, int row_guard);
+                                           double dy, int section_rows, int row_guard, int f16acc);
 /* source lines [first, last) that output lines [out_row0, out_row0+out_rows) read: the halo
  * a row-block shard has to hold (host arithmetic only) */
 int oip_remap_shift_src_range(long out_row0, long out_rows, long L, double dy,

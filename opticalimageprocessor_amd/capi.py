@@ -88,7 +88,7 @@ _SIGS = {
     "oip_remap_shift_bicubic_u16": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_bicubic_u16_f16acc": ([_vp, _vp, _l, _l, _vp, _l, _l, _i, _l, _d, _d, _i, _i], _i),
     "oip_remap_shift_bicubic_u16_window": ([_vp, _vp, _l, _l, _vp, _l, _i, _l, _l, _l, _i, _l, _d, _d, _i, _i, _i], _i),
-    "oip_remap_shift_rrc_bicubic_u16_window": ([_vp, _vp, _l, _l, _vp, _vp, _l, _i, _l, _l, _l, _i, _l, _d, _d, _i, _i], _i),
+    "oip_remap_shift_rrc_bicubic_u16_window": ([_vp, _vp, _l, _l, _vp, _vp, _l, _i, _l, _l, _l, _i, _l, _d, _d, _i, _i, _i], _i),
     "oip_remap_shift_src_range": ([_l, _l, _l, _d, _i, _lp, _lp], _i),
     "oip_align_mss_bicubic_u16x4": ([_vp, _vp, _sz, _l, _l, _vp, _l, _l, _i, _l, _dp, _dp, _i, _i, _i, _i, _i, _lp], _i),
     "oip_align_mss_src_range": ([_l, _l, _l, _dp, _i, _i, _i, _i, _i, _i, _lp, _lp], _i),
@@ -394,13 +394,13 @@ class Context:
                                                              1 if f16acc else 0))
 
     def remap_shift_rrc_bicubic_u16_window(self, src_raw, d_kb, dst, dst_pitch, dst_col0, dst_col_off, W, L, dx, dy, section_rows=30000,
-                                           row_guard=32767, src_row0=0, src_rows=None, out_row0=0, out_rows=None):
-        """the windowed resampling with the RAW strip as source: RRC applied on load (fp32; see include/oip_c.h)"""
+                                           row_guard=32767, src_row0=0, src_rows=None, out_row0=0, out_rows=None, f16acc=False):
+        """the windowed resampling with the RAW strip as source: RRC applied on load (see include/oip_c.h)"""
         src_rows = L if src_rows is None else src_rows
         out_rows = L if out_rows is None else out_rows
         self._ck(self.lib.oip_remap_shift_rrc_bicubic_u16_window(self.h, _ptr(src_raw), src_row0, src_rows, _ptr(d_kb), _ptr(dst), dst_pitch,
                                                                  dst_col0, dst_col_off, out_row0, out_rows, W, L, dx, dy, section_rows,
-                                                                 row_guard))
+                                                                 row_guard, 1 if f16acc else 0))
 
     def align_mss_bicubic_u16x4(self, planes, plane_stride, dst, Wb, Lm, cx, cy, lines_per_section=20000,
                                 line_offset=0, overlap=520, keep_leading=False, min_lines=1500,

@@ -813,15 +813,9 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         p1.release();
         prm.reset(IMO::LoadRRCParamFile(rrc2.c_str(), W));
         kb.upload((double *)prm.get(), (size_t)W * 2);
-        if (o.fp16acc) {
-            ck(oip_rrc_u16(ctx, p2.p, p2.p, W, L, kb.p));
-            ck(oip_remap_shift_bicubic_u16_window(ctx, p2.p, 0, L, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
-                                                  OIP_REMAP_ROW_GUARD, 1));
-        } else {
-            // the raw CCD-2 samples are corrected on load by the resampling kernel itself: one pass over the strip
-            ck(oip_remap_shift_rrc_bicubic_u16_window(ctx, p2.p, 0, L, kb.p, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
-                                                      OIP_REMAP_ROW_GUARD));
-        }
+        // the raw CCD-2 samples are corrected on load by the resampling kernel itself (either accumulate mode): one pass over the strip
+        ck(oip_remap_shift_rrc_bicubic_u16_window(ctx, p2.p, 0, L, kb.p, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
+                                                  OIP_REMAP_ROW_GUARD, o.fp16acc ? 1 : 0));
         std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
         st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());

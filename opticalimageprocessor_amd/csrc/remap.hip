@@ -15,6 +15,7 @@
 #include "oip_geom.h"
 #include "oip_internal.h"
 
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -209,6 +210,16 @@ __device__ __forceinline__ void load_raw6(const uint16_t *__restrict__ src, int 
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
     const long e0 = (long)row * W + c0;           // W even: parity of e0 == parity of c0
     const long d0 = e0 >> 1;
+    if ((long)(row + 2) * W <= nelem) {
+        // every line but the last of the buffer (uniform: the line comes from the row table): the six dwords end inside the
+        // next line at the latest -- one 64-bit address and six immediate offsets.  Clamping every dword index cost a 64-bit
+        // add, a 64-bit compare and two selects per dword: a quarter of the kernel's vector instructions, and the kernel is
+        // bound by them (round 3: 708 -> 530 per line and wave)
+        const uint32_t *q = p32 + d0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = q[i];
+        return;
+    }
     const long dmax = (nelem - 1) >> 1;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -333,127 +344,6 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
 // The same staging WITHOUT the correction is slower than remap_shift8_kernel's register window (3.47 against 3.19 ms on
 // two 30000 x 100000 segments, at 3 or 4 workgroups per CU): the plain call keeps the register form.
 constexpr int kLdsOut = kBlock - 2;
-
-__global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
-                                                                     const RowInfo *__restrict__ rows, int W, long out_rows,
-                                                                     long src_elems, double dx, const float *__restrict__ tab1d,
-                                                                     int rows_per_block, const double2 *__restrict__ kb, int ixmin8)
-{
-    __shared__ uint32_t lds[2][kBlock * 4];
-    const int X0 = blockIdx.x * kLdsOut * 8;
-    if (X0 + kLdsOut * 8 <= dw.col0) return;                         // nothing of this block is stored (uniform)
-    const int cbase = X0 + ixmin8;
-    const int cc = cbase + (int)threadIdx.x * 8;                     // the lane's chunk of source columns
-    const bool chunk_ok = cc >= 0 && cc + 8 <= W;                    // W % 8 == 0: a chunk is inside the line or outside it
-    double2 q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
-    const int x0 = X0 + (int)threadIdx.x * 8;
-    int c0 = 0, fx0 = 0;
-    const bool active = (int)threadIdx.x < kLdsOut && x0 < W && x0 + 8 > dw.col0 && shift_group_regular(x0, W, dx, &c0, &fx0);
-    const int d0 = active ? (c0 - cbase) >> 1 : 0;                   // host: 0 <= c0 - cbase, c0 - cbase + 10 < 2048
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > out_rows) r1 = out_rows;
-    const long src_lines = src_elems / W;
-    float wx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
-
-    int p = 0;
-    auto fetch = [&](long row) __attribute__((always_inline)) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (chunk_ok && row >= 0 && row < src_lines) v = *reinterpret_cast<const uint4 *>(src + row * W + cc);
-        return v;
-    };
-    auto stage = [&](uint4 v, float g[11]) __attribute__((always_inline)) {
-        v.x = oip_rrc_px(q[0].x, q[0].y, v.x & 0xffffu) | (oip_rrc_px(q[1].x, q[1].y, v.x >> 16) << 16);
-        v.y = oip_rrc_px(q[2].x, q[2].y, v.y & 0xffffu) | (oip_rrc_px(q[3].x, q[3].y, v.y >> 16) << 16);
-        v.z = oip_rrc_px(q[4].x, q[4].y, v.z & 0xffffu) | (oip_rrc_px(q[5].x, q[5].y, v.z >> 16) << 16);
-        v.w = oip_rrc_px(q[6].x, q[6].y, v.w & 0xffffu) | (oip_rrc_px(q[7].x, q[7].y, v.w >> 16) << 16);
-        reinterpret_cast<uint4 *>(lds[p])[threadIdx.x] = v;
-        __syncthreads();
-        if (active) {
-            uint32_t w[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) w[i] = lds[p][d0 + i];
-            expand_f32(w, c0, g);
-        }
-        p ^= 1;
-    };
-    float win[4][11];                             // tap line t at unrolled step k lives in win[(k+t)&3]
-    float w2d[16];
-    int cur_fy = -1;
-    // A run = consecutive regular output lines whose 4-line windows slide by one source line.  Its first three tap lines
-    // are staged at the run's start (k = 0 again), after that every output line stages exactly one new line.
-    long r = r0;
-    while (r < r1) {
-        const RowInfo h = rows[r];
-        if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
-        long qline = h.src[3];                    // chunks of source lines qline and qline + 1 are requested ahead (four
-        uint4 qa, qb;                             // ahead: the same 4.35 ms; as an array instead of named registers: spills)
-        {
-            const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
-            qa = fetch(qline);
-            qb = fetch(qline + 1);
-            stage(f0, win[0]);
-            stage(f1, win[1]);
-            stage(f2, win[2]);
-        }
-        int cur1 = h.src[0], cur2 = h.src[1], cur3 = h.src[2];
-        bool run = true;
-        while (run) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (r >= r1) { run = false; break; }
-                const RowInfo ri = rows[r];
-                if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
-                stage(qa, win[(k + 3) & 3]);
-                qa = qb;
-                qline += 1;
-                qb = fetch(qline + 1);
-                cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
-                const long rr_ = r;
-                ++r;
-                if (!active) continue;
-                if (ri.fy != cur_fy) {
-                    cur_fy = ri.fy;
-    #pragma unroll
-                    for (int ky = 0; ky < 4; ++ky) {
-                        const float wy = tab1d[cur_fy * 4 + ky];
-    #pragma unroll
-                        for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
-                    }
-                }
-                unsigned out[8];
-    #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float sum = 0.f;
-    #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float *L = win[(k + t) & 3];
-                        float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
-                        rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
-                        rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
-                        sum = t == 0 ? rr : __fadd_rn(sum, rr);
-                    }
-                    out[j] = oip_sat_u16(sum);
-                }
-                uint4 o;
-                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
-                uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
-                if (x0 >= dw.col0 && dw.vec) {
-                    *reinterpret_cast<uint4 *>(drow) = o;
-                } else {
-    #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
-                }
-            }
-        }
-    }
-}
 
 // ---- fp16-accumulate variant (BASELINE config 5: "fp16 accumulate, tolerance stated") ----------------------
 // Same geometry, phases, tap positions and border rules as remap_shift8_kernel; only the 16-tap sum of
@@ -606,6 +496,156 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
     }
 }
 
+// RRC on load, both accumulate modes (the block comment "RRC on load" above the fp16 helpers describes the kernel)
+template <bool F16>          // F16: the fp16-accumulate sums of remap_shift8_f16_kernel on the corrected samples
+__global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
+                                                                     const RowInfo *__restrict__ rows, int W, long out_rows,
+                                                                     long src_elems, double dx, const float *__restrict__ tab1d,
+                                                                     int rows_per_block, const double2 *__restrict__ kb, int ixmin8)
+{
+    __shared__ uint32_t lds[2][kBlock * 4];
+    const int X0 = blockIdx.x * kLdsOut * 8;
+    if (X0 + kLdsOut * 8 <= dw.col0) return;                         // nothing of this block is stored (uniform)
+    const int cbase = X0 + ixmin8;
+    const int cc = cbase + (int)threadIdx.x * 8;                     // the lane's chunk of source columns
+    const bool chunk_ok = cc >= 0 && cc + 8 <= W;                    // W % 8 == 0: a chunk is inside the line or outside it
+    double2 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
+    const int x0 = X0 + (int)threadIdx.x * 8;
+    int c0 = 0, fx0 = 0;
+    const bool active = (int)threadIdx.x < kLdsOut && x0 < W && x0 + 8 > dw.col0 && shift_group_regular(x0, W, dx, &c0, &fx0);
+    const int d0 = active ? (c0 - cbase) >> 1 : 0;                   // host: 0 <= c0 - cbase, c0 - cbase + 10 < 2048
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > out_rows) r1 = out_rows;
+    const long src_lines = src_elems / W;
+    float wx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
+
+    float win[F16 ? 1 : 4][11];                   // tap line t at unrolled step k lives in slot (k+t)&3
+    oip_h2 E[F16 ? 4 : 1][6], O[F16 ? 4 : 1][5];
+    typename std::conditional<F16, oip_h2, float>::type w2d[16];
+    int p = 0;
+    auto fetch = [&](long row) __attribute__((always_inline)) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (chunk_ok && row >= 0 && row < src_lines) v = *reinterpret_cast<const uint4 *>(src + row * W + cc);
+        return v;
+    };
+    auto stage = [&](uint4 v, int slot) __attribute__((always_inline)) {
+        v.x = oip_rrc_px(q[0].x, q[0].y, v.x & 0xffffu) | (oip_rrc_px(q[1].x, q[1].y, v.x >> 16) << 16);
+        v.y = oip_rrc_px(q[2].x, q[2].y, v.y & 0xffffu) | (oip_rrc_px(q[3].x, q[3].y, v.y >> 16) << 16);
+        v.z = oip_rrc_px(q[4].x, q[4].y, v.z & 0xffffu) | (oip_rrc_px(q[5].x, q[5].y, v.z >> 16) << 16);
+        v.w = oip_rrc_px(q[6].x, q[6].y, v.w & 0xffffu) | (oip_rrc_px(q[7].x, q[7].y, v.w >> 16) << 16);
+        reinterpret_cast<uint4 *>(lds[p])[threadIdx.x] = v;
+        __syncthreads();
+        if (active) {
+            uint32_t w[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = lds[p][d0 + i];
+            if constexpr (F16) expand_h(w, c0, E[slot], O[slot]);
+            else expand_f32(w, c0, win[slot]);
+        }
+        p ^= 1;
+    };
+    int cur_fy = -1;
+    // A run = consecutive regular output lines whose 4-line windows slide by one source line.  Its first three tap lines
+    // are staged at the run's start (k = 0 again), after that every output line stages exactly one new line.
+    long r = r0;
+    while (r < r1) {
+        const RowInfo h = rows[r];
+        if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
+        long qline = h.src[3];                    // chunks of source lines qline and qline + 1 are requested ahead (four
+        uint4 qa, qb;                             // ahead: the same 4.35 ms; as an array instead of named registers: spills)
+        {
+            const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
+            qa = fetch(qline);
+            qb = fetch(qline + 1);
+            stage(f0, 0);
+            stage(f1, 1);
+            stage(f2, 2);
+        }
+        int cur1 = h.src[0], cur2 = h.src[1], cur3 = h.src[2];
+        bool run = true;
+        while (run) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (r >= r1) { run = false; break; }
+                const RowInfo ri = rows[r];
+                if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
+                stage(qa, (k + 3) & 3);
+                qa = qb;
+                qline += 1;
+                qb = fetch(qline + 1);
+                cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+                const long rr_ = r;
+                ++r;
+                if (!active) continue;
+                if (ri.fy != cur_fy) {
+                    cur_fy = ri.fy;
+#pragma unroll
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const float wy = tab1d[cur_fy * 4 + ky];
+#pragma unroll
+                        for (int kx = 0; kx < 4; ++kx) {
+                            if constexpr (F16) {
+                                const _Float16 h = (_Float16)__fmul_rn(wy, wx[kx]);
+                                w2d[ky * 4 + kx] = oip_h2{h, h};
+                            } else {
+                                w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
+                            }
+                        }
+                    }
+                }
+                unsigned out[8];
+                if constexpr (F16) {
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
+                        oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
+                            acc = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc);
+                            acc = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc);
+                            acc = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc);
+                            acc = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc);
+                        }
+                        out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
+                        out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float sum = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float *L = win[(k + t) & 3];
+                            float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
+                            rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
+                            rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
+                            sum = t == 0 ? rr : __fadd_rn(sum, rr);
+                        }
+                        out[j] = oip_sat_u16(sum);
+                    }
+                }
+                uint4 o;
+                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+                uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
+                if (x0 >= dw.col0 && dw.vec) {
+                    *reinterpret_cast<uint4 *>(drow) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+                }
+            }
+        }
+    }
+}
+
+
 // fix-up A: irregular 8-column groups, all lines.  blockIdx.x = index into `groups`; the 256
 // lanes are 8 columns x 32 line sub-ranges.
 __global__ __launch_bounds__(kBlock) void remap_fix_cols_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
@@ -698,7 +738,6 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
                             int row_guard, bool f16acc, long dst_pitch = 0, int dst_col0 = 0, long dst_col_off = 0, const double *d_kb = nullptr)
 {
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb);
-    if (ctx && kb && f16acc) return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_rrc_bicubic_u16_window: RRC on load is an fp32 form");
     OIP_CHECK_CTX(ctx);
     if (dst_pitch <= 0) { dst_pitch = W; dst_col0 = 0; dst_col_off = 0; }
     if (dst_col0 < 0 || dst_col0 >= W || dst_col_off < 0 || dst_col_off + (W - dst_col0) > dst_pitch)
@@ -734,6 +773,8 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
     // RRC on load: the LDS-staged kernel fetches 16-byte chunks of the source lines; otherwise the general kernel (it
     // corrects on load as well)
     const bool lds = v8 && kb && (((uintptr_t)d_src) & 15) == 0;
+    if (kb && !lds && f16acc)
+        return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_rrc_bicubic_u16_window: the fp16-accumulate form needs W % 8 == 0 and a 16-byte aligned source");
     if (kb && !lds) v8 = false;
     const long fl = (long)floor(dx);
     const int ixmin8 = (int)(8 * ((fl - 2 >= 0 ? fl - 2 : fl - 2 - 7) / 8));
@@ -781,12 +822,15 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         long gy = (out_rows + rpb - 1) / rpb;
         if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
         {
-            OipProfScope prof(ctx, f16acc ? "remap_shift8_f16_kernel" : (lds ? "remap_shift8_rrc_kernel" : "remap_shift8_kernel"));
-            if (f16acc)
+            OipProfScope prof(ctx, lds ? (f16acc ? "remap_shift8_rrc_f16_kernel" : "remap_shift8_rrc_kernel") : (f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel"));
+            if (lds && f16acc)
+                hipLaunchKernelGGL(remap_shift8_rrc_kernel<true>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
+                                   out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
+            else if (f16acc)
                 hipLaunchKernelGGL(remap_shift8_f16_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
                                    src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
             else if (lds)
-                hipLaunchKernelGGL(remap_shift8_rrc_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
+                hipLaunchKernelGGL(remap_shift8_rrc_kernel<false>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
                                    out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
             else
                 hipLaunchKernelGGL(remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
@@ -852,12 +896,14 @@ extern "C" int oip_remap_shift_bicubic_u16_window(oip_ctx *ctx, const uint16_t *
 
 // The same with the source being the RAW CCD-2 strip: every sample is corrected on load (IMO::InplaceRRC's pixel, exact;
 // d_kb: the W (k, b) pairs), so Stitcher::DoRRC of CCD 2, PreStitch and the right half of StitchBigRaw are ONE pass over the
-// strip and <pan2>.RRC.RAW is not materialised either.  fp32 only.  Bits are those of RRC followed by the plain call.
+// strip and <pan2>.RRC.RAW is not materialised either.  Bits are those of RRC followed by the plain call in the same
+// accumulate mode (f16acc != 0: the fp16-accumulate sums; that mode needs a 16-byte aligned source and W % 8 == 0).
 extern "C" int oip_remap_shift_rrc_bicubic_u16_window(oip_ctx *ctx, const uint16_t *d_src_raw, long src_row0, long src_rows, const double *d_kb,
                                                       uint16_t *d_dst, long dst_pitch, int dst_col0, long dst_col_off, long out_row0,
-                                                      long out_rows, int W, long L, double dx, double dy, int section_rows, int row_guard)
+                                                      long out_rows, int W, long L, double dx, double dy, int section_rows, int row_guard,
+                                                      int f16acc)
 {
     if (ctx && (dst_pitch <= 0 || !d_kb)) return oip_fail(ctx, OIP_E_INVALID, "oip_remap_shift_rrc_bicubic_u16_window: bad argument");
-    return remap_shift_impl(ctx, d_src_raw, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, false,
+    return remap_shift_impl(ctx, d_src_raw, src_row0, src_rows, d_dst, out_row0, out_rows, W, L, dx, dy, section_rows, row_guard, f16acc != 0,
                             dst_pitch, dst_col0, dst_col_off, d_kb);
 }

@@ -714,10 +714,11 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
         backend.rrc(bufs.pan1, bufs.rrc1, W, plan.pb, kb1)
     transfers, need = plan.remap_transfers(lambda a, n: backend.remap_src_range(a, n, dy))
     f, l = need[rank]
-    if fused and not f16acc and not transfers:
+    if fused and not transfers:
         # no halo line moves anywhere (one rank) -- a decision every rank takes alike: the resampling kernel corrects the raw
         # CCD-2 samples on load -- DoRRC of CCD 2, PreStitch and the right half of the stitch are one pass, nothing in between
-        backend.remap_rrc_window(bufs.pan2, b0, plan.pb, kb2, stitched, 2 * (W - plan.fold), plan.fold, W - plan.fold, b0, plan.pb, dx, dy)
+        backend.remap_rrc_window(bufs.pan2, b0, plan.pb, kb2, stitched, 2 * (W - plan.fold), plan.fold, W - plan.fold, b0, plan.pb, dx, dy,
+                                 f16acc)
         return dx, dy, table
     bufs.alloc_rrc2(f, l)
     backend.rrc(bufs.pan2, bufs.rrc2[b0 - bufs.r2_first:b1 - bufs.r2_first], W, plan.pb, kb2)
@@ -799,10 +800,11 @@ class HipBackend:
     def rrc_window(self, src, src_pitch, dst, dst_pitch, w, h, kb):
         self.ctx.rrc_u16_window(src, src_pitch, dst, dst_pitch, w, h, kb)
 
-    def remap_rrc_window(self, src_raw, src_row0, src_rows, kb, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy):
+    def remap_rrc_window(self, src_raw, src_row0, src_rows, kb, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc=False):
         p = self.plan
         self.ctx.remap_shift_rrc_bicubic_u16_window(src_raw, kb, dst, dst_pitch, dst_col0, dst_col_off, p.W, p.L, dx, dy, p.section_rows,
-                                                    p.row_guard, src_row0=src_row0, src_rows=src_rows, out_row0=out_row0, out_rows=out_rows)
+                                                    p.row_guard, src_row0=src_row0, src_rows=src_rows, out_row0=out_row0, out_rows=out_rows,
+                                                    f16acc=f16acc)
 
     def remap_window(self, src, src_row0, src_rows, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc):
         p = self.plan

@@ -96,6 +96,6 @@ class OracleBackend:
         res, _ = oracle.prestitch(full, dx, dy, p.section_rows, p.row_guard)
         dst[:out_rows, dst_col_off:dst_col_off + p.W - dst_col0] = torch.from_numpy(res[out_row0:out_row0 + out_rows, dst_col0:])
 
-    def remap_rrc_window(self, src_raw, src_row0, src_rows, kb, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy):
+    def remap_rrc_window(self, src_raw, src_row0, src_rows, kb, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc=False):
         corrected = torch.from_numpy(oracle.rrc(np.ascontiguousarray(src_raw.numpy()), np.asarray(kb)))
-        self.remap_window(corrected, src_row0, src_rows, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, False)
+        self.remap_window(corrected, src_row0, src_rows, dst, dst_pitch, dst_col0, dst_col_off, out_row0, out_rows, dx, dy, f16acc)

@@ -207,7 +207,7 @@ def test_rrc_window(ctx, oracle_mod, w, spitch, dpitch, soff, doff):
     assert np.array_equal(got, canvas)
 
 
-@pytest.mark.parametrize("W,fold,dx,dy,f16", [(2048, 100, 3.37, -1.62, False), (2048, 100, 3.37, -1.62, True), (1016, 37, -2.25, 4.5, False),
+@pytest.mark.parametrize("W,fold,dx,dy,f16", [(2048, 100, 3.37, -1.62, False), (2048, 100, 3.37, -1.62, True), (1016, 37, -2.25, 4.5, False), (4096, 2500, -37.8, 2.25, True),
                                               (1001, 10, 0.5, -0.5, False), (4096, 2500, -37.8, 2.25, False),
                                               (6144, 40, 61.03, -0.75, False)])
 def test_remap_window_equals_remap_then_stitch(ctx, W, fold, dx, dy, f16):
@@ -229,25 +229,24 @@ def test_remap_window_equals_remap_then_stitch(ctx, W, fold, dx, dy, f16):
     ctx.remap_shift_bicubic_u16_window(src, got, 2 * (W - fold), fold, W - fold, W, L, dx, dy, f16acc=f16)
     ctx.sync()
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
-    if not f16:
-        # the RAW strip as source, corrected on load (oip_remap_shift_rrc_bicubic_u16_window): src is the RRC of `raw` under a
-        # LUT that maps 12-bit data onto other 12-bit data, so the three-pass result above is the reference bit for bit
-        kb = np.stack([np.full(W, 1.0), np.zeros(W)], 1)
-        kb[:, 0] += rng.integers(-3, 4, W) / 64.0
-        kb[:, 1] = rng.integers(-8, 9, W) / 4.0
-        raw = _cuda(rng.integers(16, 3900, (L, W), dtype=np.uint16))
-        d_kb = ctx.upload_kb(kb)
-        corrected = torch.empty_like(raw)
-        ctx.rrc_u16(raw, corrected, W, L, d_kb)
-        want2 = torch.zeros_like(want)
-        want2[:, :W - fold] = left[:, :W - fold]
-        ctx.remap_shift_bicubic_u16_window(corrected, want2, 2 * (W - fold), fold, W - fold, W, L, dx, dy)
-        got2 = torch.zeros_like(want)
-        got2[:, :W - fold] = left[:, :W - fold]
-        ctx.remap_shift_rrc_bicubic_u16_window(raw, d_kb, got2, 2 * (W - fold), fold, W - fold, W, L, dx, dy)
-        ctx.sync()
-        assert torch.equal(got2.view(torch.int16), want2.view(torch.int16))
-        assert not torch.equal(corrected.view(torch.int16), raw.view(torch.int16))
+    # the RAW strip as source, corrected on load (oip_remap_shift_rrc_bicubic_u16_window): src is the RRC of `raw` under a
+    # LUT that maps 12-bit data onto other 12-bit data, so the three-pass result above is the reference bit for bit
+    kb = np.stack([np.full(W, 1.0), np.zeros(W)], 1)
+    kb[:, 0] += rng.integers(-3, 4, W) / 64.0
+    kb[:, 1] = rng.integers(-8, 9, W) / 4.0
+    raw = _cuda(rng.integers(16, 3900, (L, W), dtype=np.uint16))
+    d_kb = ctx.upload_kb(kb)
+    corrected = torch.empty_like(raw)
+    ctx.rrc_u16(raw, corrected, W, L, d_kb)
+    want2 = torch.zeros_like(want)
+    want2[:, :W - fold] = left[:, :W - fold]
+    ctx.remap_shift_bicubic_u16_window(corrected, want2, 2 * (W - fold), fold, W - fold, W, L, dx, dy, f16acc=f16)
+    got2 = torch.zeros_like(want)
+    got2[:, :W - fold] = left[:, :W - fold]
+    ctx.remap_shift_rrc_bicubic_u16_window(raw, d_kb, got2, 2 * (W - fold), fold, W - fold, W, L, dx, dy, f16acc=f16)
+    ctx.sync()
+    assert torch.equal(got2.view(torch.int16), want2.view(torch.int16))
+    assert not torch.equal(corrected.view(torch.int16), raw.view(torch.int16))
     # a row-block shard of the same call (rows 20000..26000 with their halo) writes the same lines
     o0, n = 20000, 6000
     import opticalimageprocessor_amd as oip

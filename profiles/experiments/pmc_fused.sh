@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the fused cross-CCD step's kernels (bench.py --workload prestitch --fused), one rocprofv3 --pmc pass per set.
-#   bash profiles/experiments/pmc_fused.sh <tag> [extra bench flags]   -> gpurun_out/<tag>/pmc_fused.json
+#   [WL="--workload default"] bash profiles/experiments/pmc_fused.sh <tag> [extra bench flags]   -> gpurun_out/<tag>/pmc_fused.json
 set -o pipefail
 export TMPDIR=/tmp
 TAG=${1:-pmc_fused}; shift
@@ -13,7 +13,7 @@ SETS=(
 )
 i=0
 for S in "${SETS[@]}"; do
-  timeout -k 10 200 rocprofv3 --pmc $S --output-format csv -d $OUT/s$i -o pmc -- python3 bench.py --workload prestitch --fused --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/s$i.out 2> $OUT/s$i.err || { echo "set $i failed"; tail -3 $OUT/s$i.err; }
+  timeout -k 10 200 rocprofv3 --pmc $S --output-format csv -d $OUT/s$i -o pmc -- python3 bench.py ${WL:---workload prestitch --fused} --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs "$@" > $OUT/s$i.out 2> $OUT/s$i.err || { echo "set $i failed"; tail -3 $OUT/s$i.err; }
   i=$((i+1))
 done
 python3 - "$OUT" <<'PY'
@@ -28,7 +28,7 @@ for f in glob.glob(out + "/s*/**/*counter_collection.csv", recursive=True):
         acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
-    if not any(x in k for x in ("remap", "rrc", "stitch")): continue
+    if not any(x in k for x in ("remap", "rrc", "stitch", "align", "split", "pack_bands")): continue
     res[k] = {c: sum(v) / len(v) for c, v in d.items()}
     res[k]["_launches"] = max(len(v) for v in d.values())
 json.dump(res, open(out + "/pmc_fused.json", "w"), indent=1, sort_keys=True)

@@ -259,6 +259,34 @@ def test_remap_window_equals_remap_then_stitch(ctx, W, fold, dx, dy, f16):
     assert torch.equal(part.view(torch.int16), want[o0:o0 + n].view(torch.int16))
 
 
+def test_remap_rrc_on_load_with_a_misaligned_source(ctx):
+    """oip_remap_shift_rrc_bicubic_u16_window stages 16-byte chunks of the raw lines through LDS; a source that is only 4-byte
+    aligned takes the general kernel (which corrects on load as well) in fp32 -- same bits -- and is refused in the
+    fp16-accumulate mode (OIP_E_UNSUPPORTED, nothing written)."""
+    import torch
+    W, L, fold, dx, dy = 1024, 33000, 64, 1.37, -2.4
+    rng = _rng(77)
+    kb = np.stack([1.0 + rng.integers(-3, 4, W) / 64.0, rng.integers(-8, 9, W) / 4.0], 1)
+    d_kb = ctx.upload_kb(kb)
+    flat = _cuda(rng.integers(16, 3900, L * W + 8, dtype=np.uint16))
+    raw_al, raw_mis = flat[:L * W].view(L, W), flat[2:L * W + 2].view(L, W)
+    raw_copy = raw_mis.clone()                                   # the same lines in an aligned allocation
+    P = 2 * (W - fold)
+    want = torch.zeros(L, P, dtype=torch.uint16, device="cuda")
+    ctx.remap_shift_rrc_bicubic_u16_window(raw_copy, d_kb, want, P, fold, W - fold, W, L, dx, dy)
+    got = torch.zeros_like(want)
+    ctx.remap_shift_rrc_bicubic_u16_window(raw_mis, d_kb, got, P, fold, W - fold, W, L, dx, dy)
+    ctx.sync()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert int(want[:, W - fold:].to(torch.int32).max()) > 0
+    untouched = torch.full_like(want, 7)
+    with pytest.raises(NotImplementedError):                     # OIP_E_UNSUPPORTED in the Python binding
+        ctx.remap_shift_rrc_bicubic_u16_window(raw_mis, d_kb, untouched, P, fold, W - fold, W, L, dx, dy, f16acc=True)
+    ctx.sync()
+    assert int((untouched.to(torch.int32) != 7).sum()) == 0
+    del raw_al
+
+
 def test_rrc_idempotent_lut_full_size(ctx):
     """BASELINE config 2 size (30000 x 65536): k=1,b=0 is the identity, k=0,b=c a constant --
     size-independent properties, no oracle run at this size."""

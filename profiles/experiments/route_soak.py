@@ -5,7 +5,7 @@ import _synth
 ctx = oip.Context(0)
 s = torch.cuda.Stream(); torch.cuda.set_stream(s); ctx.set_stream(s.cuda_stream)
 worst = 0
-for seed in range(4):
+for seed in range(int(os.environ.get("SOAK_SEEDS", "4"))):
     L, W = 16000, 24000
     rng = np.random.default_rng(seed)
     shifts = [(int(rng.integers(-6, 7)), int(rng.integers(-6, 7))) for _ in range(4)]

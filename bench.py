@@ -315,8 +315,8 @@ def cpu_baseline_prestitch(W, L, sections, overlap=200):
 def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, threshold, reps=3):
     """PCIe-inclusive pass of the default action on one GPU: the raw rasters start in PAGEABLE host memory (the
     reference's heap buffers, imageop.h:52-82) and the aligned image ends in pageable host memory; file I/O is not
-    included.  Uploads run on a second host thread through the staging ring (oip_upload_staged), MSS first, then the
-    PAN strip in line blocks; each block is corrected as it lands, and a correlation section is computed as soon as its
+    included.  Uploads run on a second host thread through the staging ring (oip_upload_staged), section by section (its MSS
+    lines, then its PAN lines in blocks); each block is corrected as it lands, and a correlation section is computed as soon as its
     lines are resident -- so H2D, the RRC kernels and the FFT correlation overlap; the fit, the align kernel and the
     staged download of the aligned image follow.  Results are the bits of the HBM-resident step (same unit pairs)."""
     import queue
@@ -345,6 +345,23 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
             prev = e
         prev = max(prev, b)
     nblk = len(blocks)
+    # upload order: the MSS lines of a section go right before its PAN lines (a section's correlation needs only its own band
+    # windows), the MSS lines between the sections right after the last section -- they are needed by the align kernel only -- and
+    # the PAN lines between the sections last.  (Uploading the whole MSS strip first delayed the last section by 5 ms.)
+    order, mss_done = [], 0
+    blk_of_sec = [[i for i, (a, b) in enumerate(blocks[:n_sec_blocks]) if sa <= a and b <= sb] for sa, sb in sec_rows]
+    mss_ranges = [plan.section(s)[2:] for s in range(plan.sections)]
+    for s in range(plan.sections):
+        order.append(("mss",) + tuple(mss_ranges[s]))
+        order += [("pan", i) for i in blk_of_sec[s]]
+    prev = 0
+    for m0, m1 in sorted(mss_ranges) + [(mb, mb)]:
+        if prev < m0:
+            order.append(("mss", prev, m0))
+        prev = max(prev, m1)
+    n_before_fit = len(order)                      # every section and every MSS line is in after these
+    order += [("pan", i) for i in range(n_sec_blocks, nblk)]
+    bw = W // 4
     times, lane = [], []
     for rep in range(reps):
         raw_pan.zero_(); raw_mss.zero_(); out.zero_()
@@ -354,37 +371,42 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
         q = queue.Queue()
 
         def uploader():
-            q.put(("mss", ctx.upload_staged(raw_mss, host_mss, want_ticket=True)))
-            for i, (a, b) in enumerate(blocks):
-                q.put((i, ctx.upload_staged(raw_pan, host_pan[a:b], want_ticket=True, byte_offset=a * W * 2)))
+            for it in order:
+                if it[0] == "mss":
+                    q.put(ctx.upload_staged(raw_mss, host_mss[it[1]:it[2]], want_ticket=True, byte_offset=it[1] * W * 2))
+                else:
+                    a, b = blocks[it[1]]
+                    q.put(ctx.upload_staged(raw_pan, host_pan[a:b], want_ticket=True, byte_offset=a * W * 2))
         th = threading.Thread(target=uploader)
         th.start()
-        _, t = q.get()
-        ctx.stage_wait(t)
-        ctx.mss_split_rrc_u16(raw_mss, bufs.planes.data_ptr() + 2 * bufs.own_planes_offset(), bufs.plane_stride, W, mb, d_kb_mss)
         shifts = np.full((4, plan.n_units, 4), np.nan)
         for u in range(plan.n_units):
             shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2
         next_sec = 0
         cx = cy = None
-        for i in range(nblk):
-            _, t = q.get()
-            ctx.stage_wait(t)
-            a, b = blocks[i]
-            ctx.rrc_u16(raw_pan.data_ptr() + a * W * 2, bufs.pan.data_ptr() + a * W * 2, W, b - a, d_kb_pan)
-            # sections are uploaded whole and in order: section s is resident when its last block has landed
-            while next_sec < plan.sections and b == sec_rows[next_sec][1] and i < n_sec_blocks:
-                units = range(next_sec * plan.slices, (next_sec + 1) * plan.slices)
-                wins = [bufs.unit_windows(u) for u in units]
-                res = ctx.interband_correlate_units([w[0].data_ptr() for w in wins], [w[0].stride(0) for w in wins],
-                                                    [[x.data_ptr() for x in w[1]] for w in wins], [w[1][0].stride(0) for w in wins],
-                                                    plan.base_rows, plan.base_cols)
-                for j, u in enumerate(units):
-                    shifts[:, u, :3] = res[j]
-                next_sec += 1
-            if i == n_sec_blocks - 1:
-                # every section is in: fit, align and bring the aligned image down while the uploader thread is still
-                # sending the PAN lines between the sections (the download lane of the staging layer is independent)
+        for n, it in enumerate(order):
+            ctx.stage_wait(q.get())
+            if it[0] == "mss":
+                m0, m1 = it[1], it[2]
+                ctx.mss_split_rrc_u16(raw_mss.data_ptr() + m0 * W * 2, bufs.planes.data_ptr() + 2 * (bufs.own_planes_offset() + m0 * bw),
+                                      bufs.plane_stride, W, m1 - m0, d_kb_mss)
+            else:
+                i = it[1]
+                a, b = blocks[i]
+                ctx.rrc_u16(raw_pan.data_ptr() + a * W * 2, bufs.pan.data_ptr() + a * W * 2, W, b - a, d_kb_pan)
+                # sections are uploaded whole and in order: section s is resident when its last block has landed
+                while next_sec < plan.sections and b == sec_rows[next_sec][1] and i < n_sec_blocks:
+                    units = range(next_sec * plan.slices, (next_sec + 1) * plan.slices)
+                    wins = [bufs.unit_windows(u) for u in units]
+                    res = ctx.interband_correlate_units([w[0].data_ptr() for w in wins], [w[0].stride(0) for w in wins],
+                                                        [[x.data_ptr() for x in w[1]] for w in wins], [w[1][0].stride(0) for w in wins],
+                                                        plan.base_rows, plan.base_cols)
+                    for j, u in enumerate(units):
+                        shifts[:, u, :3] = res[j]
+                    next_sec += 1
+            if n == n_before_fit - 1:
+                # every section and the whole MSS strip are in: fit, align and bring the aligned image down while the uploader
+                # thread is still sending the PAN lines between the sections (the download lane of the staging layer is independent)
                 cx, cy = oip.filter_and_fit(shifts, threshold, 5)
                 ctx.align_mss_bicubic_u16x4(bufs.planes.data_ptr() + 2 * bufs.own_planes_offset(), bufs.plane_stride, out, W // 4, plan.Lm, cx, cy,
                                             plan.lps, plan.line_offset, plan.overlap, plan.keep, plan.min_lines)
@@ -402,8 +424,8 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
             "upload_lane": {"seconds_in_pageable_to_pinned_copies": cs, "seconds_waiting_for_a_ring_slot": ws, "GB": nb / 1e9,
                             "note": "the uploader thread's own time (oip_stage_stats): copies into the pinned ring vs waiting for a "
                                     "slot whose DMA has not finished -- the second is the link's share of the pass"},
-            "what": "pageable host rasters -> pinned staging ring -> H2D (PAN in %d line blocks on a second thread: the lines of "
-                    "the correlation sections first, the lines between them last) || RRC per block || correlation per section "
+            "what": "pageable host rasters -> pinned staging ring -> H2D (on a second thread: per section its MSS lines, then its PAN "
+                    "lines in blocks -- %d PAN blocks in all; the lines between the sections last) || RRC per block || correlation per section "
                     "as its lines land -> fit -> align -> staged D2H of the aligned image into pageable memory, under the rest of "
                     "the upload; file I/O excluded; best of %d" % (nblk, reps)}, (cx, cy)
 

@@ -351,9 +351,23 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
     order, mss_done = [], 0
     blk_of_sec = [[i for i, (a, b) in enumerate(blocks[:n_sec_blocks]) if sa <= a and b <= sb] for sa, sb in sec_rows]
     mss_ranges = [plan.section(s)[2:] for s in range(plan.sections)]
+    # Tried and switched off (OIP_E2E_SPLIT=1 turns it on): the LAST section in two groups of column slices (a unit is a column slice
+    # of all 16000 lines; oip_upload_staged_2d), so that the first group's correlation runs under the upload of the second.  The 2-D
+    # copies into the ring (24-36 KB rows instead of one 32 MiB run) cost the upload lane 21 ms more than the 7 ms the overlap
+    # returns: 164 ms against 154.
+    split = (plan.slices * 6 // 10) * plan.base_cols if plan.slices >= 4 and os.environ.get("OIP_E2E_SPLIT") == "1" else 0
+    mss_first = os.environ.get("OIP_E2E_MSS_FIRST") == "1"       # A/B switch: the whole MSS strip first (the order before round 3)
+    if mss_first:
+        order.append(("mss", 0, mb))
+        mss_ranges = [(0, mb)]
     for s in range(plan.sections):
-        order.append(("mss",) + tuple(mss_ranges[s]))
-        order += [("pan", i) for i in blk_of_sec[s]]
+        if not mss_first:
+            order.append(("mss",) + tuple(mss_ranges[s]))
+        if s == plan.sections - 1 and split:
+            order += [("pan2d", i, 0, split) for i in blk_of_sec[s]] + [("units", s, 0, split)]
+            order += [("pan2d", i, split, W) for i in blk_of_sec[s]] + [("units", s, split, W)]
+        else:
+            order += [("pan", i) for i in blk_of_sec[s]] + [("units", s, 0, W)]
     prev = 0
     for m0, m1 in sorted(mss_ranges) + [(mb, mb)]:
         if prev < m0:
@@ -374,36 +388,44 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
             for it in order:
                 if it[0] == "mss":
                     q.put(ctx.upload_staged(raw_mss, host_mss[it[1]:it[2]], want_ticket=True, byte_offset=it[1] * W * 2))
-                else:
+                elif it[0] == "pan":
                     a, b = blocks[it[1]]
                     q.put(ctx.upload_staged(raw_pan, host_pan[a:b], want_ticket=True, byte_offset=a * W * 2))
+                elif it[0] == "pan2d":
+                    a, b = blocks[it[1]]
+                    q.put(ctx.upload_staged_2d(raw_pan, W * 2, host_pan[a:b, it[2]:it[3]], want_ticket=True, byte_offset=(a * W + it[2]) * 2))
         th = threading.Thread(target=uploader)
         th.start()
         shifts = np.full((4, plan.n_units, 4), np.nan)
         for u in range(plan.n_units):
             shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2
-        next_sec = 0
         cx = cy = None
         for n, it in enumerate(order):
-            ctx.stage_wait(q.get())
+            if it[0] == "units":
+                # the lines (and columns) of these units are resident: their blocks were waited for above
+                sec, c0, c1 = it[1], it[2], it[3]
+                units = [u for u in range(sec * plan.slices, (sec + 1) * plan.slices)
+                         if c0 <= (u % plan.slices) * plan.base_cols and ((u % plan.slices) + 1) * plan.base_cols <= c1]
+                wins = [bufs.unit_windows(u) for u in units]
+                res = ctx.interband_correlate_units([w[0].data_ptr() for w in wins], [w[0].stride(0) for w in wins],
+                                                    [[x.data_ptr() for x in w[1]] for w in wins], [w[1][0].stride(0) for w in wins],
+                                                    plan.base_rows, plan.base_cols)
+                for j, u in enumerate(units):
+                    shifts[:, u, :3] = res[j]
+            else:
+                ctx.stage_wait(q.get())
             if it[0] == "mss":
                 m0, m1 = it[1], it[2]
                 ctx.mss_split_rrc_u16(raw_mss.data_ptr() + m0 * W * 2, bufs.planes.data_ptr() + 2 * (bufs.own_planes_offset() + m0 * bw),
                                       bufs.plane_stride, W, m1 - m0, d_kb_mss)
-            else:
-                i = it[1]
-                a, b = blocks[i]
+            elif it[0] == "pan":
+                a, b = blocks[it[1]]
                 ctx.rrc_u16(raw_pan.data_ptr() + a * W * 2, bufs.pan.data_ptr() + a * W * 2, W, b - a, d_kb_pan)
-                # sections are uploaded whole and in order: section s is resident when its last block has landed
-                while next_sec < plan.sections and b == sec_rows[next_sec][1] and i < n_sec_blocks:
-                    units = range(next_sec * plan.slices, (next_sec + 1) * plan.slices)
-                    wins = [bufs.unit_windows(u) for u in units]
-                    res = ctx.interband_correlate_units([w[0].data_ptr() for w in wins], [w[0].stride(0) for w in wins],
-                                                        [[x.data_ptr() for x in w[1]] for w in wins], [w[1][0].stride(0) for w in wins],
-                                                        plan.base_rows, plan.base_cols)
-                    for j, u in enumerate(units):
-                        shifts[:, u, :3] = res[j]
-                    next_sec += 1
+            elif it[0] == "pan2d":
+                a, b = blocks[it[1]]
+                c0, c1 = it[2], it[3]
+                ctx.rrc_u16_window(raw_pan.data_ptr() + (a * W + c0) * 2, W, bufs.pan.data_ptr() + (a * W + c0) * 2, W, c1 - c0, b - a,
+                                   d_kb_pan[c0:])
             if n == n_before_fit - 1:
                 # every section and the whole MSS strip are in: fit, align and bring the aligned image down while the uploader
                 # thread is still sending the PAN lines between the sections (the download lane of the staging layer is independent)

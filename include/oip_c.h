@@ -127,6 +127,10 @@ int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t offset, size_
 int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append);
 /* the same between a pageable host buffer and HBM (copies to/from the pinned ring run on a thread pool) */
 int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes, long *ticket);
+/* the same for a 2-D block (a column block of a raster): `rows` rows of `width` bytes; host rows src_pitch bytes apart,
+ * device rows dst_pitch bytes apart; width at most 32 MiB */
+int oip_upload_staged_2d(oip_ctx *ctx, void *d_dst, size_t dst_pitch, const void *host, size_t src_pitch, size_t width,
+                         size_t rows, long *ticket);
 int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes);
 int oip_stage_wait(oip_ctx *ctx, long ticket);
 int oip_stage_sync(oip_ctx *ctx);

@@ -65,6 +65,7 @@ _SIGS = {
     "oip_read_file_to_device": ([_vp, _cp, _sz, _sz, _vp, C.POINTER(_sz), _lp], _i),
     "oip_write_device_to_file": ([_vp, _vp, _sz, _cp, _i], _i),
     "oip_upload_staged": ([_vp, _vp, _vp, _sz, _lp], _i),
+    "oip_upload_staged_2d": ([_vp, _vp, _sz, _vp, _sz, _sz, _sz, _lp], _i),
     "oip_download_staged": ([_vp, _vp, _vp, _sz], _i),
     "oip_stage_wait": ([_vp, _l], _i),
     "oip_stage_sync": ([_vp], _i),
@@ -300,6 +301,14 @@ class Context:
         t = C.c_long()
         self._ck(self.lib.oip_upload_staged(self.h, _ptr(d_dst) + byte_offset, host.ctypes.data, host.nbytes,
                                             C.byref(t) if want_ticket else None))
+        return t.value if want_ticket else None
+
+    def upload_staged_2d(self, d_dst, dst_pitch_bytes, host: np.ndarray, want_ticket=False, byte_offset=0):
+        """a 2-D host view (rows contiguous, any row stride) into device rows dst_pitch_bytes apart"""
+        assert host.ndim == 2 and host.strides[1] == host.itemsize and host.strides[0] >= host.shape[1] * host.itemsize
+        t = C.c_long()
+        self._ck(self.lib.oip_upload_staged_2d(self.h, _ptr(d_dst) + byte_offset, dst_pitch_bytes, host.ctypes.data, host.strides[0],
+                                               host.shape[1] * host.itemsize, host.shape[0], C.byref(t) if want_ticket else None))
         return t.value if want_ticket else None
 
     def download_staged(self, host: np.ndarray, d_src, byte_offset=0):

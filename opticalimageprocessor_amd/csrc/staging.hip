@@ -51,12 +51,33 @@ public:
         const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
         {
             std::unique_lock<std::mutex> lk(mMu);
-            mDst = (char *)dst; mSrc = (const char *)src; mBytes = bytes; mPart = part;
+            mDst = (char *)dst; mSrc = (const char *)src; mBytes = bytes; mPart = part; mWidth = 0;
             mPending = (int)mWorkers.size();
             ++mGen;
         }
         mCv.notify_all();
         memcpy(dst, src, part < bytes ? part : bytes);                 // the caller takes piece 0
+        std::unique_lock<std::mutex> lk(mMu);
+        mDone.wait(lk, [&] { return mPending == 0; });
+    }
+    // rows of `width` bytes, the pitches in bytes: the rows are dealt over the threads in contiguous runs
+    void copy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows)
+    {
+        const int n = threads();
+        auto run = [&](size_t r0, size_t r1) {
+            for (size_t r = r0; r < r1; ++r) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
+        };
+        if (n == 1 || width * rows < ((size_t)4 << 20)) { run(0, rows); return; }
+        std::lock_guard<std::mutex> one_at_a_time(mCall);
+        const size_t part = (rows + n - 1) / n;
+        {
+            std::unique_lock<std::mutex> lk(mMu);
+            mDst = (char *)dst; mSrc = (const char *)src; mBytes = rows; mPart = part; mWidth = width; mDPitch = dpitch; mSPitch = spitch;
+            mPending = (int)mWorkers.size();
+            ++mGen;
+        }
+        mCv.notify_all();
+        run(0, part < rows ? part : rows);
         std::unique_lock<std::mutex> lk(mMu);
         mDone.wait(lk, [&] { return mPending == 0; });
     }
@@ -87,10 +108,15 @@ private:
             mCv.wait(lk, [&] { return mGen != seen; });
             seen = mGen;
             if (mStop) return;
-            char *d = mDst; const char *s = mSrc; const size_t bytes = mBytes, part = mPart;
+            char *d = mDst; const char *s = mSrc; const size_t bytes = mBytes, part = mPart, width = mWidth, dp = mDPitch, sp = mSPitch;
             lk.unlock();
             const size_t off = (size_t)idx * part;
-            if (off < bytes) memcpy(d + off, s + off, bytes - off < part ? bytes - off : part);
+            if (width == 0) {
+                if (off < bytes) memcpy(d + off, s + off, bytes - off < part ? bytes - off : part);
+            } else {                                                    // 2-D: bytes = rows, part = rows per thread
+                const size_t r1 = off + part < bytes ? off + part : bytes;
+                for (size_t r = off; r < r1; ++r) memcpy(d + r * dp, s + r * sp, width);
+            }
             lk.lock();
             if (--mPending == 0) mDone.notify_one();
         }
@@ -103,7 +129,7 @@ private:
     bool mStop = false;
     char *mDst = nullptr;
     const char *mSrc = nullptr;
-    size_t mBytes = 0, mPart = 0;
+    size_t mBytes = 0, mPart = 0, mWidth = 0, mDPitch = 0, mSPitch = 0;
 };
 
 constexpr int kSlots = 4;
@@ -384,6 +410,43 @@ extern "C" int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, si
         const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
         timed_copy(s, s->slot[i], (const char *)host + done, n);
         OIP_HIP(ctx, hipMemcpyAsync((char *)d_dst + done, s->slot[i], n, hipMemcpyHostToDevice, s->stream));
+        hipEventRecord(s->slot_free[i], s->stream);
+        s->slot_used[i] = true;
+        done += n;
+    }
+    const long t = ticket_issue(ctx, s);
+    if (ticket) *ticket = t;
+    else OIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ticket_ev[t % kTicketRing], 0));
+    return OIP_OK;
+}
+
+// The same for a 2-D block: `rows` rows of `width` bytes, host rows src_pitch bytes apart, device rows dst_pitch bytes apart
+// (a column block of a raster: the units of a correlation section are column slices, so a section can arrive slice group by
+// slice group and the first group's correlation runs under the upload of the second).
+extern "C" int oip_upload_staged_2d(oip_ctx *ctx, void *d_dst, size_t dst_pitch, const void *host, size_t src_pitch, size_t width, size_t rows,
+                                    long *ticket)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (((!d_dst || !host) && width && rows) || width > dst_pitch || width > src_pitch || width > kSlotBytes)
+        return oip_fail(ctx, OIP_E_INVALID, "oip_upload_staged_2d: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    std::lock_guard<std::mutex> lane(s->ring_mu);
+    ++s->ring_calls;
+    size_t done = 0;
+    const size_t per = width ? kSlotBytes / width : rows;
+    while (done < rows && width) {
+        int i;
+        if ((rc = slot_acquire(ctx, s, &i))) return rc;
+        const size_t n = rows - done < per ? rows - done : per;
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            CopyPool::get().copy2d(s->slot[i], width, (const char *)host + done * src_pitch, src_pitch, width, n);
+            s->copy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            s->ring_bytes += (long)(width * n);
+        }
+        OIP_HIP(ctx, hipMemcpy2DAsync((char *)d_dst + done * dst_pitch, dst_pitch, s->slot[i], width, width, n, hipMemcpyHostToDevice, s->stream));
         hipEventRecord(s->slot_free[i], s->stream);
         s->slot_used[i] = true;
         done += n;

@@ -287,6 +287,28 @@ def test_remap_rrc_on_load_with_a_misaligned_source(ctx):
     del raw_al
 
 
+def test_upload_staged_2d_column_block(ctx):
+    """oip_upload_staged_2d: a column block of a pageable raster into the same columns of a device raster, through the pinned ring
+    (more than one 32 MiB slot), with a ticket; the columns beside it stay as they were."""
+    import torch
+    L, W, c0, c1 = 9000, 6000, 1504, 5008
+    rng = _rng(9)
+    host = rng.integers(0, 65536, (L, W), dtype=np.uint16)
+    dev = torch.full((L, W), 0x1111, dtype=torch.int32, device="cuda").to(torch.int16).view(torch.uint16)
+    t = ctx.upload_staged_2d(dev, W * 2, host[:, c0:c1], want_ticket=True, byte_offset=c0 * 2)
+    ctx.stage_wait(t)
+    ctx.sync()
+    got = _u16(dev)
+    want = np.full((L, W), 0x1111, np.uint16)
+    want[:, c0:c1] = host[:, c0:c1]
+    assert np.array_equal(got, want)
+    # a row range of the block, no ticket (the compute stream is ordered behind it by the call)
+    ctx.upload_staged_2d(dev, W * 2, host[100:200, 0:64], byte_offset=100 * W * 2)
+    ctx.sync()
+    want[100:200, 0:64] = host[100:200, 0:64]
+    assert np.array_equal(_u16(dev), want)
+
+
 def test_rrc_idempotent_lut_full_size(ctx):
     """BASELINE config 2 size (30000 x 65536): k=1,b=0 is the identity, k=0,b=c a constant --
     size-independent properties, no oracle run at this size."""

@@ -617,7 +617,24 @@ def summarise(env, d, p, elapsed, steps, prof_all, prof, dom):
                                 "the x4 up-sampling operator in one pass over the data; it moves its algorithmic bytes once "
                                 "(traffic / algorithmic = 1.01) and is bound by vector-instruction issue, not by HBM "
                                 "(DESIGN.md 4.3) -- the HBM-bound passes of the step run at 3.6-5.8 TB/s")
+                gf = row_stage_gflop(d.M, d.N)
+                roof["vector_f32"] = {"achieved": gf / avg_s / 1e3, "peak": VECTOR_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": gf / avg_s / 1e3 / VECTOR_F32_PEAK_TFLOPS, "algorithmic_gflop_per_launch": gf,
+                                      "model": ROW_STAGE_FLOP_MODEL}
     return ms_per_step, value, kernels, roof
+
+
+VECTOR_F32_PEAK_TFLOPS = 157.3          # MI355X vector fp32 (packed FMA; /opt/skills/guides/MI355X_MICROARCH.md)
+ROW_STAGE_FLOP_MODEL = ("nominal flops of one corr_rows_up_kernel launch (a pair of M x N units, spectral x4 up-sampling): complex "
+                        "n-point transforms at 5 n log2 n -- 5 M of length N (1 forward + 4 inverse) and 4 M of length N/4 (the band lines); "
+                        "4 M N output bins x 2 cross-powers x 12 flops (complex product, magnitude, division); horizontal expansion "
+                        "H z + 4 G e per band bin: 4 M N x 38; vertical expansion on the way into LDS: M N x 38")
+
+
+def row_stage_gflop(M, N):
+    """ROW_STAGE_FLOP_MODEL in numbers: 29.9 GFLOP for M = 16000, N = 3000"""
+    fft = lambda n: 5.0 * n * np.log2(n)
+    return (5 * M * fft(N) + 4 * M * fft(N / 4) + 4.0 * M * N * 24 + 4.0 * M * N * 38 + 1.0 * M * N * 38) / 1e9
 
 
 def rrc_line(kernels):

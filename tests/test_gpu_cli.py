@@ -231,6 +231,13 @@ def test_fused_task_equals_the_five_command_flow(ctx, tmp_path):
                 "--fold-cols-pan", "40", "--out-pan", "fused-PAN-only.TIFF"] + stt + plain
     run(pan_only)
     assert open(os.path.join(d, "fused-PAN-only.TIFF"), "rb").read() == open(os.path.join(d, "fused-PAN.TIFF"), "rb").read()
+    # the same pair in the fp16-accumulate mode (RRC on load in remap_shift8_rrc_kernel<true> against RRC + the fp16 resampling
+    # kernel + stitch of the full task): one file again, and not the fp32 one
+    run(task + ["--fp16-accumulate", "--out-pan", "fused16-PAN.TIFF", "--out-mss", "fused16-MSS.TIFF"] + plain)
+    run(pan_only[:-len(stt + plain) - 1] + ["fused16-PAN-only.TIFF", "--fp16-accumulate"] + stt + plain)
+    f16 = open(os.path.join(d, "fused16-PAN.TIFF"), "rb").read()
+    assert open(os.path.join(d, "fused16-PAN-only.TIFF"), "rb").read() == f16
+    assert f16 != open(os.path.join(d, "fused-PAN.TIFF"), "rb").read()
     # argument errors keep the CLI's codes
     r = subprocess.run([OIP, "task", "--pan1", "A_PAN-1.RAW"], cwd=d, env=env, capture_output=True, text=True)
     assert r.returncode == 106

@@ -64,6 +64,9 @@ def parse():
                          ".RRC.PRESTT.RAW not materialised)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive pass from pageable host buffers")
+    ap.add_argument("--no-cli", action="store_true", help="skip the timed run of the `oip` executable on files in tmpfs (the `cli` object)")
+    ap.add_argument("--full-record", default=None,
+                    help="where the verbose record goes (default gpurun_out/bench_full.json); stdout carries the compact line")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short legs for the other single-GPU BASELINE configs (2, 3, 5 at N=1, 12288-wide) that "
                          "the default one-GPU run attaches as `configs`")
@@ -88,6 +91,11 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         # row stage of a pair of units with the up-sampling applied to the band spectra: PAN_A + i PAN_B in (1 array),
         # every line of the four band transforms read once per frequency line it serves (4 x 1/4 array), four outputs
         "corr_rows_up_kernel": 8.0 * MN * 6.0,
+        # row stage of ONE unit of the 1250-point geometry (12288-wide strips), vertical up-sampling on the spectra: the PAN array,
+        # two quarter-height band arrays in, two outputs
+        "corr_rows_v_kernel": 8.0 * MN * 3.5,
+        # horizontal taps of that geometry: the four u16 band windows of a unit in, two bands per complex value out ((M/4) x 4N)
+        "hpack_bands_kernel": 4 * 2.0 * win / 16.0 + 8.0 * (M / 4.0) * (4.0 * N),
         # column passes of one quarter-width band array (two vertically up-sampled f32 images in): OIP_SPECTRAL_UP=1
         "fft_pass_ct_kernel_F128_pack_quarter": 8.0 * MN / 4.0 + 2 * 4.0 * win / 4.0,
         "fft_pass_ct_kernel_F125_quarter": 16.0 * MN / 4.0,
@@ -452,6 +460,95 @@ def end_to_end_default(ctx, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, ou
                     "the upload; file I/O excluded; best of %d" % (nblk, reps)}, (cx, cy)
 
 
+def cli_default_action(env, d, kb_mss, threshold):
+    """The PRODUCT timed, file I/O included: `lib/oip --pan P.RAW --mss M.RAW --do-rrc4pan ...` (the C++ host's pipelined default
+    action, csrc/oip_host.hpp PreProcessor::RunPipelined) on the headline strip written to files in tmpfs by this harness.  Wall time
+    of the whole process and the log's own stage times (the TIMING line: seconds since the action started), for the aligned product
+    uncompressed (`raw`), with <pan>.RRC.RAW as well (`raw_rrcpan`), in the reference's LZW + predictor encoding (`lzw`) and for the
+    step-by-step flow (OIP_PIPELINE=0, the reference's order of work).  The uncompressed product is compared with the resident
+    step's aligned image."""
+    import shutil
+    import subprocess
+    import tempfile
+    ctx, torch = env.ctx, env.torch
+    W, pb, mb = d.W, d.pb, d.plan.mb
+    exe = os.path.join(ROOT, "opticalimageprocessor_amd", "lib", "oip")
+    if not os.path.exists(exe):
+        return {"error": "lib/oip not built"}
+    base = os.environ.get("OIP_BENCH_TMP", "/dev/shm")
+    tmp = tempfile.mkdtemp(prefix="oip_bench_", dir=base if os.path.isdir(base) and os.access(base, os.W_OK) else None)
+    try:
+        t0 = time.time()
+        host = np.empty((pb, W), np.uint16)
+        ctx.download_staged(host, d.raw_pan)
+        host.tofile(os.path.join(tmp, "B_PAN.RAW"))
+        host = np.empty((mb, W), np.uint16)
+        ctx.download_staged(host, d.raw_mss)
+        host.tofile(os.path.join(tmp, "B_MSS.RAW"))
+        del host
+
+        def csv(name, kb):
+            with open(os.path.join(tmp, name), "w") as f:
+                f.write("1\n%d\n0\n" % len(kb))
+                f.write("".join("%.6f , %.4f\n" % (k, b) for k, b in kb))
+        csv("PAN.csv", d.kb_pan)
+        bw = W // 4
+        for b in range(4):
+            csv("MSS.B%d.csv" % (b + 1), kb_mss[b * bw:(b + 1) * bw])
+        want = d.out[..., [2, 1, 0, 3]].contiguous().cpu().numpy()          # the product's payload: cv::imwrite's sample order
+        t_inputs = time.time() - t0
+        args = [exe, "--width", str(W), "--pan", "B_PAN.RAW", "--mss", "B_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv",
+                "--slices", str(d.plan.slices), "--ibc-sections", str(d.plan.sections), "--ibc-threshold", repr(threshold),
+                "--lines-section", str(d.plan.lps), "--line-offset", str(d.plan.line_offset), "--overlap-lines", str(d.plan.overlap)]
+        for b in range(4):
+            args += ["--rrc-msb%d" % (b + 1), "MSS.B%d.csv" % (b + 1)]
+        runs = {}
+        same = None
+        plan = [("raw", {"OIP_TIFF_COMPRESS": "none"}, []), ("raw_again", {"OIP_TIFF_COMPRESS": "none"}, []),
+                ("raw_rrcpan", {"OIP_TIFF_COMPRESS": "none"}, ["--write-rrcpan"]), ("lzw", {}, []),
+                ("steps_raw", {"OIP_TIFF_COMPRESS": "none", "OIP_PIPELINE": "0"}, [])]
+        for name, extra_env, extra_args in plan:
+            for f in ("B_MSS.ALIGNED.TIFF", "B_PAN.RRC.RAW"):
+                if os.path.exists(os.path.join(tmp, f)):
+                    os.remove(os.path.join(tmp, f))
+            e = dict(os.environ, LOGFILE=os.path.join(tmp, "oip.log"))
+            e.pop("OIP_TIFF_COMPRESS", None)
+            e.update(extra_env)
+            t1 = time.perf_counter()
+            r = subprocess.run(args + extra_args, cwd=tmp, env=e, capture_output=True, text=True)
+            wall = time.perf_counter() - t1
+            rec = {"wall_ms": wall * 1e3, "exit": r.returncode}
+            for ln in r.stdout.splitlines():
+                if ln.startswith("TIMING default_action"):
+                    rec["log_seconds"] = {k: float(v) for k, v in (kv.split("=") for kv in ln.split()[2:])}
+            if r.returncode != 0:
+                rec["tail"] = (r.stdout + r.stderr)[-400:]
+            prod = os.path.join(tmp, "B_MSS.ALIGNED.TIFF")
+            if os.path.exists(prod):
+                rec["product_bytes"] = os.path.getsize(prod)
+            if name == "raw" and r.returncode == 0:
+                with open(prod, "rb") as f:
+                    big = f.read(4)[2] == 43
+                got = np.fromfile(prod, np.uint16, count=want.size, offset=16 if big else 8).reshape(want.shape)
+                same = bool(np.array_equal(got, want))
+                del got
+            runs[name] = rec
+        best = min((runs[k] for k in ("raw", "raw_again") if runs[k]["exit"] == 0), key=lambda r_: r_["wall_ms"], default=None)
+        out = {"runs": runs, "aligned_product_equals_resident_step": same, "inputs_written_s": t_inputs, "tmp": base,
+               "bytes_in": int((pb + mb) * W * 2), "what": ("wall time of the `oip` executable (process start, HIP initialisation, file reads, "
+               "kernels, product writes) on %dx%d PAN + MSS files in tmpfs; log_seconds = the log's TIMING line, seconds since the action "
+               "started (products_written: everything on disk)" % (W, pb))}
+        if best:
+            ls = best.get("log_seconds", {})
+            out.update({"wall_ms": best["wall_ms"], "pipeline_ms": ls.get("products_written", 0.0) * 1e3,
+                        "read_GBs": out["bytes_in"] / ls["read_done"] / 1e9 if ls.get("read_done") else None,
+                        "Mpix_s_wall": 1.25 * W * pb / best["wall_ms"] / 1e3,
+                        "Mpix_s_pipeline": 1.25 * W * pb / ls["products_written"] / 1e6 if ls.get("products_written") else None})
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 class Params:
     def __init__(self, **kw):
         self.__dict__.update(kw)
@@ -719,8 +816,94 @@ def config_legs(env, args, line):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this process -- which never touches the GPU -- starts the N ranks as child
+    processes of the same command line (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1),
+    relays rank 0's JSON line and exits with the worst exit code.  Under torch.distributed.run the ranks arrive with WORLD_SIZE
+    set and this is not used."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def compact_line(line, full_path):
+    """What goes to stdout: the contract's keys, `roofline`, `cpu_baseline`, and a summary of everything else INSIDE `config` (the
+    driver's record keeps `config` whole) -- the verbose record (per-kernel tables, every leg's kernels, the CPU samples) goes to
+    `full_path`.  Kept under 8 KB."""
+    c = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                              "vs_baseline", "dtype", "data") if k in line}
+    cfg = dict(line["config"])
+    e2e = line.get("end_to_end")
+    if e2e:
+        cfg["end_to_end_ms"] = round(e2e["ms_per_pass"], 2)
+        cfg["end_to_end_Mpix_s"] = round(e2e["value"], 1)
+        cfg["end_to_end_same_fit_as_resident_step"] = e2e.get("same_fit_as_resident_step")
+        cfg["rrc_host_buffer_Gpix_s"] = round(e2e.get("rrc_host_buffer_Gpix_s", 0.0), 2)
+    cli = line.get("cli")
+    if cli and "runs" in cli:
+        cfg["cli_wall_ms"] = {k: round(v["wall_ms"], 1) for k, v in cli["runs"].items()}
+        cfg["cli_pipeline_ms"] = {k: round(v["log_seconds"]["products_written"] * 1e3, 1) for k, v in cli["runs"].items() if "log_seconds" in v}
+        cfg["cli_read_GBs"] = round(cli["read_GBs"], 1) if cli.get("read_GBs") else None
+        cfg["cli_product_equals_resident_step"] = cli.get("aligned_product_equals_resident_step")
+    legs = {}
+    for name, e in (line.get("configs") or {}).items():
+        dk = e.get("dominant_kernel") or {}
+        cb = e.get("cpu_baseline") or {}
+        legs[name] = [round(e["ms_per_step"], 3), dk.get("kernel"), round(dk["frac"], 4) if dk.get("frac") is not None else None,
+                      round(cb["value"]) if cb.get("value") else None]
+        for k in ("fp16_vs_fp32", "stitched_equals_the_three_pass_flow"):
+            if k in e:
+                legs[name].append({k: e[k]["max_abs_delta_DN"] if isinstance(e[k], dict) else e[k]})
+    if legs:
+        cfg["legs"] = legs
+        cfg["legs_fields"] = "ms_per_step, dominant kernel, its fraction of the 8 TB/s HBM peak, CPU baseline Mpix/s (all cores)"
+    if line.get("multi_gpu"):
+        cfg["multi_gpu"] = line["multi_gpu"]
+    c["config"] = cfg
+    roof = line.get("roofline")
+    if roof:
+        c["roofline"] = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                              "avg_launch_ms") if k in roof}
+        if "vector_f32" in roof:
+            c["roofline"]["vector_f32_frac"] = round(roof["vector_f32"]["frac"], 4)
+        if roof.get("traffic") is not None:
+            c["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of this command; not re-measured in this run)"
+    else:
+        c["roofline"] = None
+    cb = line.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        c["cpu_baseline"]["sample"] = cb["sample"][:420]
+        for k in ("rrc_reference_1thread_Mpix_s", "rrc_all_cores_Mpix_s"):
+            if k in cb:
+                c["cpu_baseline"][k] = round(cb[k], 1)
+    if line.get("rrc_kernel"):
+        c["rrc_kernel"] = {k: round(v, 4) for k, v in line["rrc_kernel"].items()}
+    if line.get("shift"):
+        c["shift"] = line["shift"]
+    c["value_note"] = ("`value`: rasters resident in HBM when the timed region starts; PCIe-inclusive = config.end_to_end_*, file-inclusive "
+                       "(the `oip` executable) = config.cli_*")
+    c["full_record"] = full_path
+    return c
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     import opticalimageprocessor_amd as oip
@@ -729,10 +912,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world                    # under a launcher the launcher's world size is the truth
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     # OIP_BENCH_BACKEND=gloo rehearses the N-rank path on a box with fewer GPUs than ranks
@@ -818,10 +998,20 @@ def main():
             e2e["rrc_host_buffer_Gpix_s"] = hb.size / dt / 1e9
             del hb
             line["end_to_end"] = e2e
+        if world == 1 and args.workload == "default" and not args.no_cli:
+            kb_mss = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
+            line["cli"] = cli_default_action(env, d, kb_mss, p.threshold)
         if world == 1 and args.workload == "default" and not args.no_configs and W == 30000 and pb == 100000:
             d = None                        # release the headline workload's rasters before the other configurations
             line["configs"] = config_legs(env, args, line)
-        print(json.dumps(line))
+        full = args.full_record or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+        try:
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            with open(full, "w") as f:
+                json.dump(line, f)
+        except OSError:
+            full = None
+        print(json.dumps(compact_line(line, full and os.path.relpath(full, ROOT))))
     if world > 1:
         dist.destroy_process_group()
     ctx.close()

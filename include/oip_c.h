@@ -105,15 +105,19 @@ int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *
 
 /* ---- raster I/O staging (imageop.h:43-127, stitcher.h:103-120) ---------------------------------------
  * IMO::ReadFileContent + LoadRawImage / WriteBufferToFile move a raster through one pageable heap buffer,
- * serially with the arithmetic.  These entry points move it in 32 MiB blocks through a ring of pinned
- * buffers on a staging stream of the context's own, so disk, host copies, PCIe and the kernels of the
- * compute stream overlap.  Staging calls may run on other host threads while the first drives kernels
- * through the same context: they use streams and pinned slots of their own and never touch the compute
- * stream's state.  Calls of one lane serialise on a lock (ring lane: read_file / write_file / upload_staged /
- * rrc_u16_host; download lane: download_staged), the two lanes run concurrently (full duplex).
- * Ordering: downloads and file writes start after the compute-stream work enqueued before the call; UPLOADS
- * DO NOT wait for the compute stream -- before re-uploading into a buffer that queued kernels still read,
- * call oip_stage_order_after_compute(ctx) (or upload elsewhere).
+ * serially with the arithmetic (8 MiB fread / fwrite units on the calling thread, imageop.h:69-79, :88-95).
+ * These entry points move it in 32 MiB blocks through a ring of pinned buffers on a staging stream of the
+ * context's own -- a slot is filled from the file by parallel pread on the host copy pool -- so disk, host
+ * copies, PCIe and the kernels of the compute stream overlap.  Staging calls may run on other host threads
+ * while the first drives kernels through the same context: they use streams and pinned slots of their own,
+ * set the context's device for the calling thread, and never touch the compute stream's state.  Calls of one
+ * lane serialise on a lock (ring lane: read_file / upload_staged / rrc_u16_host; download lane:
+ * download_staged[_after] / write_file[_at]), the two lanes run concurrently (full duplex): a reader thread,
+ * the compute thread and a writer thread form the pipeline of the `oip` CLI's default action.
+ * Ordering: downloads and file writes start after the compute-stream work enqueued before the call, or after
+ * a MARK of the compute stream (oip_compute_mark) when one is given; UPLOADS DO NOT wait for the compute
+ * stream -- before re-uploading into a buffer that queued kernels still read, call
+ * oip_stage_order_after_compute(ctx) (or upload elsewhere).
  *   ticket != NULL : the call returns once the last block's DMA is ENQUEUED and *ticket identifies it;
  *                    oip_stage_wait(ctx, t) makes the compute stream wait (on the device) for everything up
  *                    to t.  ticket == NULL: the compute stream is ordered behind the transfer by the call itself.
@@ -125,6 +129,16 @@ int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t offset, size_
 /* WriteBufferToFile(buff, size, saveFilePath) with `buff` in HBM (append != 0: "ab", as the section writes of
  * stitcher.h:114-120 accumulate one output file) */
 int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append);
+/* the same into an EXISTING or new file at byte `file_offset` without truncating it (the file grows as needed): a product
+ * written block by block as its lines become final -- <pan>.RRC.RAW while the strip is still being read, the pixel payload
+ * of an uncompressed TIFF (oip_tiff.hpp) behind its header.  mark: 0, or a mark of the compute stream to wait for. */
+int oip_write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, size_t file_offset, long mark);
+/* A MARK names the compute-stream work enqueued so far (an event from a ring of 64; taken by the compute thread, e.g. right
+ * after the RRC kernel of a line block).  A download-lane transfer given the mark starts once that work is done, not after
+ * what the compute thread enqueued later (a 12-ms correlation batch, say).  A mark that has left the ring means "everything
+ * enqueued so far". */
+int oip_compute_mark(oip_ctx *ctx, long *mark);
+int oip_compute_mark_sync(oip_ctx *ctx, long mark);   /* the calling host thread waits for the mark */
 /* the same between a pageable host buffer and HBM (copies to/from the pinned ring run on a thread pool) */
 int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes, long *ticket);
 /* the same for a 2-D block (a column block of a raster): `rows` rows of `width` bytes; host rows src_pitch bytes apart,
@@ -132,6 +146,7 @@ int oip_upload_staged(oip_ctx *ctx, void *d_dst, const void *host, size_t bytes,
 int oip_upload_staged_2d(oip_ctx *ctx, void *d_dst, size_t dst_pitch, const void *host, size_t src_pitch, size_t width,
                          size_t rows, long *ticket);
 int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes);
+int oip_download_staged_after(oip_ctx *ctx, void *host, const void *d_src, size_t bytes, long mark);
 int oip_stage_wait(oip_ctx *ctx, long ticket);
 int oip_stage_sync(oip_ctx *ctx);
 int oip_stage_order_after_compute(oip_ctx *ctx);      /* the ring lane's later transfers wait for the compute stream's work enqueued so far */
@@ -294,6 +309,12 @@ int oip_align_mss_src_range(long out_row0, long out_rows, long Lm, const double 
  * right[fold:W]; `fold` is the already-halved value (main.cpp:189). */
 int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_right,
                         uint16_t *d_out, int W, long L, int fold);
+
+/* In-place sample permutation of an interleaved 4-channel u16 image: sample i of every pixel becomes the former sample
+ * order[i].  cv::imwrite stores a 4-channel Mat (c0,c1,c2,c3) as samples (c2,c1,c0,c3) (preproc.h:167-185 WriteAlignedMSS_TIFF;
+ * imageop.h:390-402), GDAL writes band b from channel bandMap[b]-1 (imageop.h:529): with the image already in file order on the
+ * device, its lines go from HBM into the TIFF's pixel payload without a host pass.  d_img 16-byte aligned. */
+int oip_permute_u16x4(oip_ctx *ctx, uint16_t *d_img, size_t npixels, const int *order);
 
 /* ---- instrumentation --------------------------------------------------------------- */
 /* name + accumulated device time of the kernels launched through this context since the

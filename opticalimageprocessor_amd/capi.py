@@ -64,6 +64,11 @@ _SIGS = {
     "oip_rrc_u16_host": ([_vp, _vp, _i, _l, _dp], _i),
     "oip_read_file_to_device": ([_vp, _cp, _sz, _sz, _vp, C.POINTER(_sz), _lp], _i),
     "oip_write_device_to_file": ([_vp, _vp, _sz, _cp, _i], _i),
+    "oip_write_device_to_file_at": ([_vp, _vp, _sz, _cp, _sz, _l], _i),
+    "oip_compute_mark": ([_vp, _lp], _i),
+    "oip_compute_mark_sync": ([_vp, _l], _i),
+    "oip_download_staged_after": ([_vp, _vp, _vp, _sz, _l], _i),
+    "oip_permute_u16x4": ([_vp, _vp, _sz, C.POINTER(_i)], _i),
     "oip_upload_staged": ([_vp, _vp, _vp, _sz, _lp], _i),
     "oip_upload_staged_2d": ([_vp, _vp, _sz, _vp, _sz, _sz, _sz, _lp], _i),
     "oip_download_staged": ([_vp, _vp, _vp, _sz], _i),
@@ -296,6 +301,21 @@ class Context:
     def write_device_to_file(self, d_src, nbytes, path, append=False):
         self._ck(self.lib.oip_write_device_to_file(self.h, _ptr(d_src), nbytes, os.fsencode(path), int(append)))
 
+    def write_device_to_file_at(self, d_src, nbytes, path, file_offset, mark=0, byte_offset=0):
+        self._ck(self.lib.oip_write_device_to_file_at(self.h, _ptr(d_src) + byte_offset, nbytes, os.fsencode(path), file_offset, mark))
+
+    def compute_mark(self):
+        m = C.c_long()
+        self._ck(self.lib.oip_compute_mark(self.h, C.byref(m)))
+        return m.value
+
+    def compute_mark_sync(self, mark):
+        self._ck(self.lib.oip_compute_mark_sync(self.h, mark))
+
+    def permute_u16x4(self, img, npixels, order):
+        o = (C.c_int * 4)(*[int(v) for v in order])
+        self._ck(self.lib.oip_permute_u16x4(self.h, _ptr(img), npixels, o))
+
     def upload_staged(self, d_dst, host: np.ndarray, want_ticket=False, byte_offset=0):
         assert host.flags.c_contiguous
         t = C.c_long()
@@ -311,9 +331,9 @@ class Context:
                                                host.shape[1] * host.itemsize, host.shape[0], C.byref(t) if want_ticket else None))
         return t.value if want_ticket else None
 
-    def download_staged(self, host: np.ndarray, d_src, byte_offset=0):
+    def download_staged(self, host: np.ndarray, d_src, byte_offset=0, mark=0):
         assert host.flags.c_contiguous and host.flags.writeable
-        self._ck(self.lib.oip_download_staged(self.h, host.ctypes.data, _ptr(d_src) + byte_offset, host.nbytes))
+        self._ck(self.lib.oip_download_staged_after(self.h, host.ctypes.data, _ptr(d_src) + byte_offset, host.nbytes, mark))
 
     def stage_wait(self, ticket):
         self._ck(self.lib.oip_stage_wait(self.h, ticket))

@@ -21,10 +21,16 @@
 #include <cstring>
 #include <ctime>
 #include <chrono>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <filesystem>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "oip_c.h"
@@ -34,6 +40,7 @@ namespace OIPGPU {
 
 struct errno_error : public std::runtime_error {      // libimsux errno_error stand-in (same role)
     explicit errno_error(const std::string &s) : std::runtime_error(s + ": " + std::strerror(errno)) {}
+    errno_error(const std::string &complete, int) : std::runtime_error(complete) {}   // the C ABI's message already names the errno
 };
 struct usage_error : public std::invalid_argument {   // main.cpp:20-23
     explicit usage_error(const std::string &s) : std::invalid_argument(s) {}
@@ -94,6 +101,65 @@ inline std::string to_lower(std::string s)
     return s;
 }
 
+// ---- small threading helpers of the pipelined actions ----------------------------------------------------
+template <typename T> class BlockingQueue {
+public:
+    void push(T v)
+    {
+        { std::lock_guard<std::mutex> lk(mMu); mQ.push_back(std::move(v)); }
+        mCv.notify_one();
+    }
+    T pop()
+    {
+        std::unique_lock<std::mutex> lk(mMu);
+        mCv.wait(lk, [&] { return !mQ.empty(); });
+        T v = std::move(mQ.front());
+        mQ.pop_front();
+        return v;
+    }
+private:
+    std::mutex mMu;
+    std::condition_variable mCv;
+    std::deque<T> mQ;
+};
+
+// a thread that runs jobs in the order they are posted (a product writer: HBM -> file beside the compute thread); the
+// first exception stops it and is re-thrown by finish()
+class JobThread {
+public:
+    JobThread() : mThread([this] { loop(); }) {}
+    ~JobThread() { try { finish(); } catch (...) {} }
+    void post(std::function<void()> job) { mQ.push(std::move(job)); }
+    void finish()
+    {
+        if (mThread.joinable()) { mQ.push(nullptr); mThread.join(); }
+        if (mError) { auto e = mError; mError = nullptr; std::rethrow_exception(e); }
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job = mQ.pop();
+            if (!job) return;
+            if (mError) continue;                 // drain after a failure
+            try { job(); } catch (...) { mError = std::current_exception(); }
+        }
+    }
+    BlockingQueue<std::function<void()>> mQ;
+    std::exception_ptr mError;
+    std::thread mThread;
+};
+
+inline double seconds_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+inline std::chrono::steady_clock::time_point &process_start()
+{
+    static std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    return t;
+}
+
 // ---- device context + error mapping ----------------------------------------------------------
 class Device {
 public:
@@ -104,23 +170,29 @@ public:
     }
     oip_ctx *ctx()
     {
-        if (!mCtx && oip_create(0, &mCtx) != OIP_OK)
-            throw std::runtime_error("no usable MI355X (gfx950) device: this build has no CPU fallback");
+        if (!mCtx) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (oip_create(0, &mCtx) != OIP_OK)
+                throw std::runtime_error("no usable MI355X (gfx950) device: this build has no CPU fallback");
+            mCreateSeconds = seconds_since(t0);
+        }
         return mCtx;
     }
+    double create_seconds() const { return mCreateSeconds; }
     void check(int rc)
     {
         if (rc == OIP_OK) return;
         std::string m = oip_last_error(mCtx);
         switch (rc) {
             case OIP_E_INVALID: throw std::invalid_argument(m);
-            case OIP_E_IO: throw std::runtime_error(m);
+            case OIP_E_IO: throw errno_error(m, 0);
             default: throw std::runtime_error(m);
         }
     }
     ~Device() { if (mCtx) oip_destroy(mCtx); }
 private:
     oip_ctx *mCtx = nullptr;
+    double mCreateSeconds = 0.0;
 };
 
 template <typename T> struct DevBuf {              // RAII device buffer
@@ -690,6 +762,293 @@ public:
         auto save = IMO::BuildOutputFilePath(mPanFile, ".RRC");
         mPAN.save_file(save, mSizePAN / 2);
         OLOG("Written to file [%s].", save.c_str());
+    }
+
+    // ---- the default action (main.cpp:288-317) as ONE pipeline ------------------------------------------------------
+    // The reference runs LoadPAN, LoadMSS, DoRRC4PAN, DoRRC4MSS, CalcInterBandCorrelation and DoInterBandAlignment one after
+    // the other, each over the whole strip (preproc.h:51-80, :188-222, :224-347, :351-425), and so do the step methods above.
+    // Here three host threads share the context:
+    //   reader   the two RAW files go file -> pinned ring -> HBM (oip_read_file_to_device, parallel pread) in the order the
+    //            arithmetic needs them: per correlation section its MSS lines, then its PAN lines in blocks; the MSS lines
+    //            between the sections; the PAN lines between the sections last.  Every block carries a ticket.
+    //   compute  (this thread) waits for a block's ticket on the device, corrects it (RRC in place / BIL split + RRC), runs a
+    //            section's phase correlations as soon as its lines are resident (the pairs of units of the one-call form are
+    //            kept, so the shifts are the serial run's bits), then filter + fit, the alignment kernel and the sample
+    //            permutation of the product -- while the reader is still bringing the PAN lines between the sections.
+    //   writers  <pan>.RRC.RAW goes out block by block behind the RRC kernel of each block (--write-rrcpan), the aligned image
+    //            goes HBM -> pinned -> <mss>.ALIGNED.TIFF (uncompressed: straight into the file's pixel payload; LZW: strips
+    //            encoded on a few threads as their lines come down).
+    // Products are byte-identical to the step-by-step flow's (tests/test_gpu_cli.py runs both; OIP_PIPELINE=0 selects the steps).
+    struct DefaultActionOptions {
+        bool doRRC4PAN = false, writeRrcPan = false, doRRC4MSS = true, keepLeading = false;
+        int slices = OIP_IBCV_DEF_SLICES, sections = OIP_IBCV_DEF_SECTIONS;
+        double threshold = OIP_IBCV_DEF_THRESHOLD;
+        int linesSection = OIP_IBPA_DEFAULT_BATCHLINES, lineOffset = 0, overlapLines = OIP_IBPA_DEFAULT_LINEOVERLAP;
+    };
+
+    void RunPipelined(const DefaultActionOptions &o)
+    {
+        oip_ctx *ctx = Device::get().ctx();
+        auto ck = [](int rc) { Device::get().check(rc); };
+        const auto t0 = std::chrono::steady_clock::now();
+        const int W = mW, Wb = W / MSS_BANDS;
+        const long Lp = (long)mLinesPAN, Lm = (long)mLinesMSS;
+        // the argument checks of CalcInterBandCorrelation (preproc.h:228-237) and DoInterBandAlignment, before a byte is read
+        char msg[256];
+        if (o.slices < OIP_IBCV_MIN_SLICES) {
+            snprintf(msg, sizeof msg, "CalcInterBandCorrelation: at lease %d slice needed", OIP_IBCV_MIN_SLICES);
+            throw std::invalid_argument(msg);
+        }
+        if (o.sections <= 0) throw std::invalid_argument("CalcInterBandCorrelation: section count should be a positive integer");
+        if (o.sections > 1 && (long)o.sections * OIP_CORRELATION_LINES > Lp) {
+            snprintf(msg, sizeof msg, "CalcInterBandCorrelation: too many sections (%d lines per section), not enough total PAN data lines", OIP_CORRELATION_LINES);
+            throw std::invalid_argument(msg);
+        }
+        const long outRows = Lm - o.lineOffset - (o.keepLeading ? 0 : o.overlapLines);
+        if (outRows <= 0) throw std::invalid_argument("Too few image lines left to process");
+        // preproc.h:245-247, :274-276
+        const int baseRows = (int)std::min<long>(Lp, OIP_CORRELATION_LINES), baseCols = W / o.slices;
+        const long baseGap = (Lp - (long)baseRows * o.sections) / (o.sections + 1);
+        const int bandRows = baseRows / MSS_BANDS, bandCols = baseCols / MSS_BANDS;
+        const long bandGap = baseGap / MSS_BANDS;
+        if (bandRows <= 0 || bandCols <= 0) throw std::invalid_argument("oip_interband_correlate: slice too small");
+        std::vector<long> p0(o.sections), m0(o.sections);
+        for (int sec = 0; sec < o.sections; ++sec) {
+            p0[sec] = baseGap + (long)sec * (baseRows + baseGap);                 // preproc.h:257
+            m0[sec] = bandGap + (long)sec * (bandRows + bandGap);                 // preproc.h:284
+            if (p0[sec] + baseRows > Lp || m0[sec] + bandRows > Lm) throw std::invalid_argument("oip_interband_correlate: section outside the strip");
+        }
+        // LUTs
+        DevBuf<double> kbPan, kbMss;
+        if (o.doRRC4PAN) {
+            std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile(mRrcPanFile.c_str(), W));
+            kbPan.alloc((size_t)W * 2);
+            kbPan.upload((double *)prm.get(), (size_t)W * 2);
+        }
+        if (o.doRRC4MSS) {
+            std::vector<double> all((size_t)W * 2);
+            for (int i = 0; i < MSS_BANDS; ++i) {
+                std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile(mRrcMssBndFile[i].c_str(), Wb));
+                memcpy(&all[(size_t)i * Wb * 2], prm.get(), sizeof(double) * 2 * Wb);
+            }
+            kbMss.alloc((size_t)W * 2);
+            kbMss.upload(all.data(), (size_t)W * 2);
+        }
+        mPAN.alloc((size_t)W * Lp);
+        mMssBil.alloc((size_t)W * Lm);
+        mPlaneStride = (size_t)Wb * Lm;
+        mPlanes.alloc(mPlaneStride * MSS_BANDS);
+        DevBuf<uint16_t> out((size_t)outRows * Wb * MSS_BANDS);
+        const double tSetup = seconds_since(t0);
+
+        // ---- the order of arrival
+        enum Kind { kMss, kPan, kUnits, kFit };
+        struct Item { Kind kind; long a, b; };
+        std::vector<Item> order;
+        const long blockLines = std::max<long>(1, (long)(((size_t)256 << 20) / ((size_t)W * BYTES_PER_PIXEL)));
+        auto pan_blocks = [&](long a, long b) { for (long r = a; r < b; r += blockLines) order.push_back({kPan, r, std::min(b, r + blockLines)}); };
+        for (int sec = 0; sec < o.sections; ++sec) {
+            order.push_back({kMss, m0[sec], m0[sec] + bandRows});
+            pan_blocks(p0[sec], p0[sec] + baseRows);
+            order.push_back({kUnits, sec, 0});
+        }
+        {   // the MSS lines between the sections: only the alignment reads them
+            long prev = 0;
+            for (int sec = 0; sec <= o.sections; ++sec) {
+                const long a = sec < o.sections ? m0[sec] : Lm;
+                if (prev < a) order.push_back({kMss, prev, a});
+                prev = sec < o.sections ? m0[sec] + bandRows : Lm;
+            }
+        }
+        order.push_back({kFit, 0, 0});
+        {   // the PAN lines between the sections: no arithmetic of this action reads them (they are read and corrected as
+            // the reference does -- the strip's size is checked, --write-rrcpan wants them)
+            long prev = 0;
+            for (int sec = 0; sec <= o.sections; ++sec) {
+                const long a = sec < o.sections ? p0[sec] : Lp;
+                if (prev < a) pan_blocks(prev, a);
+                prev = sec < o.sections ? p0[sec] + baseRows : Lp;
+            }
+        }
+
+        // ---- reader thread
+        OLOG("Loading PAN raw image ...");
+        OLOG("Loading MSS raw image ...");
+        OLOG("Reading raw image from file `%s' ...", mPanFile.c_str());
+        OLOG("Reading raw image from file `%s' ...", mMssFile.c_str());
+        BlockingQueue<long> tickets;                       // one per read item, in order; -1: the reader failed
+        std::atomic<bool> cancel{false};
+        std::exception_ptr readerError;
+        double tReadDone = 0.0;
+        const size_t lineBytes = (size_t)W * BYTES_PER_PIXEL;
+        std::thread reader([&] {
+            try {
+                for (const Item &it : order) {
+                    if (it.kind != kMss && it.kind != kPan) continue;
+                    if (cancel.load()) break;
+                    const bool pan = it.kind == kPan;
+                    const size_t off = (size_t)it.a * lineBytes, n = (size_t)(it.b - it.a) * lineBytes;
+                    size_t got = 0;
+                    long t = 0;
+                    const int rc = oip_read_file_to_device(ctx, (pan ? mPanFile : mMssFile).c_str(), off, n,
+                                                           (char *)(pan ? mPAN.p : mMssBil.p) + off, &got, &t);
+                    if (rc != OIP_OK) Device::get().check(rc);
+                    if (got != n)
+                        throw std::runtime_error("file size(" + std::to_string(pan ? mSizePAN : mSizeMSS) + ") doesn't match with read byte count(" +
+                                                 std::to_string(off + got) + ")");
+                    tickets.push(t);
+                }
+                tReadDone = seconds_since(t0);
+            } catch (...) {
+                readerError = std::current_exception();
+                tickets.push(-1);
+            }
+        });
+        double tCorrDone = 0.0, tAlignDone = 0.0;
+        std::string alignedPath;
+        std::unique_ptr<TiffWriterU16> tiff;               // (declared before the writers: their jobs use it)
+        JobThread panWriter, productWriter;
+        struct Joiner {                                    // whatever happens below, the threads are stopped and joined
+            std::thread &reader; std::atomic<bool> &cancel;
+            ~Joiner() { cancel = true; if (reader.joinable()) reader.join(); }
+        } joiner{reader, cancel};
+
+        const std::string rrcPanPath = IMO::BuildOutputFilePath(mPanFile, ".RRC");
+        if (o.writeRrcPan) {                               // sized up front: blocks land at their offsets in any order
+            FILE *f = fopen(rrcPanPath.c_str(), "wb");
+            if (!f) throw std::runtime_error("open file [" + rrcPanPath + "] failed: " + std::to_string(errno));
+            fclose(f);
+        }
+        if (o.doRRC4PAN) OLOG("Begin inplace RRC for PAN data ... ");
+        OLOG("Splitting %d bands of MSS image%s ...", MSS_BANDS, o.doRRC4MSS ? " with inplace RRC" : "");
+        OLOG("Calculating inter-band correlation with %d slices in %d section(s) ...", o.slices, o.sections);
+
+        const int n = o.slices * o.sections;
+        std::vector<double> table((size_t)MSS_BANDS * n * 4, NAN);
+        for (int b = 0; b < MSS_BANDS; ++b)
+            for (int u = 0; u < n; ++u) table[((size_t)b * n + u) * 4 + 3] = (double)((u % o.slices) * baseCols + baseCols / 2);   // preproc.h:326
+        int unitsDone = 0;
+        for (const Item &it : order) {
+            if (it.kind == kMss || it.kind == kPan) {
+                const long t = tickets.pop();
+                if (t < 0) { reader.join(); std::rethrow_exception(readerError); }
+                ck(oip_stage_wait(ctx, t));
+                if (it.kind == kMss) {
+                    ck(oip_mss_split_rrc_u16(ctx, mMssBil.p + (size_t)it.a * W, mPlanes.p + (size_t)it.a * Wb, mPlaneStride, W, it.b - it.a,
+                                             o.doRRC4MSS ? kbMss.p : nullptr));
+                } else {
+                    uint16_t *blk = mPAN.p + (size_t)it.a * W;
+                    if (o.doRRC4PAN) ck(oip_rrc_u16(ctx, blk, blk, W, it.b - it.a, kbPan.p));
+                    if (o.writeRrcPan) {
+                        long mark = 0;
+                        ck(oip_compute_mark(ctx, &mark));
+                        const size_t off = (size_t)it.a * lineBytes, nb = (size_t)(it.b - it.a) * lineBytes;
+                        panWriter.post([=] { Device::get().check(oip_write_device_to_file_at(ctx, blk, nb, rrcPanPath.c_str(), off, mark)); });
+                    }
+                }
+            } else if (it.kind == kUnits) {
+                // the units of the sections resident so far, in the pairs (2k, 2k+1) of the one-call form (a pair that spans two
+                // sections -- odd slice counts -- waits for the second)
+                const int sec = (int)it.a;
+                int hi = (sec + 1) * o.slices;
+                if (sec != o.sections - 1) hi &= ~1;
+                const int cnt = hi - unitsDone;
+                if (cnt <= 0) continue;
+                std::vector<const uint16_t *> dPan(cnt), dBands((size_t)cnt * MSS_BANDS);
+                std::vector<size_t> panPitch(cnt, (size_t)W), bandPitch(cnt, (size_t)Wb);
+                for (int j = 0; j < cnt; ++j) {
+                    const int u = unitsDone + j, us = u / o.slices, i = u % o.slices;
+                    dPan[j] = mPAN.p + (size_t)p0[us] * W + (size_t)i * baseCols;
+                    for (int b = 0; b < MSS_BANDS; ++b) dBands[(size_t)j * MSS_BANDS + b] = mPlanes.p + (size_t)b * mPlaneStride + (size_t)m0[us] * Wb + (size_t)i * bandCols;
+                }
+                std::vector<double> r((size_t)12 * cnt);
+                ck(oip_interband_correlate_units(ctx, dPan.data(), panPitch.data(), dBands.data(), bandPitch.data(), cnt, baseRows, baseCols, r.data()));
+                for (int j = 0; j < cnt; ++j)
+                    for (int b = 0; b < MSS_BANDS; ++b)
+                        for (int k = 0; k < 3; ++k) table[((size_t)b * n + unitsDone + j) * 4 + k] = r[(size_t)12 * j + 3 * b + k];
+                unitsDone = hi;
+                if (sec == o.sections - 1) tCorrDone = seconds_since(t0);
+            } else {
+                // every section and every MSS line is in: filter, fit, align, product
+                OLOG("Inter-band correlation finished in %.3f seconds, result:", tCorrDone);
+                for (int b = 0; b < MSS_BANDS; ++b) {
+                    mBandShift[b].resize(n);
+                    for (int i = 0; i < n; ++i) {
+                        const double *sv = &table[((size_t)b * n + i) * 4];
+                        mBandShift[b][i] = InterBandShift{sv[0], sv[1], sv[2], (int)sv[3]};
+                    }
+                }
+                DumpInterBandShiftValues(o.slices, o.sections);
+                OLOG("Filter invalid correlation values & try polynomial fitting ...");
+                char err[512];
+                const int rc = oip_filter_and_fit_mode(table.data(), n, o.threshold, OIP_IBCV_MIN_COUNT, mFitMode, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0], err, sizeof err);
+                if (rc != OIP_OK) { OLOG("%s.", err); throw std::runtime_error(err); }
+                for (int b = 0; b < MSS_BANDS; ++b) {
+                    OLOG("BAND %d\tdeltaX coeff: [1] %.15f, [0] %.9f", b, mDeltaXcoeffs[b][1], mDeltaXcoeffs[b][0]);
+                    OLOG("\tdeltaY coeff: [2] %.15f, [1] %.15f, [0] %.9f", mDeltaYcoeffs[b][2], mDeltaYcoeffs[b][1], mDeltaYcoeffs[b][0]);
+                }
+                OLOG("CalcInterBandCorrelation(): done.");
+                OLOG("Doing inter-band alignment ...");
+                long processed = 0;
+                ck(oip_align_mss_bicubic_u16x4(ctx, mPlanes.p, mPlaneStride, 0, Lm, out.p, 0, outRows, Wb, Lm, &mDeltaXcoeffs[0][0], &mDeltaYcoeffs[0][0],
+                                               o.linesSection, o.lineOffset, o.overlapLines, o.keepLeading ? 1 : 0, OIP_IBPA_MIN_PROCESSLINES, &processed));
+                // preproc.h:167-185 WriteAlignedMSS_TIFF: cv::imwrite stores the Mat's channels (c0,c1,c2,c3) as samples (c2,c1,c0,c3);
+                // the image takes that order on the device, so its lines go from HBM into the file as they are
+                const int fileOrder[4] = {2, 1, 0, 3};
+                ck(oip_permute_u16x4(ctx, out.p, (size_t)outRows * Wb, fileOrder));
+                long mark = 0;
+                ck(oip_compute_mark(ctx, &mark));
+                alignedPath = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
+                const int comp = tiff_compression(TIFF_LZW);
+                tiff.reset(new TiffWriterU16(alignedPath, Wb, outRows, MSS_BANDS, false, comp));
+                TiffWriterU16 *tw = tiff.get();
+                const uint16_t *img = out.p;
+                const size_t rowSamples = (size_t)Wb * MSS_BANDS;
+                const long rows = outRows;
+                productWriter.post([=, &tAlignDone] {
+                    Device::get().check(oip_compute_mark_sync(ctx, mark));
+                    tAlignDone = seconds_since(t0);
+                    OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", tAlignDone, processed, rows);
+                    OLOG("Outputing aligned TIFF image (%d x %ld x 4) to [%s] ...", Wb, rows, alignedPath.c_str());
+                    if (comp == TIFF_NONE) {
+                        const uint64_t at = tw->begin_external_payload();
+                        Device::get().check(oip_write_device_to_file_at(ctx, img, (size_t)rows * rowSamples * 2, alignedPath.c_str(), (size_t)at, mark));
+                        tw->end_external_payload();
+                    } else {
+                        // strips are encoded as their lines come down: 256 MiB of lines per round
+                        const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
+                        std::vector<uint16_t> host((size_t)std::min(chunk, rows) * rowSamples);
+                        for (long r0 = 0; r0 < rows; r0 += chunk) {
+                            const long nr = std::min(chunk, rows - r0);
+                            Device::get().check(oip_download_staged_after(ctx, host.data(), img + (size_t)r0 * rowSamples, (size_t)nr * rowSamples * 2, mark));
+                            tw->write_rows(host.data(), nr);
+                        }
+                    }
+                    tw->close();
+                    OLOG("Output done.");
+                });
+            }
+        }
+        reader.join();
+        if (readerError) std::rethrow_exception(readerError);
+        ck(oip_sync(ctx));
+        const double tComputeDone = seconds_since(t0);
+        OLOG("%zu bytes read in %.3f seconds (%.1f MBps).", mSizePAN + mSizeMSS, tReadDone, (mSizePAN + mSizeMSS) / tReadDone / 1024.0 / 1024.0);
+        if (o.doRRC4PAN) OLOG("RRC for PAN done in %.4f seconds (%.1f MBps).", tComputeDone, mSizePAN / tComputeDone / 1024.0 / 1024.0);
+        OLOG("RRC done for MSS bands in %.4f seconds (%.1f MBps).", tComputeDone, mSizeMSS / tComputeDone / 1024.0 / 1024.0);
+        panWriter.finish();
+        if (o.writeRrcPan) OLOG("Written to file [%s].", rrcPanPath.c_str());
+        productWriter.finish();
+        const double tAll = seconds_since(t0);
+        mMssBil.release();
+        mPlanes.release();
+        mPAN.release();
+        OLOG("DoInterBandAlignment(): done.");
+        // one line for harnesses (bench.py's `cli` object): seconds since the action started
+        RLOG("TIMING default_action pipelined=1 setup=%.4f read_done=%.4f correlation_done=%.4f aligned=%.4f compute_done=%.4f products_written=%.4f "
+             "device_create=%.4f bytes_read=%zu bytes_written=%zu",
+             tSetup, tReadDone, tCorrDone, tAlignDone, tComputeDone, tAll, Device::get().create_seconds(), mSizePAN + mSizeMSS,
+             (size_t)outRows * Wb * MSS_BANDS * 2 + (o.writeRrcPan ? mSizePAN : 0));
     }
 
     const double *deltaXcoeffs() const { return &mDeltaXcoeffs[0][0]; }

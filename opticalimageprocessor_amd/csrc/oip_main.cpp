@@ -235,6 +235,19 @@ int run_default(const std::vector<std::string> &args, int width)
     // main.cpp:301-316
     PreProcessor pp(p.str("--pan"), p.str("--mss"), p.str("--rrc-pan"), msb, width);
     pp.SetFitMode(fit_mode(p));
+    const char *pl = getenv("OIP_PIPELINE");
+    if (!(pl && atoi(pl) == 0)) {
+        // the same steps as one pipeline: read || RRC || correlation || product writes (PreProcessor::RunPipelined);
+        // OIP_PIPELINE=0 runs them one after the other as the reference does -- the products are the same bytes
+        PreProcessor::DefaultActionOptions o;
+        o.doRRC4PAN = doRRC4PAN; o.writeRrcPan = doRRC4PAN && p.flag.count("--write-rrcpan") != 0; o.doRRC4MSS = doRRC4MSS;
+        o.keepLeading = p.flag.count("--keep-leading") != 0;
+        o.slices = p.integer("--slices", OIP_IBCV_DEF_SLICES); o.sections = p.integer("--ibc-sections", OIP_IBCV_DEF_SECTIONS); o.threshold = thr;
+        o.linesSection = p.integer("--lines-section", OIP_IBPA_DEFAULT_BATCHLINES); o.lineOffset = p.integer("--line-offset", 0);
+        o.overlapLines = p.integer("--overlap-lines", OIP_IBPA_DEFAULT_LINEOVERLAP);
+        pp.RunPipelined(o);
+        return 0;
+    }
     pp.LoadPAN();
     pp.LoadMSS();
     if (doRRC4PAN) {

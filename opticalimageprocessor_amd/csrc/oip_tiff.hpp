@@ -203,7 +203,7 @@ public:
         // classic TIFF offsets are 32 bit.  LZW can also GROW a strip: at worst one 12-bit code per byte (x1.5), so the
         // choice is made on the worst case and a classic file can never overflow half-way (BigTIFF is always valid).
         const size_t worst = compression == TIFF_LZW ? data + data / 2 : data;
-        mBig = worst + (size_t)height * 16 / 64 + 4096 > 0xFFFFF000ull;
+        mBig = worst + (size_t)height * 16 / 64 + 16384 > 0xFFFFF000ull;      // header, page-aligned payload, strip tables, directory
         mRowsPerStrip = (long)((8u << 20) / mRowBytes);
         if (mRowsPerStrip < 1) mRowsPerStrip = 1;
         if (mRowsPerStrip > height) mRowsPerStrip = height;
@@ -322,6 +322,29 @@ public:
 
     ~TiffWriterU16() { if (mF) fclose(mF); }
     bool bigtiff() const { return mBig; }
+
+    // Uncompressed files only: the whole pixel payload (height x width x spp samples, already in FILE sample order) is written
+    // by someone else at the returned byte offset -- the staging layer, straight from HBM (oip_write_device_to_file_at) --
+    // between begin_external_payload() and end_external_payload(); close() then appends the directory.
+    uint64_t begin_external_payload()
+    {
+        if (mComp != TIFF_NONE || mRowsDone != 0) throw std::logic_error("TiffWriterU16: external payload needs an empty uncompressed file");
+        if (mSwap) throw std::logic_error("TiffWriterU16: external payload is written in file sample order");
+        // right behind the header, where write_rows() would put it: the file is the same bytes either way
+        if (fflush(mF) != 0) throw std::runtime_error("TiffWriterU16: write failed");
+        return mPos;
+    }
+    void end_external_payload()
+    {
+        for (long r = 0; r < mH; r += mRowsPerStrip) {
+            const long n = std::min<long>(mRowsPerStrip, mH - r);
+            mStripOff.push_back(mPos);
+            mStripLen.push_back((uint64_t)n * mRowBytes);
+            mPos += (uint64_t)n * mRowBytes;
+        }
+        mRowsDone = mH;
+        if (fseeko(mF, (off_t)mPos, SEEK_SET) != 0) throw std::runtime_error("TiffWriterU16: seek failed");
+    }
 
 private:
     // encode `nrows` rows (whole strips, the last one possibly short) on a few threads and append them to the file

@@ -5,24 +5,36 @@
 // fseek/fread/fwrite of Stitcher::PreStitch (stitcher.h:103-120).  The reference moves every raster
 // through one pageable heap buffer, serially with the arithmetic; here a raster travels in blocks
 // through a ring of pinned buffers on a stream of its own:
-//     file --fread--> pinned slot --DMA--> HBM        (the next block is being read while this one flies)
-//     HBM --DMA--> pinned slot --fwrite--> file
+//     file --pread x T--> pinned slot --DMA--> HBM    (the next block is being read while this one flies; the slot is filled
+//                                                      by T pool threads, each with a pread of its own share)
+//     HBM --DMA--> pinned slot --pwrite--> file       (block k+1 comes down while block k is written; ONE writer per file:
+//                                                      buffered writes hold the inode lock and the faults of a shared mapping
+//                                                      contend -- measured, see write_device_to_file_at)
 //     pageable buffer --pool memcpy--> pinned slot --DMA--> HBM   (and back)
 // so disk, host copies, PCIe and the kernels of the context's compute stream overlap.  Staging calls
 // use only staging streams and pinned slots of their own and never change the context's compute stream or
 // profiler: they may run on other host threads while the first one drives kernels through the same
 // context.  Three lanes, each serialised by its own mutex (a second caller of the same lane waits):
-//   ring lane      oip_read_file_to_device, oip_write_device_to_file, oip_upload_staged, oip_rrc_u16_host
+//   ring lane      oip_read_file_to_device, oip_upload_staged, oip_rrc_u16_host
 //                  (four pinned slots; stream `stream`, oip_rrc_u16_host also `rrc_stream`)
-//   download lane  oip_download_staged (two pinned slots, stream `stream2`)
-// so an upload thread and a download thread run full duplex.  The state is created once under a lock.
+//   download lanes oip_download_staged[_after], oip_write_device_to_file[_at] (two lanes of two pinned slots and a stream each:
+//                  a call takes a free one, so two products can go out at the same time)
+// so a reader thread and a writer thread run full duplex beside the compute thread.  The state is created once under a lock.
 // A call returns a TICKET; oip_stage_wait(ctx, ticket) makes the compute stream wait -- on the device, not the
 // host -- for the transfers up to that ticket, and oip_stage_sync(ctx) blocks the host until they are done.
 // Ordering against the compute stream: downloads and file writes start after the compute-stream work
-// enqueued before the call.  UPLOADS DO NOT WAIT for the compute stream (an uploader thread must keep the
+// enqueued before the call -- or, given a MARK (oip_compute_mark, taken by the compute thread right after the
+// kernel that produced the data), after that mark only: a writer thread then does not queue behind a
+// correlation batch that was enqueued later.  UPLOADS DO NOT WAIT for the compute stream (an uploader thread must keep the
 // link busy while a 60-ms correlation is queued): re-uploading into a buffer that queued kernels still read
 // is the caller's hazard -- call oip_stage_order_after_compute(ctx) first, or upload into another buffer.
 #include "oip_internal.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/statvfs.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -33,8 +45,8 @@
 
 namespace {
 
-// ---- a small persistent pool for the pageable <-> pinned copies ---------------------------------
-// (one thread moves ~10 GB/s, the link ~55: the copies, not the link, bound a pageable host buffer)
+// ---- a small persistent pool for the host side of the ring: pageable <-> pinned copies, pread into a slot, copies into a
+// file mapping (one thread moves ~10 GB/s, the link ~55: the host side, not the link, bounds a staged raster)
 class CopyPool {
 public:
     static CopyPool &get()
@@ -43,43 +55,68 @@ public:
         return p;
     }
     int threads() const { return (int)mWorkers.size() + 1; }
-    void copy(void *dst, const void *src, size_t bytes)
+    // fn(part, nparts) on every thread of the pool (part 0 on the caller); returns when all are done
+    void run(const std::function<void(int, int)> &fn)
     {
         const int n = threads();
-        if (n == 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
-        std::lock_guard<std::mutex> one_at_a_time(mCall);          // an upload and a download thread may both be here
-        const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+        if (n == 1) { fn(0, 1); return; }
+        std::lock_guard<std::mutex> one_at_a_time(mCall);          // a reader and a writer thread may both be here
         {
             std::unique_lock<std::mutex> lk(mMu);
-            mDst = (char *)dst; mSrc = (const char *)src; mBytes = bytes; mPart = part; mWidth = 0;
+            mFn = &fn;
             mPending = (int)mWorkers.size();
             ++mGen;
         }
         mCv.notify_all();
-        memcpy(dst, src, part < bytes ? part : bytes);                 // the caller takes piece 0
+        fn(0, n);
         std::unique_lock<std::mutex> lk(mMu);
         mDone.wait(lk, [&] { return mPending == 0; });
+        mFn = nullptr;
+    }
+    void copy(void *dst, const void *src, size_t bytes)
+    {
+        if (threads() == 1 || bytes < ((size_t)4 << 20)) { memcpy(dst, src, bytes); return; }
+        run([&](int i, int n) {
+            const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095, off = (size_t)i * part;
+            if (off < bytes) memcpy((char *)dst + off, (const char *)src + off, bytes - off < part ? bytes - off : part);
+        });
     }
     // rows of `width` bytes, the pitches in bytes: the rows are dealt over the threads in contiguous runs
     void copy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows)
     {
-        const int n = threads();
-        auto run = [&](size_t r0, size_t r1) {
+        auto rows_of = [&](size_t r0, size_t r1) {
             for (size_t r = r0; r < r1; ++r) memcpy((char *)dst + r * dpitch, (const char *)src + r * spitch, width);
         };
-        if (n == 1 || width * rows < ((size_t)4 << 20)) { run(0, rows); return; }
-        std::lock_guard<std::mutex> one_at_a_time(mCall);
-        const size_t part = (rows + n - 1) / n;
-        {
-            std::unique_lock<std::mutex> lk(mMu);
-            mDst = (char *)dst; mSrc = (const char *)src; mBytes = rows; mPart = part; mWidth = width; mDPitch = dpitch; mSPitch = spitch;
-            mPending = (int)mWorkers.size();
-            ++mGen;
-        }
-        mCv.notify_all();
-        run(0, part < rows ? part : rows);
-        std::unique_lock<std::mutex> lk(mMu);
-        mDone.wait(lk, [&] { return mPending == 0; });
+        if (threads() == 1 || width * rows < ((size_t)4 << 20)) { rows_of(0, rows); return; }
+        run([&](int i, int n) {
+            const size_t part = (rows + n - 1) / n, r0 = (size_t)i * part;
+            if (r0 < rows) rows_of(r0, r0 + part < rows ? r0 + part : rows);
+        });
+    }
+    // pread of [off, off + bytes) of fd into dst, every thread its own share; returns the bytes read when the file covered
+    // the range, less when it ended early (the contiguous prefix), (size_t)-1 on a read error (errno kept in *err)
+    size_t pread_all(int fd, void *dst, size_t bytes, size_t off, int *err)
+    {
+        std::atomic<size_t> short_at{bytes};
+        std::atomic<int> failed{0};
+        auto share = [&](int i, int n) {
+            const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095;
+            size_t o = (size_t)i * part;
+            const size_t end = o + part < bytes ? o + part : bytes;
+            while (o < end) {
+                const ssize_t r = pread(fd, (char *)dst + o, end - o, (off_t)(off + o));
+                if (r < 0) { if (errno == EINTR) continue; failed = errno ? errno : EIO; return; }
+                if (r == 0) {                                          // end of file inside this share
+                    size_t cur = short_at.load();
+                    while (o < cur && !short_at.compare_exchange_weak(cur, o)) {}
+                    return;
+                }
+                o += (size_t)r;
+            }
+        };
+        if (bytes < ((size_t)1 << 20)) share(0, 1); else run(share);
+        if (failed.load()) { *err = failed.load(); return (size_t)-1; }
+        return short_at.load();
     }
 
 private:
@@ -87,7 +124,7 @@ private:
     {
         const char *e = getenv("OIP_HOST_COPY_THREADS");
         int n = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        n = n < 1 ? 1 : (n > 16 ? 16 : n);
+        n = n < 1 ? 1 : (n > 64 ? 64 : (!e && n > 16 ? 16 : n));
         for (int i = 1; i < n; ++i) mWorkers.emplace_back([this, i] { work(i); });
     }
     ~CopyPool()
@@ -108,15 +145,10 @@ private:
             mCv.wait(lk, [&] { return mGen != seen; });
             seen = mGen;
             if (mStop) return;
-            char *d = mDst; const char *s = mSrc; const size_t bytes = mBytes, part = mPart, width = mWidth, dp = mDPitch, sp = mSPitch;
+            const std::function<void(int, int)> *fn = mFn;
+            const int n = threads();
             lk.unlock();
-            const size_t off = (size_t)idx * part;
-            if (width == 0) {
-                if (off < bytes) memcpy(d + off, s + off, bytes - off < part ? bytes - off : part);
-            } else {                                                    // 2-D: bytes = rows, part = rows per thread
-                const size_t r1 = off + part < bytes ? off + part : bytes;
-                for (size_t r = off; r < r1; ++r) memcpy(d + r * dp, s + r * sp, width);
-            }
+            (*fn)(idx, n);
             lk.lock();
             if (--mPending == 0) mDone.notify_one();
         }
@@ -127,9 +159,7 @@ private:
     unsigned long mGen = 0;
     int mPending = 0;
     bool mStop = false;
-    char *mDst = nullptr;
-    const char *mSrc = nullptr;
-    size_t mBytes = 0, mPart = 0, mWidth = 0, mDPitch = 0, mSPitch = 0;
+    const std::function<void(int, int)> *mFn = nullptr;
 };
 
 constexpr int kSlots = 4;
@@ -141,22 +171,29 @@ constexpr int kTicketRing = 64;
 // the staging state lives behind the context (opaque to the other translation units)
 struct oip_stage_state {
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // the download lane's stream
     hipStream_t rrc_stream = nullptr;       // second stream of oip_rrc_u16_host (up and down transfers of neighbouring blocks overlap)
-    std::mutex ring_mu, down_mu;            // one caller per lane at a time
+    std::mutex ring_mu;                     // one caller per lane at a time
     void *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t slot_free[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // recorded after the DMA that last used the slot
     bool slot_used[kSlots] = {false, false, false, false};
     int next = 0;
     hipEvent_t ticket_ev[kTicketRing];
     hipEvent_t compute_ev = nullptr;        // marks the compute stream's position for uploads
-    // the download lane: its own two slots, stream2 and event, so that oip_download_staged on one host thread and an
-    // upload on another never touch the same state (full duplex over the link)
-    void *dslot[2] = {nullptr, nullptr};
-    hipEvent_t dslot_free[2] = {nullptr, nullptr};
-    bool dslot_used[2] = {false, false};
-    int dnext = 0;
-    hipEvent_t down_compute_ev = nullptr;
+    // the download lanes: each its own two slots, stream and event, so that a download or a file write on one host thread
+    // and an upload on another never touch the same state (full duplex over the link); two of them, so that two products
+    // (different files: writers of ONE file serialise in the kernel anyway) can be written at the same time
+    struct DownLane {
+        std::mutex mu;
+        hipStream_t stream = nullptr;
+        void *slot[2] = {nullptr, nullptr};
+        hipEvent_t slot_free[2] = {nullptr, nullptr};
+        bool slot_used[2] = {false, false};
+        int next = 0;
+        hipEvent_t compute_ev = nullptr;
+    } down[2];
+    // marks of the compute stream (oip_compute_mark): taken by the compute thread, waited for by the download lane
+    hipEvent_t mark_ev[kTicketRing];
+    std::atomic<long> mark{0};
     std::atomic<long> ticket{0};
     // where the host side of the ring lane spends its time (oip_stage_stats): pageable <-> pinned copies on the pool, and
     // waiting for a slot whose DMA has not finished (the link is the limit then)
@@ -170,12 +207,15 @@ static std::mutex g_stage_init_mu;
 static int stage_init(oip_ctx *ctx)
 {
     // first staging calls may come from two threads at once: the state is created exactly once
+    // every staging entry point comes through here first: the calling thread -- possibly a fresh reader or writer thread --
+    // gets the context's device before it touches a stream or an event
+    OIP_HIP(ctx, hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> once(g_stage_init_mu);
     if (ctx->stage) return OIP_OK;
-    OIP_HIP(ctx, hipSetDevice(ctx->device));
     oip_stage_state *s = new oip_stage_state();
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->down[0].stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->down[1].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->rrc_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
     for (int i = 0; i < kSlots; ++i) {
         if (hipHostMalloc(&s->slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
@@ -185,15 +225,18 @@ static int stage_init(oip_ctx *ctx)
         }
     }
     for (int i = 0; i < kTicketRing; ++i)
-        if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+        if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->mark_ev[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
     if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->down_compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
-    for (int i = 0; i < 2; ++i)
-        if (hipHostMalloc(&s->dslot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&s->dslot_free[i], hipEventDisableTiming) != hipSuccess) {
-            delete s;
-            return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
-        }
+        hipEventCreateWithFlags(&s->down[0].compute_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->down[1].compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    for (auto &d : s->down)
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&d.slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&d.slot_free[i], hipEventDisableTiming) != hipSuccess) {
+                delete s;
+                return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
+            }
     ctx->stage = s;
     return OIP_OK;
 }
@@ -203,13 +246,15 @@ void oip_stage_destroy(oip_ctx *ctx)
     oip_stage_state *s = ctx->stage;
     if (!s) return;
     if (s->stream) hipStreamSynchronize(s->stream);
-    if (s->stream2) { hipStreamSynchronize(s->stream2); hipStreamDestroy(s->stream2); }
+    for (auto &d : s->down) if (d.stream) { hipStreamSynchronize(d.stream); hipStreamDestroy(d.stream); }
     if (s->rrc_stream) { hipStreamSynchronize(s->rrc_stream); hipStreamDestroy(s->rrc_stream); }
     for (int i = 0; i < kSlots; ++i) { if (s->slot[i]) hipHostFree(s->slot[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
-    for (int i = 0; i < kTicketRing; ++i) hipEventDestroy(s->ticket_ev[i]);
+    for (int i = 0; i < kTicketRing; ++i) { hipEventDestroy(s->ticket_ev[i]); hipEventDestroy(s->mark_ev[i]); }
     if (s->compute_ev) hipEventDestroy(s->compute_ev);
-    if (s->down_compute_ev) hipEventDestroy(s->down_compute_ev);
-    for (int i = 0; i < 2; ++i) { if (s->dslot[i]) hipHostFree(s->dslot[i]); if (s->dslot_free[i]) hipEventDestroy(s->dslot_free[i]); }
+    for (auto &d : s->down) {
+        if (d.compute_ev) hipEventDestroy(d.compute_ev);
+        for (int i = 0; i < 2; ++i) { if (d.slot[i]) hipHostFree(d.slot[i]); if (d.slot_free[i]) hipEventDestroy(d.slot_free[i]); }
+    }
     if (s->d_kb) hipFree(s->d_kb);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
@@ -310,38 +355,37 @@ extern "C" int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t of
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
     std::lock_guard<std::mutex> lane(s->ring_mu);
-    FILE *f = fopen(path, "rb");
-    if (!f) return oip_fail(ctx, OIP_E_INVALID, "cannot open file [%s]: %d", path, errno);      // imageop.h:55-57
-    if (bytes == 0) {                                                                            // all available (imageop.h:59-63)
-        if (fseeko(f, 0, SEEK_END)) { fclose(f); return oip_fail(ctx, OIP_E_INVALID, "ReadFileContent(): seek2end failed"); }
-        const off_t end = ftello(f);
-        bytes = (size_t)end > offset ? (size_t)end - offset : 0;
-    }
-    if (fseeko(f, (off_t)offset, SEEK_SET)) { fclose(f); return oip_fail(ctx, OIP_E_INVALID, "ReadFileContent(): rewind failed"); }
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return oip_fail(ctx, OIP_E_INVALID, "cannot open file [%s]: %d", path, errno);  // imageop.h:55-57
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return oip_fail(ctx, OIP_E_INVALID, "ReadFileContent(): seek2end failed"); }
+    const size_t avail = (size_t)st.st_size > offset ? (size_t)st.st_size - offset : 0;
+    if (bytes == 0 || bytes > avail) bytes = avail;                                              // all available (imageop.h:59-63); a short file reads short
     size_t done = 0;
     while (done < bytes) {
         int i;
-        if ((rc = slot_acquire(ctx, s, &i))) { fclose(f); return rc; }
+        if ((rc = slot_acquire(ctx, s, &i))) { close(fd); return rc; }
         const size_t want = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
-        size_t got = 0;
-        while (got < want) {                                                                     // imageop.h:69-79, 8 MiB units
-            const size_t unit = want - got < ((size_t)8 << 20) ? want - got : ((size_t)8 << 20);
-            const size_t rn = fread((char *)s->slot[i] + got, 1, unit, f);
-            got += rn;
-            if (rn == 0) break;
-        }
+        // the slot is filled by the pool: every thread preads its own share (imageop.h:69-79 reads 8 MiB units on one thread)
+        int err = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t got = CopyPool::get().pread_all(fd, s->slot[i], want, offset + done, &err);
+        s->copy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (got == (size_t)-1) { close(fd); return oip_fail(ctx, OIP_E_RUNTIME, "read of file [%s] failed: %d", path, err); }
+        s->ring_bytes += (long)got;
         if (got) {
             if (hipMemcpyAsync((char *)d_dst + done, s->slot[i], got, hipMemcpyHostToDevice, s->stream) != hipSuccess) {
-                fclose(f);
+                close(fd);
                 return oip_fail(ctx, OIP_E_DEVICE, "H2D of a staged block failed");
             }
             hipEventRecord(s->slot_free[i], s->stream);
             s->slot_used[i] = true;
         }
         done += got;
-        if (got < want) break;                                                                   // short file
+        if (got < want) break;                                                                   // the file shrank under us
     }
-    fclose(f);
+    close(fd);
+    ++s->ring_calls;
     if (bytes_read) *bytes_read = done;
     const long t = ticket_issue(ctx, s);
     if (ticket) *ticket = t;
@@ -349,48 +393,139 @@ extern "C" int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t of
     return OIP_OK;
 }
 
-extern "C" int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append)
+// the download lane's stream waits for the compute stream: for `mark` when one is given (and still in the ring), else for
+// everything enqueued so far
+static int down_order(oip_ctx *ctx, oip_stage_state *s, oip_stage_state::DownLane &d, long mark)
 {
-    if (!ctx) return OIP_E_INVALID;
-    if (!path || (!d_src && bytes)) return oip_fail(ctx, OIP_E_INVALID, "oip_write_device_to_file: bad argument");
+    if (mark > 0 && mark <= s->mark.load() && s->mark.load() - mark < kTicketRing - 2) {
+        OIP_HIP(ctx, hipStreamWaitEvent(d.stream, s->mark_ev[mark % kTicketRing], 0));
+        return OIP_OK;
+    }
+    OIP_HIP(ctx, hipEventRecord(d.compute_ev, ctx->stream));
+    OIP_HIP(ctx, hipStreamWaitEvent(d.stream, d.compute_ev, 0));
+    return OIP_OK;
+}
+
+// a free download lane (the first one when both are busy: the caller waits there)
+struct DownLaneLock {
+    oip_stage_state::DownLane *d;
+    explicit DownLaneLock(oip_stage_state *s)
+    {
+        if (s->down[0].mu.try_lock()) d = &s->down[0];
+        else if (s->down[1].mu.try_lock()) d = &s->down[1];
+        else { s->down[0].mu.lock(); d = &s->down[0]; }
+    }
+    ~DownLaneLock() { d->mu.unlock(); }
+};
+
+extern "C" int oip_compute_mark(oip_ctx *ctx, long *mark)
+{
+    if (!ctx || !mark) return OIP_E_INVALID;
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
-    std::lock_guard<std::mutex> lane(s->ring_mu);
-    FILE *f = fopen(path, append ? "ab" : "wb");
-    if (!f) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);      // imageop.h:86-88
-    if ((rc = order_after_compute(ctx, s))) { fclose(f); return rc; }
-    // block k's DMA is in flight while block k-1 is written
+    const long m = s->mark.load() + 1;
+    OIP_HIP(ctx, hipEventRecord(s->mark_ev[m % kTicketRing], ctx->stream));
+    s->mark.store(m);
+    *mark = m;
+    return OIP_OK;
+}
+
+extern "C" int oip_compute_mark_sync(oip_ctx *ctx, long mark)
+{
+    if (!ctx) return OIP_E_INVALID;
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    if (mark > 0 && mark <= s->mark.load() && s->mark.load() - mark < kTicketRing - 2) {
+        OIP_HIP(ctx, hipEventSynchronize(s->mark_ev[mark % kTicketRing]));
+        return OIP_OK;
+    }
+    OIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OIP_OK;
+}
+
+// HBM -> pinned slot -> file at `file_offset` (SIZE_MAX: at the end).  Block k+1 comes down while block k is written.
+// Measured on the GPU box (profiles/r04_io_probe.txt): a NEW tmpfs file takes 5.3-6.7 GB/s from one writing thread (page
+// allocation under the inode lock); 8-32 threads of pwrite on the one inode stay at 3.5-5.6 GB/s, a MAP_SHARED mapping
+// filled by 1-64 threads at 3.4 -> 1.3 GB/s (the faults contend).  So: one writer, plain pwrite of whole slots
+// (OIP_FILE_WRITE=mmap keeps the mapping route for file systems where it pays).
+static int write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, size_t file_offset, bool truncate, long mark)
+{
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    DownLaneLock lane(s);
+    oip_stage_state::DownLane &d = *lane.d;
+    const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC | (truncate ? O_TRUNC : 0), 0644);
+    if (fd < 0) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);  // imageop.h:86-88
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno); }
+    if (file_offset == (size_t)-1) file_offset = (size_t)st.st_size;
+    char *map = nullptr;
+    size_t map_len = 0, map_skew = 0;
+    const char *mode = getenv("OIP_FILE_WRITE");
+    if (mode && !strcmp(mode, "mmap") && bytes) {
+        // a mapping reports a full file system as SIGBUS, not as an error: only with room to spare
+        struct statvfs vfs;
+        const bool room = fstatvfs(fd, &vfs) == 0 && (double)vfs.f_bavail * (double)vfs.f_frsize > (double)bytes + 256e6;
+        if (room && ((size_t)st.st_size >= file_offset + bytes || ftruncate(fd, (off_t)(file_offset + bytes)) == 0)) {
+            const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+            map_skew = file_offset % page;
+            map_len = bytes + map_skew;
+            void *m = mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)(file_offset - map_skew));
+            if (m != MAP_FAILED) { map = (char *)m; madvise(m, map_len, MADV_HUGEPAGE); }
+        }
+    }
+    if ((rc = down_order(ctx, s, d, mark))) { if (map) munmap(map, map_len); close(fd); return rc; }
     int prev = -1;
-    size_t prev_bytes = 0, done = 0;
-    auto flush = [&](int i, size_t n) -> int {
-        if (hipEventSynchronize(s->slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+    size_t prev_bytes = 0, prev_off = 0, done = 0;
+    auto flush = [&](int i, size_t off, size_t n) -> int {
+        if (hipEventSynchronize(d.slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        if (map) { CopyPool::get().copy(map + map_skew + off, d.slot[i], n); return OIP_OK; }
         size_t w = 0;
-        while (w < n) {                                                                          // imageop.h:88-95, 8 MiB units
-            const size_t unit = n - w < ((size_t)8 << 20) ? n - w : ((size_t)8 << 20);
-            const size_t wb = fwrite((const char *)s->slot[i] + w, 1, unit, f);
-            if (wb == 0) return oip_fail(ctx, OIP_E_RUNTIME, "write file failed: %d", errno);
-            w += wb;
+        while (w < n) {                                                                          // imageop.h:88-95
+            const ssize_t wb = pwrite(fd, (const char *)d.slot[i] + w, n - w, (off_t)(file_offset + off + w));
+            if (wb < 0 && errno == EINTR) continue;
+            if (wb <= 0) return oip_fail(ctx, OIP_E_RUNTIME, "write file failed: %d", errno);
+            w += (size_t)wb;
         }
         return OIP_OK;
     };
     while (done < bytes) {
-        int i;
-        if ((rc = slot_acquire(ctx, s, &i))) break;
+        const int i = d.next;
+        d.next ^= 1;
+        if (d.slot_used[i] && hipEventSynchronize(d.slot_free[i]) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed"); break; }
         const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
-        if (hipMemcpyAsync(s->slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream) != hipSuccess) {
+        if (hipMemcpyAsync(d.slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, d.stream) != hipSuccess) {
             rc = oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
             break;
         }
-        hipEventRecord(s->slot_free[i], s->stream);
-        s->slot_used[i] = true;
-        if (prev >= 0 && (rc = flush(prev, prev_bytes))) break;
-        prev = i; prev_bytes = n;
+        hipEventRecord(d.slot_free[i], d.stream);
+        d.slot_used[i] = true;
+        if (prev >= 0 && (rc = flush(prev, prev_off, prev_bytes))) break;
+        prev = i; prev_off = done; prev_bytes = n;
         done += n;
     }
-    if (rc == OIP_OK && prev >= 0) rc = flush(prev, prev_bytes);
-    if (fclose(f) != 0 && rc == OIP_OK) rc = oip_fail(ctx, OIP_E_RUNTIME, "close file [%s] failed: %d", path, errno);
+    if (rc == OIP_OK && prev >= 0) rc = flush(prev, prev_off, prev_bytes);
+    if (rc != OIP_OK) hipStreamSynchronize(d.stream);
+    if (map) munmap(map, map_len);
+    if (close(fd) != 0 && rc == OIP_OK) rc = oip_fail(ctx, OIP_E_RUNTIME, "close file [%s] failed: %d", path, errno);
     return rc;
+}
+
+extern "C" int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!path || (!d_src && bytes)) return oip_fail(ctx, OIP_E_INVALID, "oip_write_device_to_file: bad argument");
+    return write_device_to_file_at(ctx, d_src, bytes, path, append ? (size_t)-1 : 0, !append, 0);
+}
+
+extern "C" int oip_write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, size_t file_offset, long mark)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!path || (!d_src && bytes)) return oip_fail(ctx, OIP_E_INVALID, "oip_write_device_to_file_at: bad argument");
+    return write_device_to_file_at(ctx, d_src, bytes, path, file_offset, false, mark);
 }
 
 // ---- pageable host buffer <-> device ---------------------------------------------------------------
@@ -457,38 +592,43 @@ extern "C" int oip_upload_staged_2d(oip_ctx *ctx, void *d_dst, size_t dst_pitch,
     return OIP_OK;
 }
 
-extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes)
+extern "C" int oip_download_staged_after(oip_ctx *ctx, void *host, const void *d_src, size_t bytes, long mark)
 {
     if (!ctx) return OIP_E_INVALID;
     if ((!d_src || !host) && bytes) return oip_fail(ctx, OIP_E_INVALID, "oip_download_staged: bad argument");
     int rc = stage_init(ctx);
     if (rc) return rc;
     oip_stage_state *s = ctx->stage;
-    std::lock_guard<std::mutex> lane(s->down_mu);
-    // the download lane (see oip_stage_state): ordered after what the compute stream has enqueued so far
-    OIP_HIP(ctx, hipEventRecord(s->down_compute_ev, ctx->stream));
-    OIP_HIP(ctx, hipStreamWaitEvent(s->stream2, s->down_compute_ev, 0));
+    DownLaneLock lane(s);
+    oip_stage_state::DownLane &d = *lane.d;
+    // a download lane (see oip_stage_state): ordered after the mark, or after what the compute stream has enqueued so far
+    if ((rc = down_order(ctx, s, d, mark))) return rc;
     int prev = -1;
     size_t prev_bytes = 0, prev_off = 0, done = 0;
     auto drain = [&](int i, size_t off, size_t n) -> int {
-        if (hipEventSynchronize(s->dslot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
-        CopyPool::get().copy((char *)host + off, s->dslot[i], n);
+        if (hipEventSynchronize(d.slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        CopyPool::get().copy((char *)host + off, d.slot[i], n);
         return OIP_OK;
     };
     while (done < bytes) {
-        const int i = s->dnext;
-        s->dnext ^= 1;
-        if (s->dslot_used[i]) OIP_HIP(ctx, hipEventSynchronize(s->dslot_free[i]));
+        const int i = d.next;
+        d.next ^= 1;
+        if (d.slot_used[i]) OIP_HIP(ctx, hipEventSynchronize(d.slot_free[i]));
         const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
-        OIP_HIP(ctx, hipMemcpyAsync(s->dslot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, s->stream2));
-        hipEventRecord(s->dslot_free[i], s->stream2);
-        s->dslot_used[i] = true;
+        OIP_HIP(ctx, hipMemcpyAsync(d.slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, d.stream));
+        hipEventRecord(d.slot_free[i], d.stream);
+        d.slot_used[i] = true;
         if (prev >= 0 && (rc = drain(prev, prev_off, prev_bytes))) return rc;
         prev = i; prev_off = done; prev_bytes = n;
         done += n;
     }
     if (prev >= 0) rc = drain(prev, prev_off, prev_bytes);
     return rc;
+}
+
+extern "C" int oip_download_staged(oip_ctx *ctx, void *host, const void *d_src, size_t bytes)
+{
+    return oip_download_staged_after(ctx, host, d_src, bytes, 0);
 }
 
 // ---- IMO::InplaceRRC on the reference's heap buffer (imageop.h:129-138 as DoRRC4RAW calls it, :194-228) -----------

@@ -102,7 +102,53 @@ __global__ __launch_bounds__(kBlock) void stitch_rows_scalar_kernel(const uint16
     }
 }
 
+// In-place sample permutation of an interleaved 4-channel image: sample i of every pixel becomes sample order[i].  A lane
+// owns two pixels (one 16-byte load and store of its own: in place is safe); `sel` holds the four selectors, 4 bits each.
+__global__ __launch_bounds__(kBlock) void permute_u16x4_kernel(uint16_t *__restrict__ img, long npairs, long npix, unsigned sel)
+{
+    const long stride = (long)gridDim.x * kBlock;
+    for (long f = (long)blockIdx.x * kBlock + threadIdx.x; f < npairs; f += stride) {
+        if (2 * f + 1 < npix) {
+            uint4 v = reinterpret_cast<uint4 *>(img)[f], o;
+            const unsigned a[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+            const unsigned b[4] = {v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
+            o.x = a[sel & 3] | (a[(sel >> 4) & 3] << 16);
+            o.y = a[(sel >> 8) & 3] | (a[(sel >> 12) & 3] << 16);
+            o.z = b[sel & 3] | (b[(sel >> 4) & 3] << 16);
+            o.w = b[(sel >> 8) & 3] | (b[(sel >> 12) & 3] << 16);
+            reinterpret_cast<uint4 *>(img)[f] = o;
+        } else {                                                        // the odd last pixel
+            uint2 v = reinterpret_cast<uint2 *>(img)[2 * f], o;
+            const unsigned a[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+            o.x = a[sel & 3] | (a[(sel >> 4) & 3] << 16);
+            o.y = a[(sel >> 8) & 3] | (a[(sel >> 12) & 3] << 16);
+            reinterpret_cast<uint2 *>(img)[2 * f] = o;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int oip_permute_u16x4(oip_ctx *ctx, uint16_t *d_img, size_t npixels, const int *order)
+{
+    OIP_CHECK_CTX(ctx);
+    if (!order || (!d_img && npixels)) return oip_fail(ctx, OIP_E_INVALID, "oip_permute_u16x4: bad argument");
+    unsigned sel = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (order[i] < 0 || order[i] > 3) return oip_fail(ctx, OIP_E_INVALID, "oip_permute_u16x4: sample index outside 0..3");
+        sel |= (unsigned)order[i] << (4 * i);
+    }
+    if (((uintptr_t)d_img & 15) != 0) return oip_fail(ctx, OIP_E_INVALID, "oip_permute_u16x4: image not 16-byte aligned");
+    if (npixels == 0 || sel == 0x3210u) return OIP_OK;
+    OipProfScope prof(ctx, "permute_u16x4_kernel");
+    const long npairs = (long)((npixels + 1) / 2);
+    long blocks = (npairs + kBlock - 1) / kBlock;
+    const long cap = (long)ctx->cu_count * 64;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(permute_u16x4_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, ctx->stream, d_img, npairs, (long)npixels, sel);
+    OIP_HIP(ctx, hipGetLastError());
+    return OIP_OK;
+}
 
 extern "C" int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_right, uint16_t *d_out,
                                    int W, long L, int fold)

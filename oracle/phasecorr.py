@@ -45,35 +45,38 @@ def _cross_power_ccs(F1: np.ndarray, F2: np.ndarray, M: int, N: int) -> np.ndarr
       * first/last column: double-precision formula
       * everything else: float formula with denom = mag*mag + eps in f32.
     """
-    F1 = F1.astype(np.complex64)
-    F2 = F2.astype(np.complex64)
-    ar, ai = F1.real, F1.imag
-    br, bi = F2.real, F2.imag
-    # mulSpectrums, conjB=true (f32 arithmetic)
-    pr = (ar * br + ai * bi).astype(np.float32)
-    pi = (ai * br - ar * bi).astype(np.float32)
-    mag = np.sqrt(pr.astype(np.float64) ** 2 + pi.astype(np.float64) ** 2).astype(np.float32)
-    eps = FLT_EPSILON
-    # generic bins: float formula (B = (mag, 0))
-    denom = (mag * mag + np.float32(0) + eps).astype(np.float32).astype(np.float64)
-    cr = ((pr * mag).astype(np.float32).astype(np.float64) / denom).astype(np.float32)
-    ci = ((pi * mag).astype(np.float32).astype(np.float64) / denom).astype(np.float32)
-    C = (cr + 1j * ci).astype(np.complex64)
-    # first (kx=0) and, for even N, last (kx=N/2) column: double formula
-    cols = [0] + ([N // 2] if N % 2 == 0 else [])
-    for kx in cols:
-        m = mag[:, kx].astype(np.float64)
-        d = m * m + float(eps)
-        C[:, kx] = ((pr[:, kx].astype(np.float64) * m / d).astype(np.float32)
-                    + 1j * (pi[:, kx].astype(np.float64) * m / d).astype(np.float32))
-        # real-only bins: product is a*b, "magnitude" is its square
-        rows = [0] + ([M // 2] if M % 2 == 0 else [])
-        for ky in rows:
-            a = np.float32(ar[ky, kx] * br[ky, kx])
-            C[ky, kx] = np.float32(a / np.float32(np.float32(a * a) + eps))
-        # the mirrored half of these columns is implied by Hermitian symmetry in CCS
-        for ky in range(M // 2 + 1, M):
-            C[ky, kx] = np.conj(C[M - ky, kx])
+    # |P|^2 overflows f32 for large windows (16000 x 3000: the DC column; a strong horizontal ramp: interior bins too) -- inf and
+    # inf/inf = NaN are the reference's own f32 arithmetic there (divSpectrums), not an accident of this restatement
+    with np.errstate(over="ignore", invalid="ignore"):
+        F1 = F1.astype(np.complex64)
+        F2 = F2.astype(np.complex64)
+        ar, ai = F1.real, F1.imag
+        br, bi = F2.real, F2.imag
+        # mulSpectrums, conjB=true (f32 arithmetic)
+        pr = (ar * br + ai * bi).astype(np.float32)
+        pi = (ai * br - ar * bi).astype(np.float32)
+        mag = np.sqrt(pr.astype(np.float64) ** 2 + pi.astype(np.float64) ** 2).astype(np.float32)
+        eps = FLT_EPSILON
+        # generic bins: float formula (B = (mag, 0))
+        denom = (mag * mag + np.float32(0) + eps).astype(np.float32).astype(np.float64)
+        cr = ((pr * mag).astype(np.float32).astype(np.float64) / denom).astype(np.float32)
+        ci = ((pi * mag).astype(np.float32).astype(np.float64) / denom).astype(np.float32)
+        C = (cr + 1j * ci).astype(np.complex64)
+        # first (kx=0) and, for even N, last (kx=N/2) column: double formula
+        cols = [0] + ([N // 2] if N % 2 == 0 else [])
+        for kx in cols:
+            m = mag[:, kx].astype(np.float64)
+            d = m * m + float(eps)
+            C[:, kx] = ((pr[:, kx].astype(np.float64) * m / d).astype(np.float32)
+                        + 1j * (pi[:, kx].astype(np.float64) * m / d).astype(np.float32))
+            # real-only bins: product is a*b, "magnitude" is its square
+            rows = [0] + ([M // 2] if M % 2 == 0 else [])
+            for ky in rows:
+                a = np.float32(ar[ky, kx] * br[ky, kx])
+                C[ky, kx] = np.float32(a / np.float32(np.float32(a * a) + eps))
+            # the mirrored half of these columns is implied by Hermitian symmetry in CCS
+            for ky in range(M // 2 + 1, M):
+                C[ky, kx] = np.conj(C[M - ky, kx])
     return C
 
 

@@ -137,6 +137,56 @@ def test_prestitch_stitch_and_default_action(ctx, oracle_mod, tmp_path):
     assert np.array_equal(twice, np.concatenate([out[:, :out.shape[1] - 1], out[:, 1:]], axis=1))
 
 
+def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
+    """`oip --pan --mss` runs the default action as a pipeline (reader thread || compute thread || product writers,
+    PreProcessor::RunPipelined); OIP_PIPELINE=0 runs the reference's steps one after the other (preproc.h:51-80, :188-222,
+    :224-347, :351-425).  Same product files, byte for byte -- with an ODD slice count over two sections, so that a pair of
+    correlation units spans the sections (the pipeline has to keep the one-call pairing), with --write-rrcpan (the corrected
+    PAN strip goes out block by block behind the RRC kernels) and in both TIFF encodings."""
+    W, L = 1024, 33024
+    base = str(tmp_path)
+    pan, bands = _synth.pan_mss(L, W, [(2, -1), (1, 1), (-1, -2), (-2, 1)], seed=21)
+    bil = np.concatenate(bands, axis=1)
+    runs = {}
+    for comp in ("lzw", "none"):
+        for name, pl in (("steps", "0"), ("pipe", "1")):
+            d = os.path.join(base, comp + "-" + name)
+            os.makedirs(d)
+            pan.tofile(os.path.join(d, "T_PAN.RAW")); bil.tofile(os.path.join(d, "T_MSS.RAW"))
+            _csv(os.path.join(d, "PAN.csv"), _synth.lut(W, 3))
+            for b in range(4):
+                _csv(os.path.join(d, "MSS.B%d.csv" % (b + 1)), _synth.lut(W // 4, 20 + b))
+            env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp)
+            args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv", "--write-rrcpan",
+                    "--slices", "9", "--ibc-sections", "2", "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
+            for b in range(4):
+                args += ["--rrc-msb%d" % (b + 1), "MSS.B%d.csv" % (b + 1)]
+            r = subprocess.run(args, cwd=d, env=env, capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert ("TIMING default_action pipelined=1" in r.stdout) == (pl == "1")
+            runs[(comp, name)] = (d, r.stdout)
+        for f in ("T_PAN.RRC.RAW", "T_MSS.ALIGNED.TIFF"):
+            a = open(os.path.join(runs[(comp, "steps")][0], f), "rb").read()
+            b = open(os.path.join(runs[(comp, "pipe")][0], f), "rb").read()
+            assert len(a) > 100000 and a == b, (comp, f)
+        # the same correlation table and polynomials in the two logs
+        pick = lambda out: [ln for ln in out.splitlines() if ln.startswith("|") or "coeff:" in ln]
+        ta, tb = pick(runs[(comp, "steps")][1]), pick(runs[(comp, "pipe")][1])
+        strip = lambda lines: [ln.split(" ", 2)[-1] if "coeff:" in ln else ln for ln in lines]
+        assert len(ta) > 20 and strip(ta) == strip(tb)
+    # errors keep their exit codes in the pipeline: a truncated MSS file (size check, preproc.h:552-572) and too many sections
+    d = runs[("none", "pipe")][0]
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"))
+    r = subprocess.run([OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--no-rrc4mss", "--ibc-sections", "3"], cwd=d, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "too many sections" in r.stdout
+    with open(os.path.join(d, "T_MSS.RAW"), "r+b") as f:
+        f.truncate(bil.nbytes - W * 2 * 4)
+    r = subprocess.run([OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--no-rrc4mss", "--ibc-sections", "1"], cwd=d, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "PAN file size does not match MSS file size" in r.stdout
+
+
 def test_default_action_at_the_30000_wide_geometry(ctx, oracle_mod, tmp_path):
     """The C++ host on a strip of the BASELINE width: 30000 columns, 10 slices of 3000 -- the geometry whose inter-band
     correlation runs on the band spectra -- one correlation section of 16000 lines.  The polynomials

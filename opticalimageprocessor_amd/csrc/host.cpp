@@ -187,20 +187,25 @@ extern "C" int oip_filter_and_fit_mode(const double *shifts, int n, double thres
     auto fit = fit_mode == OIP_FIT_LSTSQ ? oip_polyfit : oip_polyfit_reference;
     std::vector<double> cxv(n), xv(n), yv(n);
     for (int b = 0; b < OIP_MSS_BANDS; ++b) {
-        int vvi = 0;
+        // Two tests, as the reference has them: FilterInterBandShiftValues counts a unit unless `rs < threshold`
+        // (preproc.h:498-503) -- a NaN response, which the f32 cross-power spectrum produces when |P|^2 overflows, is
+        // not below the threshold and counts towards min_count -- while DoCorrelationPolynomialFitting takes a unit
+        // into the fit when `rs >= threshold` (preproc.h:527), which a NaN fails.
+        int vvi = 0, fc = 0;
         for (int i = 0; i < n; ++i) {
             const double *s = shifts + ((size_t)b * n + i) * 4;
-            if (s[2] >= threshold) {            // NaN responses (sections another rank owns) fail this test
+            if (!(s[2] < threshold)) ++fc;
+            if (s[2] >= threshold) {
                 cxv[vvi] = s[3];
                 xv[vvi] = s[0];
                 yv[vvi] = s[1];
                 ++vvi;
             }
         }
-        if (vvi < min_count) {
+        if (fc < min_count) {
             if (err && errlen > 0)
                 snprintf(err, errlen, "Not enough valid correlation values for band#%d: %d valid values found, %d expected at least",
-                         b + 1, vvi, min_count);
+                         b + 1, fc, min_count);
             return OIP_E_RUNTIME;
         }
         int rc = fit(cxv.data(), xv.data(), vvi, 1, cx_out + b * 2);

@@ -30,6 +30,7 @@
 #include <thread>
 
 #include "oip_host.hpp"
+#include "oip_rankguard.hpp"
 
 namespace OIPGPU {
 
@@ -373,37 +374,9 @@ inline void PrintCcdPlan(const CcdPlanC &p, double dy)
 }
 
 // ---- the node: one context, stream and communicator per GPU, one host thread per GPU -------------------------------
-struct HostBarrier {
-    std::mutex mu;
-    std::condition_variable cv;
-    int n, waiting = 0;
-    unsigned long gen = 0;
-    bool aborted = false;
-    explicit HostBarrier(int n_) : n(n_) {}
-    bool wait()                 // false: a rank has given up (abort()), nobody waits any longer
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        if (aborted) return false;
-        const unsigned long g = gen;
-        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g || aborted; });
-        return !aborted;
-    }
-    void abort()
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        aborted = true;
-        cv.notify_all();
-    }
-};
-
-struct PeerFailed : public std::runtime_error {
-    PeerFailed() : std::runtime_error("another GPU's step failed") {}
-};
-
 class Node {
 public:
-    explicit Node(int n) : N(n), bar(n), ctx(n, nullptr), comm(n, nullptr), err(n)
+    explicit Node(int n) : N(n), bar(n), ctx(n, nullptr), comms(n), err(n)
     {
         int have = 0;
         if (hipGetDeviceCount(&have) != hipSuccess || have < n)
@@ -413,7 +386,7 @@ public:
             devs[i] = i;
             if (oip_create(i, &ctx[i]) != OIP_OK) throw std::runtime_error("no usable MI355X (gfx950) device " + std::to_string(i));
         }
-        if (ncclCommInitAll(comm.data(), n, devs.data()) != ncclSuccess) throw std::runtime_error("ncclCommInitAll failed");
+        if (ncclCommInitAll(comms.comm.data(), n, devs.data()) != ncclSuccess) throw std::runtime_error("ncclCommInitAll failed");
         // a communication stream per GPU: the window exchange runs on it, beside the compute stream's kernels
         cstream.assign(n, nullptr);
         for (int i = 0; i < n; ++i) {
@@ -424,7 +397,7 @@ public:
     ~Node()
     {
         for (size_t i = 0; i < cstream.size(); ++i) if (cstream[i]) { hipSetDevice((int)i); hipStreamDestroy(cstream[i]); }
-        if (!comms_aborted) for (auto c : comm) if (c) ncclCommDestroy(c);       // ncclCommAbort has already freed them otherwise
+        if (!comms.aborted()) for (auto c : comms.comm) if (c) ncclCommDestroy(c);       // ncclCommAbort has already freed them otherwise
         for (auto c : ctx) if (c) oip_destroy(c);
     }
     hipStream_t stream(int r) { return (hipStream_t)oip_get_stream(ctx[r]); }
@@ -466,18 +439,23 @@ public:
     {
         if (!bar.wait() || failed) throw PeerFailed();
     }
+    // waits for the RCCL calls in flight on the peers' threads (CommGuard), then aborts every communicator once; from then
+    // on with_comm() throws PeerFailed instead of touching a freed communicator
     void abort_comms()
     {
-        bool expected = false;
-        if (comms_aborted.compare_exchange_strong(expected, true))
-            for (auto c : comm) if (c) ncclCommAbort(c);
+        comms.abort_all([](ncclComm_t c) { if (c) ncclCommAbort(c); });
+    }
+    // every use of a communicator -- one call or a whole ncclGroupStart .. ncclGroupEnd sequence -- goes through here
+    template <typename F> void with_comm(int r, F f)
+    {
+        if (failed) throw PeerFailed();
+        comms.use(r, f);
     }
     // an RCCL call that fails is this rank's failure: raised at once (run() then aborts the communicators), never carried
     // into a stream synchronisation that a peer may not be able to complete
-    void nccl_ok(ncclResult_t rc, const char *what)
+    static void nccl_ok(ncclResult_t rc, const char *what)
     {
         if (rc != ncclSuccess) throw std::runtime_error(std::string(what) + " failed: " + ncclGetErrorString(rc));
-        if (failed) throw PeerFailed();
     }
 
     // exchange step 1, overlapped with the correlation: every group of units that is not entirely on its rank is packed and
@@ -529,12 +507,14 @@ public:
                     }
                 }
             }
-            if (!sends.empty() || !recvs.empty()) {
-                nccl_ok(ncclGroupStart(), "ncclGroupStart");
-                for (auto &x : sends) nccl_ok(ncclSend(x.buf, x.bytes, ncclUint8, x.peer, comm[r], cs), "ncclSend (window piece)");
-                for (auto &x : recvs) nccl_ok(ncclRecv(x.buf, x.bytes, ncclUint8, x.peer, comm[r], cs), "ncclRecv (window piece)");
-                nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-            }
+            if (!sends.empty() || !recvs.empty())
+                with_comm(r, [&](ncclComm_t c) {
+                    fault_point(r, "exchange");
+                    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+                    for (auto &x : sends) nccl_ok(ncclSend(x.buf, x.bytes, ncclUint8, x.peer, c, cs), "ncclSend (window piece)");
+                    for (auto &x : recvs) nccl_ok(ncclRecv(x.buf, x.bytes, ncclUint8, x.peer, c, cs), "ncclRecv (window piece)");
+                    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+                });
             PendingGroup pg;
             pg.units = g.first;
             if (hipEventCreateWithFlags(&pg.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(pg.ev, cs) != hipSuccess)
@@ -567,15 +547,17 @@ public:
         sync_point();
         bool any = false;
         for (const LineTransfer &t : tr) any = any || t.src == r || t.dst == r;
-        if (any) {
-            nccl_ok(ncclGroupStart(), "ncclGroupStart");
-            for (const LineTransfer &t : tr)
-                for (int b = 0; b < planes; ++b) {
-                    if (t.src == r) nccl_ok(ncclSend(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.dst, comm[r], st), "ncclSend (halo lines)");
-                    if (t.dst == r) nccl_ok(ncclRecv(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.src, comm[r], st), "ncclRecv (halo lines)");
-                }
-            nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
-        }
+        if (any)
+            with_comm(r, [&](ncclComm_t c) {
+                fault_point(r, "halo");
+                nccl_ok(ncclGroupStart(), "ncclGroupStart");
+                for (const LineTransfer &t : tr)
+                    for (int b = 0; b < planes; ++b) {
+                        if (t.src == r) nccl_ok(ncclSend(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.dst, c, st), "ncclSend (halo lines)");
+                        if (t.dst == r) nccl_ok(ncclRecv(ptr_of(t.row0, b), (size_t)t.rows * bytes_per_line, ncclUint8, t.src, c, st), "ncclRecv (halo lines)");
+                    }
+                nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+            });
         check(r, oip_sync(ctx[r]));
         sync_point();
     }
@@ -591,7 +573,10 @@ public:
         check(r, oip_memcpy_h2d(ctx[r], d_send, table->data(), n * sizeof(double)));
         check(r, oip_sync(ctx[r]));
         sync_point();
-        nccl_ok(ncclAllGather(d_send, d_recv, n, ncclDouble, comm[r], stream(r)), "ncclAllGather");
+        with_comm(r, [&](ncclComm_t c) {
+            fault_point(r, "allgather");
+            nccl_ok(ncclAllGather(d_send, d_recv, n, ncclDouble, c, stream(r)), "ncclAllGather");
+        });
         std::vector<double> all(n * N);
         check(r, oip_memcpy_d2h(ctx[r], all.data(), d_recv, n * N * sizeof(double)));
         check(r, oip_sync(ctx[r]));
@@ -605,12 +590,23 @@ public:
 
     const int N;
     HostBarrier bar;
+    // OIP_FAULT_INJECT="<rank>:<point>" (point: exchange, halo, allgather) makes that rank throw at that point -- behind the
+    // barrier that precedes the exchange, its peers already posting: what the failure path has to survive (test_gpu_cli.py)
+    static void fault_point(int r, const char *point)
+    {
+        const char *e = getenv("OIP_FAULT_INJECT");
+        if (!e) return;
+        char want[32] = "";
+        int rank = -1;
+        if (sscanf(e, "%d:%31s", &rank, want) == 2 && rank == r && !strcmp(want, point))
+            throw std::runtime_error(std::string("injected failure on GPU ") + std::to_string(r) + " at " + point);
+    }
+
     std::vector<oip_ctx *> ctx;
-    std::vector<ncclComm_t> comm;
+    CommGuard<ncclComm_t> comms;
     std::vector<hipStream_t> cstream;
     std::vector<std::string> err;
     std::atomic<bool> failed{false};
-    std::atomic<bool> comms_aborted{false};
 };
 
 struct MultiGpuDefaultOptions {

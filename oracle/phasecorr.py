@@ -203,10 +203,15 @@ def filter_and_fit(shifts: np.ndarray, threshold=0.4, min_count=5, method="numcp
     """
     cxs = np.zeros((4, 2)); cys = np.zeros((4, 3))
     for b in range(4):
-        ok = shifts[b, :, 2] >= threshold
-        if int(ok.sum()) < min_count:
+        # preproc.h:498-503 counts a unit as valid unless `rs < threshold` -- a NaN response (f32 overflow of the cross-power
+        # spectrum, see _cross_power_ccs) is not below the threshold and IS counted; preproc.h:527 takes a unit into the
+        # fit when `rs >= threshold` -- the NaN unit is NOT taken.  Two different tests, restated as they are.
+        with np.errstate(invalid="ignore"):
+            fc = int((~(shifts[b, :, 2] < threshold)).sum())
+            ok = shifts[b, :, 2] >= threshold
+        if fc < min_count:
             raise RuntimeError("Not enough valid correlation values for band#%d: %d valid values "
-                               "found, %d expected at least" % (b + 1, int(ok.sum()), min_count))
+                               "found, %d expected at least" % (b + 1, fc, min_count))
         x = shifts[b, ok, 3]; dx = shifts[b, ok, 0]; dy = shifts[b, ok, 1]
         cxs[b] = polyfit(x, dx, 1, method)
         cys[b] = polyfit(x, dy, 2, method)

@@ -330,3 +330,9 @@ def test_multigpu_host_on_one_gpu_equals_the_plain_cli(tmp_path):
         a = open(os.path.join(dirs["plain"], f), "rb").read()
         b = open(os.path.join(dirs["node"], f), "rb").read()
         assert len(a) > 1000 and a == b, f
+    # a rank that fails inside the communication phase (OIP_FAULT_INJECT, oip_multigpu.hpp): the communicators are aborted
+    # under the guard, the process leaves with that rank's message and exit code 2 -- no hang, no crash
+    d = dirs["node"]
+    env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_TIFF_COMPRESS="none", OIP_FAULT_INJECT="0:allgather")
+    r = subprocess.run(args, cwd=d, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "injected failure on GPU 0 at allgather" in r.stdout, r.stdout + r.stderr

@@ -18,7 +18,6 @@ def test_read_file_to_device_ranges_short_files_and_errors(ctx, tmp_path):
     """ReadFileContent(filePath, size, offset, total) with the buffer in HBM: whole file, a range across several 32 MiB slots at an
     odd offset, a range past the end (reads short, as fread does), an empty range, a missing file."""
     import torch
-    import opticalimageprocessor_amd as oip
     rng = np.random.default_rng(3)
     n = (70 << 20) + 12345                                   # three ring slots, the last one ragged
     data = rng.integers(0, 256, n, dtype=np.uint8)
@@ -38,9 +37,8 @@ def test_read_file_to_device_ranges_short_files_and_errors(ctx, tmp_path):
     ctx.sync()
     assert got == 1000 and np.array_equal(d[:1000].cpu().numpy(), data[-1000:])
     assert ctx.read_file_to_device(path, d, offset=n + 10, nbytes=100) == 0
-    with pytest.raises(oip.OipError) as e:
+    with pytest.raises(ValueError, match="cannot open file"):                    # std::invalid_argument, imageop.h:55-57
         ctx.read_file_to_device(str(tmp_path / "missing.bin"), d)
-    assert e.value.status == 1 and "cannot open file" in str(e.value)            # std::invalid_argument, imageop.h:55-57
     torch.cuda.synchronize()
 
 
@@ -108,6 +106,5 @@ def test_permute_u16x4_in_place(ctx):
             ctx.permute_u16x4(d, npix, order)
             ctx.sync()
             assert np.array_equal(d.cpu().numpy(), img[:, order]), (npix, order)
-    import opticalimageprocessor_amd as oip
-    with pytest.raises(oip.OipError):
+    with pytest.raises(ValueError, match="outside 0..3"):
         ctx.permute_u16x4(torch.zeros(8, dtype=torch.uint16, device="cuda"), 2, [0, 1, 2, 4])

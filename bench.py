@@ -495,7 +495,7 @@ def cli_default_action(env, d, kb_mss, threshold):
         bw = W // 4
         for b in range(4):
             csv("MSS.B%d.csv" % (b + 1), kb_mss[b * bw:(b + 1) * bw])
-        want = d.out[..., [2, 1, 0, 3]].contiguous().cpu().numpy()          # the product's payload: cv::imwrite's sample order
+        want = d.out.cpu().numpy()[..., [2, 1, 0, 3]]                     # the product's payload: cv::imwrite's sample order
         t_inputs = time.time() - t0
         args = [exe, "--width", str(W), "--pan", "B_PAN.RAW", "--mss", "B_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv",
                 "--slices", str(d.plan.slices), "--ibc-sections", str(d.plan.sections), "--ibc-threshold", repr(threshold),

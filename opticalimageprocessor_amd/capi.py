@@ -269,6 +269,10 @@ class Context:
         s = getattr(stream, "cuda_stream", stream)
         self._ck(self.lib.oip_set_stream(self.h, s))
 
+    def get_stream(self):
+        """the hipStream_t the context's kernels run on, as an integer"""
+        return self.lib.oip_get_stream(self.h) or 0
+
     def sync(self):
         self._ck(self.lib.oip_sync(self.h))
 

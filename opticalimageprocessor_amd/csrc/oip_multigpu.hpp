@@ -54,7 +54,14 @@ struct LineTransfer {
 // the resident groups' kernels; a rank computes its resident groups first, then the others in index order as they arrive.
 // Every group starts where most of its bytes are; then single groups move, best move first, while a move lowers the ranks'
 // finish times sorted from the latest down.  The constants are dist.py's (LINK_GBS etc.; unmeasured on hardware).
-constexpr long kLinkGBs = 50, kPairUs16000x3000 = 2500, kCcdSectionUs16000x200 = 150;
+// OIP_LINK_GBS (an integer, GB/s) overrides the link figure in both hosts; `oip plan` prints what was used.
+constexpr long kPairUs16000x3000 = 2500, kCcdSectionUs16000x200 = 150;
+inline long link_gbs()
+{
+    const char *e = getenv("OIP_LINK_GBS");
+    const long v = e ? atol(e) : 50;
+    return v > 0 ? v : 50;
+}
 
 inline long rank_finish_us(const std::vector<long> &costs, long compute_us, long bytes_per_us)
 {
@@ -163,7 +170,7 @@ struct StripPlanC {
             }
             missing.push_back(m);
         }
-        const std::vector<int> where = assign_groups_by_cost(missing, world, compute_us, kLinkGBs * 1000, &predicted_finish_us);
+        const std::vector<int> where = assign_groups_by_cost(missing, world, compute_us, link_gbs() * 1000, &predicted_finish_us);
         assign.resize(n_units);
         for (int u = 0; u < n_units; ++u) assign[u] = where[u / 2];
     }
@@ -273,7 +280,7 @@ struct CcdPlanC {
             add_missing_bytes(&m, gap + (long)s * step, lps, cols, 2, pb, world);
             missing.push_back(m);
         }
-        assign = assign_groups_by_cost(missing, world, compute_us, kLinkGBs * 1000, &predicted_finish_us);
+        assign = assign_groups_by_cost(missing, world, compute_us, link_gbs() * 1000, &predicted_finish_us);
     }
     std::vector<long> predicted_finish_us;
     long section_start(int s) const { return gap + (long)s * step; }
@@ -356,7 +363,9 @@ inline void PrintStripPlan(const StripPlanC &p, const double *cy)
     std::vector<std::pair<long, long>> need;
     auto tr = p.align_transfers(cy, &need);
     for (size_t i = 0; i < tr.size(); ++i) printf("%s[%d,%d,%ld,%ld]", i ? "," : "", tr[i].src, tr[i].dst, tr[i].row0, tr[i].rows);
-    printf("]}\n");
+    printf("],\"link_gbs\":%ld,\"predicted_finish_us\":", link_gbs());
+    { std::vector<int> v(p.predicted_finish_us.begin(), p.predicted_finish_us.end()); print_int_list(v); }
+    printf("}\n");
 }
 inline void PrintCcdPlan(const CcdPlanC &p, double dy)
 {
@@ -370,7 +379,9 @@ inline void PrintCcdPlan(const CcdPlanC &p, double dy)
     for (size_t i = 0; i < tr.size(); ++i) printf("%s[%d,%d,%ld,%ld]", i ? "," : "", tr[i].src, tr[i].dst, tr[i].row0, tr[i].rows);
     printf("],\"need\":[");
     for (size_t i = 0; i < need.size(); ++i) printf("%s[%ld,%ld]", i ? "," : "", need[i].first, need[i].second);
-    printf("]}\n");
+    printf("],\"link_gbs\":%ld,\"predicted_finish_us\":", link_gbs());
+    { std::vector<int> v(p.predicted_finish_us.begin(), p.predicted_finish_us.end()); print_int_list(v); }
+    printf("}\n");
 }
 
 // ---- the node: one context, stream and communicator per GPU, one host thread per GPU -------------------------------
@@ -726,12 +737,18 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
             for (size_t j = 0; j < units.size(); ++j) memcpy(&table[(size_t)units[j] * 12], &res[12 * j], sizeof(double) * 12);
         };
         {
+            // A pair (2k, 2k+1) is resident only when BOTH its units are: with an odd slice count a pair spans two sections and one
+            // unit can be local while its partner is not -- computing the local one alone would shift every later pairing on this
+            // rank, and a unit's last digits depend on its partner.  Such a pair waits for its exchange group and is
+            // computed whole.
+            auto pair_of = [&](int u) { std::vector<int> v; for (int w = u & ~1; w < std::min((u & ~1) + 2, plan.n_units); ++w) v.push_back(w); return v; };
+            auto pair_local = [&](int u) { for (int w : pair_of(u)) if (!plan.unit_is_local(w)) return false; return true; };
             std::vector<int> resident;
-            for (int u : mine) if (plan.unit_is_local(u)) resident.push_back(u);
+            for (int u : mine) if (pair_local(u)) resident.push_back(u);
             correlate(resident);
             for (const auto &g : pending.groups) {
                 std::vector<int> here;
-                for (int u : g.units) if (plan.assign[u] == r) here.push_back(u);
+                for (int u : pair_of(g.units[0])) if (plan.assign[u] == r) here.push_back(u);
                 if (here.empty()) continue;
                 node.wait_group(r, g);
                 correlate(here);

@@ -30,6 +30,8 @@ tests); this module only plans rows and moves them.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -76,7 +78,17 @@ class Piece:
 # LINK_GBS is what one xGMI link is assumed to sustain for a grouped send/recv (spec peak 153 GB/s per direction;
 # 50 is deliberately conservative and, like every number here, UNMEASURED on hardware: no multi-GPU node was
 # available to the builder).
-LINK_GBS = 50
+# OIP_LINK_GBS overrides it for both hosts (this module and csrc/oip_multigpu.hpp read the same variable): the first run on
+# a multi-GPU node prints predicted against measured times (bench.py `multi_gpu`), the variable is how the result is fed back.
+def _link_gbs_default():
+    try:
+        v = int(os.environ.get("OIP_LINK_GBS", "50"))
+    except ValueError:
+        v = 50
+    return v if v > 0 else 50
+
+
+LINK_GBS = _link_gbs_default()
 PAIR_US_16000x3000 = 2500
 CCD_SECTION_US_16000x200 = 150
 
@@ -515,13 +527,19 @@ def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, r
     # the result -- is that of the single-GPU order.
     pending = []
     if multi:
+        if bufs_is_cuda(bufs) and hasattr(backend, "check_stream_contract"):
+            backend.check_stream_contract()
         if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
             backend.sync()                      # host-staged rehearsal: the RRC output is read through .cpu()
         pending = post_pieces(plan.exchange_groups(), bufs, rank, group)
-    correlate([u for u in mine if plan.unit_is_local(u)])
+    # (with an odd slice count a pair spans two sections and one unit can be local while its partner is not: the pair then
+    # waits for its exchange group and is computed whole -- a local unit computed alone would shift every later pairing)
+    pair_of = lambda u: [v for v in (u - u % 2, u - u % 2 + 1) if v < plan.n_units]
+    pair_local = lambda u: all(plan.unit_is_local(v) for v in pair_of(u))
+    correlate([u for u in mine if pair_local(u)])
     for units, wait in pending:
         wait()
-        correlate([u for u in units if plan.assign[u] == rank])
+        correlate([u for u in pair_of(units[0]) if plan.assign[u] == rank])
     if multi:
         shifts = gather_table(shifts, bufs.pan.device if bufs.pan.is_cuda else "cpu", group)
     cx, cy = backend.filter_and_fit(shifts, threshold, min_count, fit)
@@ -697,6 +715,8 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
     mine = plan.units_of(rank)
     pending = []
     if multi:
+        if bufs_is_cuda(bufs) and hasattr(backend, "check_stream_contract"):
+            backend.check_stream_contract()
         if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
             backend.sync()
         pending = post_pieces(plan.exchange_groups(), bufs, rank, group)     # posted first, computed as they arrive
@@ -742,6 +762,15 @@ class HipBackend:
 
     def sync(self):
         self.ctx.sync()
+
+    def check_stream_contract(self):
+        """The N-rank steps order RRC output -> RCCL send, RCCL receive -> work.wait() -> correlation kernels through ONE stream:
+        torch's current stream (the one RCCL synchronises against) must be the context's compute stream (a caller that
+        kept the context's own stream would send windows before their RRC has run, silently)."""
+        import torch
+        if torch.cuda.is_available() and self.ctx.get_stream() != torch.cuda.current_stream().cuda_stream:
+            raise RuntimeError("the oip context's stream is not torch's current stream: call ctx.set_stream(torch.cuda.current_stream()) "
+                               "before an N-rank step (RCCL orders its transfers against torch's current stream)")
 
     def rrc(self, src, dst, w, h, kb):
         self.ctx.rrc_u16(src, dst, w, h, kb)

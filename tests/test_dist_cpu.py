@@ -22,14 +22,14 @@ ALIGN = dict(lines_per_section=700, line_offset=0, overlap=60, keep_leading=Fals
 THR = -1.0      # tiny windows: accept every correlation, the test is about the plumbing
 
 
-def _inputs():
+def _inputs(W=W):
     from opticalimageprocessor_amd import synth
     kb = synth.lut(W)
     kb4 = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
     return kb, kb4
 
 
-def _run_rank(rank, world, port, tmp):
+def _run_rank(rank, world, port, tmp, slices=SLICES, W=W):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -37,16 +37,28 @@ def _run_rank(rank, world, port, tmp):
     from opticalimageprocessor_amd import synth
     from opticalimageprocessor_amd.dist import ShardBuffers, StripPlan, default_action_step
     from _oracle_backend import OracleBackend
-    kb, kb4 = _inputs()
-    plan = StripPlan(W, LP, world, SLICES, SECTIONS, CORR, halo_cap=16, **ALIGN)
+    kb, kb4 = _inputs(W)
+    plan = StripPlan(W, LP, world, slices, SECTIONS, CORR, halo_cap=16, **ALIGN)
     bufs = ShardBuffers(plan, rank, "cpu")
+    # which units every correlation call was handed (the GPU kernels process the list two at a time: calls must be whole pairs)
+    calls, seen = [], []
+    orig_windows = bufs.unit_windows
+    bufs.unit_windows = lambda u: (seen.append(u), orig_windows(u))[1]
+    backend = OracleBackend(plan)
+    orig_units = backend.interband_units
+
+    def logged_units(pw, bw):
+        calls.append(list(seen[-len(pw):]))
+        return orig_units(pw, bw)
+    backend.interband_units = logged_units
     raw_pan = synth.pan_strip(64 + rank * plan.pb, plan.pb, W, kb, device="cpu")
     raw_mss = synth.mss_strip(16 + rank * plan.mb, plan.mb, W, kb4, device="cpu")
     o0, o1 = plan.align_out_rows(rank)
     out = torch.zeros(o1 - o0, W // 4, 4, dtype=torch.uint16)
-    cx, cy, rows = default_action_step(OracleBackend(plan), plan, bufs, raw_pan, raw_mss, kb, kb4, out, rank,
+    cx, cy, rows = default_action_step(backend, plan, bufs, raw_pan, raw_mss, kb, kb4, out, rank,
                                        threshold=THR)
     np.savez(os.path.join(tmp, "w%d_r%d.npz" % (world, rank)), out=out.numpy(), cx=cx, cy=cy, rows=np.array(rows),
+             calls=np.array(sum([c + [-1] for c in calls], []), dtype=np.int64),
              remote=np.array([u for u in plan.units_of(rank) if not plan.unit_is_local(u)]),
              mine=np.array(plan.units_of(rank)))
     if world > 1:
@@ -88,6 +100,46 @@ def test_four_rank_shards_equal_single_process(tmp_path):
     parts = [np.load(os.path.join(tmp, "w4_r%d.npz" % r)) for r in range(4)]
     assert sum(len(p["remote"]) for p in parts) > 0
     assert sorted(np.concatenate([p["mine"] for p in parts]).tolist()) == list(range(SLICES * SECTIONS))
+    for p in parts:
+        assert np.array_equal(p["cx"], one["cx"]) and np.array_equal(p["cy"], one["cy"])
+    assert np.array_equal(np.concatenate([p["out"] for p in parts], 0), one["out"])
+
+
+def test_odd_slice_count_keeps_the_unit_pairs_whole(tmp_path):
+    """with an odd slice count a pair (2k, 2k+1) of correlation units spans two sections, so one unit can be resident
+    on its rank while its partner needs lines of another rank.  The GPU kernels process a call's units two at a time and a unit's
+    last digits depend on its partner: every call must consist of whole pairs of the single-GPU order, on every rank -- and the
+    result must still be the single process's."""
+    tmp = str(tmp_path)
+    slices, width = 9, 720                                         # 80-column units, as in the 8-slice tests
+    _run_rank(0, 1, _free_port(), tmp, slices, width)
+    mp.spawn(_run_rank, args=(2, _free_port(), tmp, slices, width), nprocs=2, join=True)
+    one = np.load(os.path.join(tmp, "w1_r0.npz"))
+    parts = [np.load(os.path.join(tmp, "w2_r%d.npz" % r)) for r in range(2)]
+    n_units = slices * SECTIONS
+    done = []
+    mixed = 0
+    for p in parts:
+        flat = p["calls"].tolist()
+        call = []
+        for v in flat:
+            if v >= 0:
+                call.append(v)
+                continue
+            assert len(call) > 0
+            for j in range(0, len(call), 2):                       # consecutive entries form the kernel's pairs
+                a = call[j]
+                assert a % 2 == 0, call
+                if a + 1 < n_units:
+                    assert j + 1 < len(call) and call[j + 1] == a + 1, call
+                else:
+                    assert j + 1 == len(call), call
+            done += call
+            call = []
+        remote = set(p["remote"].tolist())
+        mixed += sum(1 for u in p["mine"].tolist() if u % 2 == 0 and u + 1 < n_units and ((u in remote) != (u + 1 in remote)))
+    assert sorted(done) == list(range(n_units))
+    assert mixed > 0                                               # the case the test is about does occur in this geometry
     for p in parts:
         assert np.array_equal(p["cx"], one["cx"]) and np.array_equal(p["cy"], one["cy"])
     assert np.array_equal(np.concatenate([p["out"] for p in parts], 0), one["out"])

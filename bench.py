@@ -520,7 +520,9 @@ def cli_default_action(env, d, kb_mss, threshold):
             rec = {"wall_ms": wall * 1e3, "exit": r.returncode}
             for ln in r.stdout.splitlines():
                 if ln.startswith("TIMING default_action"):
-                    rec["log_seconds"] = {k: float(v) for k, v in (kv.split("=") for kv in ln.split()[2:])}
+                    kv = dict(x.split("=", 1) for x in ln.split()[2:])
+                    rec["correlation_calls_start_plus_ms"] = kv.pop("correlation_calls_ms", None)
+                    rec["log_seconds"] = {k: float(v) for k, v in kv.items()}
             if r.returncode != 0:
                 rec["tail"] = (r.stdout + r.stderr)[-400:]
             prod = os.path.join(tmp, "B_MSS.ALIGNED.TIFF")
@@ -580,13 +582,13 @@ def build_workload(env, p):
         stitched = torch.empty(pb, 2 * (W - cplan.fold), dtype=torch.uint16, device=dev)
         backend = HipBackend(ctx, cplan)
 
-        def step():
+        def step(timer=None):
             # main.cpp:270-286 then :177-190: correlation on the raw strips, RRC of both, remap of CCD 2, stitch
             dx, dy, _ = prestitch_stitch_step(backend, cplan, cbufs, d_kb_pan, d_kb2, prestt, stitched, rank,
-                                              threshold=p.threshold, f16acc=p.fp16, fused=getattr(p, "fused", False))
+                                              threshold=p.threshold, f16acc=p.fp16, fused=getattr(p, "fused", False), timer=timer)
             info["dx"], info["dy"] = dx, dy
         d.__dict__.update(step=step, pix_per_rank=2 * W * pb, base_rows=16000, base_cols=OV, M=16000, N=OV, out_local=0,
-                          rows_arrays=2.0, prestt=prestt, stitched=stitched, sections=nsec,
+                          rows_arrays=2.0, prestt=prestt, stitched=stitched, sections=nsec, plan=cplan, backend=backend,
                           workload=("prestitch + stitch: 2 CCD segments %dx%d%s, %d x (16000x%d) phase correlations, RRC x2, "
                                     "constant-shift bicubic remap (30000-row sections, %s accumulate), RAW stitch fold %d%s" %
                                     (W, Lp, " in %d scan-line blocks" % world if world > 1 else "", nsec, OV,
@@ -613,9 +615,9 @@ def build_workload(env, p):
         out = torch.zeros(max(o1 - o0, 1), W // 4, 4, dtype=torch.uint16, device=dev)
         backend = HipBackend(ctx, plan)
 
-        def step():
+        def step(timer=None):
             cx, cy, _ = default_action_step(backend, plan, bufs, raw_pan, raw_mss, d_kb_pan, d_kb_mss, out, rank,
-                                            threshold=p.threshold)
+                                            threshold=p.threshold, timer=timer)
             info["cx"], info["cy"] = cx, cy
         base_rows, base_cols = plan.base_rows, W // p.slices
         M, N = optimal_dft_size(base_rows), optimal_dft_size(base_cols)
@@ -627,7 +629,8 @@ def build_workload(env, p):
                          (world, pb, sections_total, min(len(plan.units_of(r)) for r in range(world)),
                           max(len(plan.units_of(r)) for r in range(world)), plan.n_units))
         d.__dict__.update(step=step, pix_per_rank=W * pb + W * plan.mb, base_rows=base_rows, base_cols=base_cols, M=M, N=N,
-                          out_local=o1 - o0, workload=workload, plan=plan, bufs=bufs, raw_pan=raw_pan, raw_mss=raw_mss, out=out)
+                          out_local=o1 - o0, workload=workload, plan=plan, bufs=bufs, raw_pan=raw_pan, raw_mss=raw_mss, out=out,
+                          backend=backend)
     # a synthetic scene that does not clear --ibc-threshold is an error here, not a reason to change the workload
     d.step()
     ctx.sync()
@@ -816,6 +819,31 @@ def config_legs(env, args, line):
     return out
 
 
+def multi_gpu_stage_times(env, d):
+    """ONE instrumented step after the timed region (dist.StepTimer: the stream is drained at every stage boundary, so the step is
+    slower than a timed one): per rank the stage times, next to what the placement model predicted for the correlation stage --
+    the model's constants (dist.LINK_GBS, PAIR_US_16000x3000) have never met a multi-GPU node; this is what the first run on one
+    has to confirm or refute.  On the gloo rehearsal (ranks sharing GPUs, host-staged transfers) the numbers only show that the
+    fields work."""
+    from opticalimageprocessor_amd.dist import LINK_GBS, StepTimer
+    env.barrier()
+    t = StepTimer(d.backend)
+    d.step(timer=t)
+    mine = t.result()
+    allr = [None] * env.world
+    env.dist.all_gather_object(allr, mine)
+    if env.rank != 0:
+        return None
+    rnd = lambda v: [round(x, 3) for x in v] if isinstance(v, list) else round(v, 3)
+    keys = sorted({k for r in allr for k in r})
+    return {"mode": "rccl over xGMI" if env.dist_backend == "nccl" else "rehearsal (%s, ranks share GPUs, transfers staged through the host)" % env.dist_backend,
+            "link_GBs_assumed": LINK_GBS,
+            "predicted_correlation_finish_us": [int(v) for v in d.plan.predicted_finish_us],
+            "measured_correlation_finish_us": [int(r.get("correlation_finish_ms", 0.0) * 1e3) for r in allr],
+            "measured_ms": {k: [rnd(r.get(k, 0.0)) for r in allr] for k in keys if k != "correlation_finish_ms"},
+            "note": "per rank; list entries = one per received pair of units; measured on one instrumented step outside the timed region"}
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: this process -- which never touches the GPU -- starts the N ranks as child
     processes of the same command line (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, rendezvous on 127.0.0.1),
@@ -948,6 +976,7 @@ def main():
                threshold=args.ibc_threshold, fp16=args.fp16_accumulate, fused=args.fused)
     d = build_workload(env, p)
     elapsed, prof_all, prof, dom = measure(env, d, args.steps, args.warmup)
+    multi_gpu = multi_gpu_stage_times(env, d) if world > 1 and args.workload != "rrc" else None
 
     if rank == 0:
         W, pb = d.W, d.pb
@@ -970,6 +999,8 @@ def main():
         r = rrc_line(kernels)
         if r:
             line["rrc_kernel"] = r
+        if multi_gpu:
+            line["multi_gpu"] = multi_gpu
         if args.workload == "prestitch":
             line["shift"] = {"dx": d.info.get("dx"), "dy": d.info.get("dy"), "truth_px": list(synth.CCD_SHIFT)}
         if world == 1 and not args.no_cpu_baseline:

@@ -384,6 +384,48 @@ inline void PrintCcdPlan(const CcdPlanC &p, double dy)
     printf("}\n");
 }
 
+// ---- stage times of a rank's step -------------------------------------------------------------------
+// The placement model (predicted_finish_us) has never met a multi-GPU node: every N-GPU run logs, per GPU, where its step's
+// time went -- host time between points at which the rank's stream is drained anyway (RRC done, a correlation call returned,
+// the all-gather or halo exchange synchronised, the product block downloaded) -- next to the model's prediction.
+struct StageClock {
+    std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    std::vector<std::pair<std::string, double>> ms;
+    double since_rrc = 0.0, correlation_finish = 0.0;
+    bool rrc_done = false;
+    void tick(const char *name)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+        for (auto &e : ms) if (e.first == name) { e.second += d; goto booked; }
+        ms.push_back({name, d});
+    booked:
+        if (rrc_done) since_rrc += d;
+        if (!strcmp(name, "rrc")) rrc_done = true;
+        if (!strncmp(name, "correlate", 9)) correlation_finish = since_rrc;
+    }
+    std::string line() const
+    {
+        std::string s;
+        char b[96];
+        for (auto &e : ms) { snprintf(b, sizeof b, "%s%s %.2f", s.empty() ? "" : " | ", e.first.c_str(), e.second); s += b; }
+        return s;
+    }
+};
+inline void LogStageClocks(const std::vector<StageClock> &clk, const std::vector<long> &predicted_us)
+{
+    OLOG("Stage times per GPU in ms (host clock at points where the GPU's stream is drained; link figure assumed by the placement: %ld GB/s):", link_gbs());
+    for (size_t r = 0; r < clk.size(); ++r) RLOG("  GPU %zu: %s", r, clk[r].line().c_str());
+    std::string p, m;
+    char b[48];
+    for (size_t r = 0; r < clk.size(); ++r) {
+        snprintf(b, sizeof b, "%s%ld", r ? ", " : "", r < predicted_us.size() ? predicted_us[r] : -1L); p += b;
+        snprintf(b, sizeof b, "%s%.0f", r ? ", " : "", clk[r].correlation_finish * 1e3); m += b;
+    }
+    RLOG("  correlation stage finished (us after the RRC): predicted [%s], measured [%s]", p.c_str(), m.c_str());
+}
+
 // ---- the node: one context, stream and communicator per GPU, one host thread per GPU -------------------------------
 class Node {
 public:
@@ -537,7 +579,10 @@ public:
     // the compute stream waits (on the device) for one group's bytes
     void wait_group(int r, const PendingGroup &g)
     {
-        if (hipStreamWaitEvent(stream(r), g.ev, 0) != hipSuccess) throw std::runtime_error("exchange wait failed");
+        // the host waits too (the correlation call that follows could not start earlier anyway): the wait for a pair's bytes is
+        // then booked apart from the pair's correlation (StageClock)
+        if (hipEventSynchronize(g.ev) != hipSuccess || hipStreamWaitEvent(stream(r), g.ev, 0) != hipSuccess)
+            throw std::runtime_error("exchange wait failed");
     }
     void finish_pieces(int r, PendingExchange *pe)
     {
@@ -658,7 +703,9 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
     std::vector<std::vector<uint16_t>> blocks(N);             // aligned rows of each rank, on the host
     std::vector<std::pair<long, long>> out_rows(N);
     double cxAll[MSS_BANDS][2] = {}, cyAll[MSS_BANDS][3] = {};
+    std::vector<StageClock> clocks(N);
     node.run([&](int r) {
+        StageClock &clk = clocks[r];
         oip_ctx *c = node.ctx[r];
         auto ck = [&](int rc) { node.check(r, rc); };
         // the rank's own lines, read from the files at the block's offset
@@ -681,6 +728,8 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
         };
         read_block(panFile, (size_t)r * plan.pb * lineBytes, (size_t)plan.pb * lineBytes, pan);
         read_block(mssFile, (size_t)r * plan.mb * lineBytes, (size_t)plan.mb * lineBytes, bil);
+        ck(oip_sync(c));
+        clk.tick("read");
         double *d_kb = nullptr;
         ck(oip_malloc(c, (void **)&d_kb, (size_t)W * 16));
         if (o.doRRC4PAN) {
@@ -692,6 +741,7 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
         uint16_t *own = planes + (size_t)head * Wb;
         ck(oip_mss_split_rrc_u16(c, bil, own, plane_stride, W, plan.mb, o.doRRC4MSS ? d_kb : nullptr));
         ck(oip_sync(c));
+        clk.tick("rrc");
         ck(oip_free(c, bil));
         // exchange 1: compact windows of the units this rank computes but does not hold entirely
         const std::vector<int> mine = plan.units_of(r);
@@ -711,6 +761,7 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
                 if (p.kind == 0) return wpan[p.unit] + (size_t)p.dst_row * plan.base_cols;
                 return wmss[p.unit] + (size_t)b * plan.band_rows * plan.band_cols + (size_t)p.dst_row * plan.band_cols;
             });
+        clk.tick("exchange_post");
         // The units, pairs as in the single-GPU order (a pair is resident or not as a whole): the resident pairs are computed
         // while the exchange runs on the communication stream, then every received pair behind its own event.
         std::vector<double> table((size_t)plan.n_units * 12, std::numeric_limits<double>::quiet_NaN());
@@ -746,17 +797,22 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
             std::vector<int> resident;
             for (int u : mine) if (pair_local(u)) resident.push_back(u);
             correlate(resident);
+            clk.tick("correlate_resident");
             for (const auto &g : pending.groups) {
                 std::vector<int> here;
                 for (int u : pair_of(g.units[0])) if (plan.assign[u] == r) here.push_back(u);
                 if (here.empty()) continue;
                 node.wait_group(r, g);
+                clk.tick("exchange_wait");
                 correlate(here);
+                clk.tick("correlate_received");
             }
             node.finish_pieces(r, &pending);
+            clk.tick("exchange_drain");
         }
         // exchange 2: the table [unit][band][dx, dy, rs]
         node.allgather_table(r, &table, 12);
+        clk.tick("allgather");
         std::vector<double> shifts((size_t)MSS_BANDS * plan.n_units * 4);
         for (int b = 0; b < MSS_BANDS; ++b)
             for (int u = 0; u < plan.n_units; ++u) {
@@ -777,6 +833,7 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
         node.exchange_lines(r, tr, MSS_BANDS, (size_t)Wb * 2, [&](long line, int b) -> void * {
             return planes + (size_t)b * plane_stride + (size_t)(line - m_first) * Wb;
         });
+        clk.tick("fit+halo");
         long v0 = b0, v1 = b1;
         for (const LineTransfer &t : tr) if (t.dst == r) { v0 = std::min(v0, t.row0); v1 = std::max(v1, t.row0 + t.rows); }
         long o0, o1;
@@ -793,9 +850,11 @@ inline void RunDefaultActionMultiGpu(const std::string &panFile, const std::stri
             ck(oip_download_staged(c, blocks[r].data(), out, n * 2));
             ck(oip_free(c, out));
         }
+        clk.tick("align+download");
         for (int u : mine) { if (wpan[u]) oip_free(c, wpan[u]); if (wmss[u]) oip_free(c, wmss[u]); }
         oip_free(c, d_kb); oip_free(c, planes); oip_free(c, pan);
     });
+    LogStageClocks(clocks, plan.predicted_finish_us);
     for (int b = 0; b < MSS_BANDS; ++b) {
         OLOG("BAND %d\tdeltaX coeff: [1] %.15f, [0] %.9f", b, cxAll[b][1], cxAll[b][0]);
         OLOG("\tdeltaY coeff: [2] %.15f, [1] %.15f, [0] %.9f", cyAll[b][2], cyAll[b][1], cyAll[b][0]);
@@ -838,7 +897,9 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
     const std::string fp = IMO::BuildOutputFilePath(f2, ".PRESTT");
     Node node(N);
     double dxAll = 0, dyAll = 0;
+    std::vector<StageClock> clocks(N);
     node.run([&](int r) {
+        StageClock &clk = clocks[r];
         oip_ctx *c = node.ctx[r];
         auto ck = [&](int rc) { node.check(r, rc); };
         const long b0 = r * plan.pb;
@@ -870,6 +931,9 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
                 return {(p.kind == 0 ? p1 : p2) + (size_t)(p.row0 - b0) * W + p.col0, (size_t)W};
             },
             [&](const Piece &p, int) -> void * { return (p.kind == 0 ? wa : wb)[p.unit] + (size_t)p.dst_row * plan.cols; });
+        ck(oip_sync(c));
+        clk.tick("read");
+        clk.tick("rrc");                                  // CalcSttParameters works on the RAW lines: the model's time 0 is here
         std::vector<double> table((size_t)plan.sections * 3, std::numeric_limits<double>::quiet_NaN());
         auto correlate = [&](const std::vector<int> &units) {
             if (units.empty()) return;
@@ -891,16 +955,21 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
             std::vector<int> resident;
             for (int u : mine) if (plan.unit_is_local(u)) resident.push_back(u);
             correlate(resident);
+            clk.tick("correlate_resident");
             for (const auto &g : pending.groups) {
                 std::vector<int> here;
                 for (int u : g.units) if (plan.assign[u] == r) here.push_back(u);
                 if (here.empty()) continue;
                 node.wait_group(r, g);
+                clk.tick("exchange_wait");
                 correlate(here);
+                clk.tick("correlate_received");
             }
             node.finish_pieces(r, &pending);
+            clk.tick("exchange_drain");
         }
         node.allgather_table(r, &table, 3);
+        clk.tick("allgather");
         double dx, dy, resp;
         int valid = 0;
         if (oip_stt_mean(table.data(), plan.sections, o.threshold, o.maxDeltaY, &dx, &dy, &resp, &valid) != OIP_OK)      // stitcher.h:181-198
@@ -939,11 +1008,15 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
             ck(oip_sync(c));
         }
         oip_free(c, p2);
+        clk.tick("rrc_x2");
         node.exchange_lines(r, tr, 1, lineBytes, [&](long line, int) -> void * { return r2 + (size_t)(line - f) * W; });
+        clk.tick("halo");
         uint16_t *dst = nullptr;
         ck(oip_malloc(c, (void **)&dst, blockBytes));
         auto fn = o.fp16acc ? oip_remap_shift_bicubic_u16_f16acc : oip_remap_shift_bicubic_u16;
         ck(fn(c, r2, f, l - f, dst, b0, plan.pb, W, L, dx, dy, OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
+        ck(oip_sync(c));
+        clk.tick("remap");
         // products: the ranks append their blocks to the files in rank order (every rank passes N turns)
         for (int t = 0; t < N; ++t) {
             if (t == r) {
@@ -955,8 +1028,10 @@ inline void RunPrestitchMultiGpu(const std::string &pan1, const std::string &pan
             }
             node.sync_point();
         }
+        clk.tick("write");
         oip_free(c, dst); oip_free(c, r2); oip_free(c, p1);
     });
+    LogStageClocks(clocks, plan.predicted_finish_us);
     if (!o.onlyCalc) OLOG("Pre-stitched PAN2 written to file '%s' (dx %.5f, dy %.5f).", fp.c_str(), dxAll, dyAll);
 }
 

@@ -25,8 +25,10 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -39,10 +41,17 @@ enum TiffCompression { TIFF_NONE = 1, TIFF_LZW = 5 };
 
 namespace tiffdetail {
 
+// threads of the strip encoder / decoder: half the host's threads, at most 32 (OIP_TIFF_THREADS overrides, up to 128) -- LZW is
+// the one stage of a compressed product that stays on the CPU, ~100 MB/s per thread
 inline int worker_count()
 {
-    int n = (int)std::thread::hardware_concurrency() / 2;
-    return n < 1 ? 1 : (n > 16 ? 16 : n);
+    static const int n = [] {
+        const char *e = getenv("OIP_TIFF_THREADS");
+        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        const int cap = e ? 128 : 32;
+        return v < 1 ? 1 : (v > cap ? cap : v);
+    }();
+    return n;
 }
 
 // run fn(i) for i in [0, n) on a few threads
@@ -61,61 +70,87 @@ template <typename F> inline void parallel_for(size_t n, F fn)
     for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 }
 
-struct BitWriter {
-    std::vector<uint8_t> &out;
-    uint64_t acc = 0;
-    int nbits = 0;
-    explicit BitWriter(std::vector<uint8_t> &o) : out(o) {}
-    void put(unsigned code, int width)
+// The string table of the encoder: open addressing over 16384 slots (4x the 4094 entries), a slot = (generation << 20) |
+// (prefix code << 8) | byte.  ClearCode starts a new GENERATION instead of wiping the table -- sensor data barely compresses
+// (a code per 1.3 bytes), so the table fills every ~5 KB of input and wiping 64 KB each time cost more than the coding itself.
+struct LzwTable {
+    static constexpr int kHash = 1 << 14;
+    uint32_t key[kHash];
+    uint16_t code[kHash];
+    uint32_t gen = 0;
+    LzwTable() { memset(key, 0, sizeof key); }
+    void clear()
     {
-        acc = (acc << width) | code;
-        nbits += width;
-        while (nbits >= 8) { out.push_back((uint8_t)(acc >> (nbits - 8))); nbits -= 8; }
+        if (++gen == (1u << 12)) { memset(key, 0, sizeof key); gen = 1; }      // generation 0 is never current: zeroed slots are empty
     }
-    void flush() { if (nbits > 0) { out.push_back((uint8_t)(acc << (8 - nbits))); nbits = 0; } }
 };
 
-inline void lzw_encode(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+// encoded strip: a buffer that is NOT value-initialised (a vector would zero 1.5 x the strip before the encoder overwrites it)
+struct LzwStrip {
+    std::unique_ptr<uint8_t[]> p;
+    size_t n = 0;
+    const uint8_t *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+
+inline void lzw_encode(const uint8_t *src, size_t n, LzwStrip &out)
 {
-    constexpr int kHash = 1 << 14;                 // open addressing, 4x the table
-    std::vector<int32_t> hkey(kHash, -1);          // (prefix << 8) | byte
-    std::vector<uint16_t> hcode(kHash);
-    out.clear();
-    out.reserve(n / 2 + 64);
-    BitWriter bw(out);
+    static thread_local std::unique_ptr<LzwTable> tab;  // ~96 KB, once per encoding thread
+    if (!tab) tab.reset(new LzwTable());
+    tab->clear();
+    // worst case: one 12-bit code per byte, plus Clear / EOI codes
+    out.p.reset(new uint8_t[n + n / 2 + n / 1024 + 64]);
+    uint8_t *o = out.p.get();
+    uint64_t acc = 0;
+    int nbits = 0;
+    auto put = [&](unsigned code, int width) {
+        acc = (acc << width) | code;
+        nbits += width;
+        while (nbits >= 8) { *o++ = (uint8_t)(acc >> (nbits - 8)); nbits -= 8; }
+    };
     int width = 9, next = 258;
-    bw.put(256, width);
-    if (n == 0) { bw.put(257, width); bw.flush(); return; }
+    put(256, width);
+    if (n == 0) {
+        put(257, width);
+        if (nbits > 0) *o++ = (uint8_t)(acc << (8 - nbits));
+        out.n = (size_t)(o - out.p.get());
+        return;
+    }
+    uint32_t gen = tab->gen << 20;
     int ent = src[0];
     for (size_t i = 1; i < n; ++i) {
         const int c = src[i];
-        const int32_t key = (ent << 8) | c;
-        unsigned h = ((unsigned)key * 2654435761u) >> 18;
+        const uint32_t key = gen | ((uint32_t)ent << 8) | (uint32_t)c;
+        unsigned h = ((((uint32_t)ent << 8) | (uint32_t)c) * 2654435761u) >> 18;
         bool found = false;
-        while (hkey[h] != -1) {
-            if (hkey[h] == key) { ent = hcode[h]; found = true; break; }
-            h = (h + 1) & (kHash - 1);
+        for (;;) {
+            const uint32_t k = tab->key[h];
+            if (k == key) { ent = tab->code[h]; found = true; break; }
+            if ((k >> 20) != (gen >> 20)) break;                            // empty in this generation
+            h = (h + 1) & (LzwTable::kHash - 1);
         }
         if (found) continue;
-        bw.put((unsigned)ent, width);
+        put((unsigned)ent, width);
         ent = c;
-        hkey[h] = key;
-        hcode[h] = (uint16_t)next++;
+        tab->key[h] = key;
+        tab->code[h] = (uint16_t)next++;
         if (next == 4094) {                        // table full: clear (libtiff: free_ent == CODE_MAX - 1)
-            bw.put(256, width);
-            std::fill(hkey.begin(), hkey.end(), -1);
+            put(256, width);
+            tab->clear();
+            gen = tab->gen << 20;
             width = 9;
             next = 258;
         } else if (next == (1 << width) && width < 12) {
             ++width;
         }
     }
-    bw.put((unsigned)ent, width);
+    put((unsigned)ent, width);
     ++next;                                        // libtiff's LZWPostEncode: the last code counts as an entry too
-    if (next == 4094) { bw.put(256, width); width = 9; }
+    if (next == 4094) { put(256, width); width = 9; }
     else if (next == (1 << width) && width < 12) ++width;
-    bw.put(257, width);
-    bw.flush();
+    put(257, width);
+    if (nbits > 0) *o++ = (uint8_t)(acc << (8 - nbits));
+    out.n = (size_t)(o - out.p.get());
 }
 
 // returns the number of bytes produced (at most cap); throws on a corrupt stream
@@ -352,18 +387,18 @@ private:
     {
         const size_t rw = (size_t)mW * mSpp;
         const long nstrips = (nrows + mRowsPerStrip - 1) / mRowsPerStrip;
-        std::vector<std::vector<uint8_t>> enc((size_t)nstrips);
+        std::vector<tiffdetail::LzwStrip> enc((size_t)nstrips);
         tiffdetail::parallel_for((size_t)nstrips, [&](size_t k) {
             const long r0 = (long)k * mRowsPerStrip;
             const long n = std::min<long>(mRowsPerStrip, nrows - r0);
-            std::vector<uint16_t> buf((size_t)n * rw);
+            std::unique_ptr<uint16_t[]> buf(new uint16_t[(size_t)n * rw]);
             for (long r = 0; r < n; ++r) {
                 const uint16_t *src = rows + (size_t)(r0 + r) * rw;
-                uint16_t *d = buf.data() + (size_t)r * rw;
+                uint16_t *d = buf.get() + (size_t)r * rw;
                 if (mSwap) swap_row(src, d); else memcpy(d, src, rw * 2);
                 tiffdetail::predictor2_encode(d, (size_t)mW, mSpp);
             }
-            tiffdetail::lzw_encode((const uint8_t *)buf.data(), buf.size() * 2, enc[k]);
+            tiffdetail::lzw_encode((const uint8_t *)buf.get(), (size_t)n * rw * 2, enc[k]);
         });
         for (long k = 0; k < nstrips; ++k) {
             if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }

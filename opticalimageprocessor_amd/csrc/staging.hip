@@ -55,15 +55,17 @@ public:
         return p;
     }
     int threads() const { return (int)mWorkers.size() + 1; }
-    // fn(part, nparts) on every thread of the pool (part 0 on the caller); returns when all are done
-    void run(const std::function<void(int, int)> &fn)
+    int copy_threads() const { return mCopyThreads; }
+    // fn(part, nparts) on the first `limit` threads of the pool (0: all; part 0 on the caller); returns when all are done
+    void run(const std::function<void(int, int)> &fn, int limit = 0)
     {
-        const int n = threads();
+        const int n = limit > 0 && limit < threads() ? limit : threads();
         if (n == 1) { fn(0, 1); return; }
         std::lock_guard<std::mutex> one_at_a_time(mCall);          // a reader and a writer thread may both be here
         {
             std::unique_lock<std::mutex> lk(mMu);
             mFn = &fn;
+            mParts = n;
             mPending = (int)mWorkers.size();
             ++mGen;
         }
@@ -79,7 +81,7 @@ public:
         run([&](int i, int n) {
             const size_t part = ((bytes + n - 1) / n + 4095) & ~(size_t)4095, off = (size_t)i * part;
             if (off < bytes) memcpy((char *)dst + off, (const char *)src + off, bytes - off < part ? bytes - off : part);
-        });
+        }, mCopyThreads);
     }
     // rows of `width` bytes, the pitches in bytes: the rows are dealt over the threads in contiguous runs
     void copy2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t rows)
@@ -91,7 +93,7 @@ public:
         run([&](int i, int n) {
             const size_t part = (rows + n - 1) / n, r0 = (size_t)i * part;
             if (r0 < rows) rows_of(r0, r0 + part < rows ? r0 + part : rows);
-        });
+        }, mCopyThreads);
     }
     // pread of [off, off + bytes) of fd into dst, every thread its own share; returns the bytes read when the file covered
     // the range, less when it ended early (the contiguous prefix), (size_t)-1 on a read error (errno kept in *err)
@@ -120,11 +122,16 @@ public:
     }
 
 private:
+    // Two sizes, both measured on the GPU box: pageable <-> pinned memcpy is best on 8-16 threads (more only
+    // contend), pread from the page cache into a slot keeps gaining up to 32 (profiles/r04_io_*).  OIP_HOST_COPY_THREADS sets
+    // the first, OIP_HOST_READ_THREADS the pool size (both at most 64).
     CopyPool()
     {
-        const char *e = getenv("OIP_HOST_COPY_THREADS");
-        int n = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        n = n < 1 ? 1 : (n > 64 ? 64 : (!e && n > 16 ? 16 : n));
+        auto env_int = [](const char *name, int def) { const char *e = getenv(name); const int v = e ? atoi(e) : def; return v < 1 ? 1 : (v > 64 ? 64 : v); };
+        const int half = (int)std::thread::hardware_concurrency() / 2;
+        mCopyThreads = env_int("OIP_HOST_COPY_THREADS", half > 16 ? 16 : half);
+        int n = env_int("OIP_HOST_READ_THREADS", half > 32 ? 32 : half);
+        if (n < mCopyThreads) n = mCopyThreads;
         for (int i = 1; i < n; ++i) mWorkers.emplace_back([this, i] { work(i); });
     }
     ~CopyPool()
@@ -146,9 +153,9 @@ private:
             seen = mGen;
             if (mStop) return;
             const std::function<void(int, int)> *fn = mFn;
-            const int n = threads();
+            const int n = mParts;
             lk.unlock();
-            (*fn)(idx, n);
+            if (idx < n) (*fn)(idx, n);
             lk.lock();
             if (--mPending == 0) mDone.notify_one();
         }
@@ -157,7 +164,7 @@ private:
     std::mutex mMu, mCall;
     std::condition_variable mCv, mDone;
     unsigned long mGen = 0;
-    int mPending = 0;
+    int mPending = 0, mParts = 1, mCopyThreads = 1;
     bool mStop = false;
     const std::function<void(int, int)> *mFn = nullptr;
 };
@@ -212,6 +219,7 @@ static int stage_init(oip_ctx *ctx)
     OIP_HIP(ctx, hipSetDevice(ctx->device));
     std::lock_guard<std::mutex> once(g_stage_init_mu);
     if (ctx->stage) return OIP_OK;
+    const auto t_init = std::chrono::steady_clock::now();
     oip_stage_state *s = new oip_stage_state();
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->down[0].stream, hipStreamNonBlocking) != hipSuccess ||
@@ -230,14 +238,24 @@ static int stage_init(oip_ctx *ctx)
     if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->down[0].compute_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->down[1].compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+    // (the download lanes pin their slots on first use -- down_lane_ready: a reader that never writes does not pay for them,
+    // and a writer thread pins its own while the reader is already moving data)
     for (auto &d : s->down)
         for (int i = 0; i < 2; ++i)
-            if (hipHostMalloc(&d.slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
-                hipEventCreateWithFlags(&d.slot_free[i], hipEventDisableTiming) != hipSuccess) {
-                delete s;
-                return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
-            }
+            if (hipEventCreateWithFlags(&d.slot_free[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
     ctx->stage = s;
+    if (getenv("OIP_STAGE_TRACE"))
+        fprintf(stderr, "oip staging: ring of %d x %zu MiB pinned in %.1f ms\n", kSlots, kSlotBytes >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count());
+    return OIP_OK;
+}
+
+// called with the lane's lock held
+static int down_lane_ready(oip_ctx *ctx, oip_stage_state::DownLane &d)
+{
+    for (int i = 0; i < 2; ++i)
+        if (!d.slot[i] && hipHostMalloc(&d.slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess)
+            return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
     return OIP_OK;
 }
 
@@ -343,7 +361,7 @@ extern "C" int oip_stage_sync(oip_ctx *ctx)
     return OIP_OK;
 }
 
-extern "C" int oip_stage_threads(void) { return CopyPool::get().threads(); }
+extern "C" int oip_stage_threads(void) { return CopyPool::get().copy_threads(); }
 
 // ---- file <-> device -------------------------------------------------------------------------------
 extern "C" int oip_read_file_to_device(oip_ctx *ctx, const char *path, size_t offset, size_t bytes, void *d_dst,
@@ -457,6 +475,7 @@ static int write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes
     oip_stage_state *s = ctx->stage;
     DownLaneLock lane(s);
     oip_stage_state::DownLane &d = *lane.d;
+    if ((rc = down_lane_ready(ctx, d))) return rc;
     const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC | (truncate ? O_TRUNC : 0), 0644);
     if (fd < 0) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);  // imageop.h:86-88
     struct stat st;
@@ -601,6 +620,7 @@ extern "C" int oip_download_staged_after(oip_ctx *ctx, void *host, const void *d
     oip_stage_state *s = ctx->stage;
     DownLaneLock lane(s);
     oip_stage_state::DownLane &d = *lane.d;
+    if ((rc = down_lane_ready(ctx, d))) return rc;
     // a download lane (see oip_stage_state): ordered after the mark, or after what the compute stream has enqueued so far
     if ((rc = down_order(ctx, s, d, mark))) return rc;
     int prev = -1;

@@ -492,8 +492,43 @@ def gather_table(local: np.ndarray, device, group=None) -> np.ndarray:
 gather_shifts = gather_table
 
 
+class StepTimer:
+    """Stage times of ONE instrumented N-rank step on this rank: the placement model (`predicted_finish_us`)
+    has never met hardware, so the first run on a node must show where a step's time goes.  tick(name) drains the backend's
+    stream and books the host time since the previous tick to `name`; list-valued stages (one entry per received pair) keep
+    every entry.  An instrumented step is slower than a plain one (the drains) -- bench.py runs it once, outside the timed region.
+    `correlation_finish_ms`: from the end of the RRC (the model's time 0) to this rank's last correlation."""
+
+    def __init__(self, backend):
+        import time as _t
+        self._now = _t.perf_counter
+        self.backend = backend
+        self.ms = {}
+        self.backend.sync()
+        self.t0 = self.last = self._now()
+        self.t_rrc = None
+
+    def tick(self, name, listed=False):
+        self.backend.sync()
+        now = self._now()
+        d = (now - self.last) * 1e3
+        if listed:
+            self.ms.setdefault(name, []).append(d)
+        else:
+            self.ms[name] = self.ms.get(name, 0.0) + d
+        self.last = now
+        if name == "rrc_ms":
+            self.t_rrc = now
+        if name.startswith("correlate"):
+            self.ms["correlation_finish_ms"] = (now - (self.t_rrc or self.t0)) * 1e3
+
+    def result(self):
+        self.ms["step_ms"] = (self.last - self.t0) * 1e3
+        return self.ms
+
+
 def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, raw_mss_bil, kb_pan, kb_mss4, out,
-                        rank: int, threshold=0.4, min_count=5, group=None, fit="reference"):
+                        rank: int, threshold=0.4, min_count=5, group=None, fit="reference", timer: "StepTimer | None" = None):
     """One pass of the sharded default action on this rank.
 
     backend provides (all on device memory):
@@ -509,6 +544,8 @@ def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, r
     backend.rrc(raw_pan, bufs.pan, W, plan.pb, kb_pan)
     backend.mss_split_rrc(raw_mss_bil, bufs.planes, bufs.own_planes_offset(), bufs.plane_stride, W, plan.mb, kb_mss4)
     bufs.m_valid = list(plan.mss_block(rank))
+    tick = timer.tick if timer is not None else (lambda *a, **k: None)
+    tick("rrc_ms")
     shifts = np.full((4, plan.n_units, 4), np.nan)
     for u in range(plan.n_units):
         shifts[:, u, 3] = (u % plan.slices) * plan.base_cols + plan.base_cols // 2        # preproc.h:326
@@ -532,24 +569,39 @@ def default_action_step(backend, plan: StripPlan, bufs: ShardBuffers, raw_pan, r
         if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
             backend.sync()                      # host-staged rehearsal: the RRC output is read through .cpu()
         pending = post_pieces(plan.exchange_groups(), bufs, rank, group)
+        tick("exchange_post_ms")
     # (with an odd slice count a pair spans two sections and one unit can be local while its partner is not: the pair then
     # waits for its exchange group and is computed whole -- a local unit computed alone would shift every later pairing)
     pair_of = lambda u: [v for v in (u - u % 2, u - u % 2 + 1) if v < plan.n_units]
     pair_local = lambda u: all(plan.unit_is_local(v) for v in pair_of(u))
     correlate([u for u in mine if pair_local(u)])
+    tick("correlate_resident_ms")
     for units, wait in pending:
         wait()
-        correlate([u for u in pair_of(units[0]) if plan.assign[u] == rank])
+        here = [u for u in pair_of(units[0]) if plan.assign[u] == rank]
+        if here:
+            tick("exchange_wait_ms", listed=True)          # what this rank waited for the pair's bytes beyond its own work
+        correlate(here)
+        if here:
+            tick("correlate_received_ms", listed=True)
+    tick("exchange_drain_ms")                              # pairs sent to other ranks: their handles are waited for too
     if multi:
         shifts = gather_table(shifts, bufs.pan.device if bufs.pan.is_cuda else "cpu", group)
+        tick("allgather_ms")
     cx, cy = backend.filter_and_fit(shifts, threshold, min_count, fit)
+    tick("fit_ms")
     o0, o1 = plan.align_out_rows(rank)
     if multi:
         transfers, _ = plan.align_transfers(lambda a, n: backend.align_src_range(a, n, cy))
         run_transfers(transfers, bufs, rank, group)
+        tick("halo_ms")
     if o1 > o0:
         backend.align(bufs.planes, bufs.plane_stride, bufs.m_first, bufs.m_valid[0], bufs.m_valid[1], out, o0,
                       o1 - o0, cx, cy)
+    tick("align_ms")
+    if timer is not None:
+        timer.ms["units_resident"] = len([u for u in mine if pair_local(u)])
+        timer.ms["units_received"] = len(mine) - timer.ms["units_resident"]
     return cx, cy, (o0, o1)
 
 
@@ -685,7 +737,7 @@ class CcdBuffers:
 
 
 def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, prestt, stitched, rank: int,
-                          threshold=0.4, max_delta_y=0.0, f16acc=False, group=None, fused=False):
+                          threshold=0.4, max_delta_y=0.0, f16acc=False, group=None, fused=False, timer: "StepTimer | None" = None):
     """One pass of the sharded cross-CCD path on this rank: CalcSttParameters on the RAW lines (App. B-1) ->
     RRC of both CCDs -> constant-shift bicubic remap of CCD 2 with row halo -> RAW stitch.
 
@@ -704,6 +756,8 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
     multi = plan.world > 1
     b0, b1 = plan.block(rank)
     table = np.full((plan.sections, 3), np.nan)
+    tick = timer.tick if timer is not None else (lambda *a, **k: None)
+    tick("rrc_ms")                                          # (nothing yet: CalcSttParameters reads the RAW lines -- the model's time 0)
 
     def correlate(units):
         if not units:
@@ -720,12 +774,21 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
         if bufs_is_cuda(bufs) and dist.get_backend(group) == "gloo":
             backend.sync()
         pending = post_pieces(plan.exchange_groups(), bufs, rank, group)     # posted first, computed as they arrive
+        tick("exchange_post_ms")
     correlate([u for u in mine if plan.unit_is_local(u)])
+    tick("correlate_resident_ms")
     for units, wait in pending:
         wait()
-        correlate([u for u in units if plan.assign[u] == rank])
+        here = [u for u in units if plan.assign[u] == rank]
+        if here:
+            tick("exchange_wait_ms", listed=True)
+        correlate(here)
+        if here:
+            tick("correlate_received_ms", listed=True)
+    tick("exchange_drain_ms")
     if multi:
         table = gather_table(table, bufs.pan1.device if bufs.pan1.is_cuda else "cpu", group)
+        tick("allgather_ms")
     dx, dy, _, _ = backend.stt_mean(table, threshold, max_delta_y)       # identical on every rank
     # DoRRC (stitcher.h:141-146): own lines of both CCDs; CCD 2 lands in the halo-capable buffer
     if fused:
@@ -739,18 +802,23 @@ def prestitch_stitch_step(backend, plan: CcdPlan, bufs: CcdBuffers, kb1, kb2, pr
         # CCD-2 samples on load -- DoRRC of CCD 2, PreStitch and the right half of the stitch are one pass, nothing in between
         backend.remap_rrc_window(bufs.pan2, b0, plan.pb, kb2, stitched, 2 * (W - plan.fold), plan.fold, W - plan.fold, b0, plan.pb, dx, dy,
                                  f16acc)
+        tick("rrc_remap_stitch_ms")
         return dx, dy, table
     bufs.alloc_rrc2(f, l)
     backend.rrc(bufs.pan2, bufs.rrc2[b0 - bufs.r2_first:b1 - bufs.r2_first], W, plan.pb, kb2)
+    tick("rrc_x2_ms")
     if multi:
         backend.sync()
         run_transfers(transfers, bufs, rank, group)
+        tick("halo_ms")
     if fused:
         backend.remap_window(bufs.rrc2, bufs.r2_first, bufs.rrc2.shape[0], stitched, 2 * (W - plan.fold), plan.fold, W - plan.fold, b0,
                              plan.pb, dx, dy, f16acc)
+        tick("remap_stitch_ms")
         return dx, dy, table
     backend.remap(bufs.rrc2, bufs.r2_first, bufs.rrc2.shape[0], prestt, b0, plan.pb, dx, dy, f16acc)
     backend.stitch(bufs.rrc1, prestt, stitched, plan.pb)
+    tick("remap_stitch_ms")
     return dx, dy, table
 
 

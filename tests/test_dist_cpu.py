@@ -29,7 +29,7 @@ def _inputs(W=W):
     return kb, kb4
 
 
-def _run_rank(rank, world, port, tmp, slices=SLICES, W=W):
+def _run_rank(rank, world, port, tmp, slices=SLICES, W=W, timed=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -55,9 +55,13 @@ def _run_rank(rank, world, port, tmp, slices=SLICES, W=W):
     raw_mss = synth.mss_strip(16 + rank * plan.mb, plan.mb, W, kb4, device="cpu")
     o0, o1 = plan.align_out_rows(rank)
     out = torch.zeros(o1 - o0, W // 4, 4, dtype=torch.uint16)
+    from opticalimageprocessor_amd.dist import StepTimer
+    timer = StepTimer(backend) if timed else None
     cx, cy, rows = default_action_step(backend, plan, bufs, raw_pan, raw_mss, kb, kb4, out, rank,
-                                       threshold=THR)
+                                       threshold=THR, timer=timer)
+    import json
     np.savez(os.path.join(tmp, "w%d_r%d.npz" % (world, rank)), out=out.numpy(), cx=cx, cy=cy, rows=np.array(rows),
+             stages=np.array(json.dumps(timer.result() if timer else {})),
              calls=np.array(sum([c + [-1] for c in calls], []), dtype=np.int64),
              remote=np.array([u for u in plan.units_of(rank) if not plan.unit_is_local(u)]),
              mine=np.array(plan.units_of(rank)))
@@ -95,9 +99,21 @@ def test_four_rank_shards_equal_single_process(tmp_path):
     ranks, pairs are posted one batch each and computed as they arrive -- still the single-process bits"""
     tmp = str(tmp_path)
     _run_rank(0, 1, _free_port(), tmp)
-    mp.spawn(_run_rank, args=(4, _free_port(), tmp), nprocs=4, join=True)
+    mp.spawn(_run_rank, args=(4, _free_port(), tmp, SLICES, W, True), nprocs=4, join=True)
     one = np.load(os.path.join(tmp, "w1_r0.npz"))
     parts = [np.load(os.path.join(tmp, "w4_r%d.npz" % r)) for r in range(4)]
+    # the instrumented form of the step (dist.StepTimer; what bench.py --gpus N prints as `multi_gpu`): every stage is booked on
+    # every rank, a rank that received pairs lists a wait and a correlation time per pair -- and the results are still the bits
+    import json
+    for p in parts:
+        st = json.loads(str(p["stages"]))
+        for k in ("rrc_ms", "exchange_post_ms", "correlate_resident_ms", "exchange_drain_ms", "allgather_ms", "fit_ms", "halo_ms", "align_ms",
+                  "step_ms", "correlation_finish_ms", "units_resident", "units_received"):
+            assert k in st, (k, st)
+        assert st["units_resident"] + st["units_received"] == len(p["mine"])
+        assert len(st.get("exchange_wait_ms", [])) == len(st.get("correlate_received_ms", [])) == (st["units_received"] + 1) // 2
+        assert abs(st["step_ms"] - sum(v if not isinstance(v, list) else sum(v) for k, v in st.items()
+                                       if k.endswith("_ms") and k not in ("step_ms", "correlation_finish_ms"))) < 1e-6
     assert sum(len(p["remote"]) for p in parts) > 0
     assert sorted(np.concatenate([p["mine"] for p in parts]).tolist()) == list(range(SLICES * SECTIONS))
     for p in parts:

@@ -525,6 +525,8 @@ def cli_default_action(env, d, kb_mss, threshold):
                     rec["log_seconds"] = {k: float(v) for k, v in kv.items()}
             if r.returncode != 0:
                 rec["tail"] = (r.stdout + r.stderr)[-400:]
+            if r.stderr.strip():
+                rec["stderr_tail"] = r.stderr.strip()[-300:]
             prod = os.path.join(tmp, "B_MSS.ALIGNED.TIFF")
             if os.path.exists(prod):
                 rec["product_bytes"] = os.path.getsize(prod)

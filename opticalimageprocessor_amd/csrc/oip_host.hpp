@@ -250,6 +250,40 @@ template <typename T> struct DevBuf {              // RAII device buffer
 constexpr int BYTES_PER_PIXEL = 2;
 constexpr int MSS_BANDS = OIP_MSS_BANDS;
 
+// A TIFF product whose pixels are in HBM (rows x width x spp u16, interleaved).  Uncompressed: the pixel payload goes from
+// the device into the file behind the header (TiffWriterU16::begin_external_payload + oip_write_device_to_file_at) -- no
+// strip-sized heap copy, as the reference's cv::imwrite / GDAL paths make (imageop.h:316-328, preproc.h:167-185).  LZW: the
+// lines come down 256 MiB at a time and their strips are encoded on a few threads.  opencv_order (4 samples): the image takes
+// cv::imwrite's on-disk sample order (c2,c1,c0,c3) ON THE DEVICE first -- d_img is modified; `order` (4 samples, GDAL band
+// maps): out sample i = in sample order[i], likewise.  mark: 0, or the compute-stream mark the image is complete at.
+inline void write_tiff_from_device(const std::string &path, uint16_t *d_img, int width, long height, int spp, int compression,
+                                   bool opencv_order, const int *order = nullptr, long mark = 0, bool permute_done = false)
+{
+    oip_ctx *ctx = Device::get().ctx();
+    if (spp == MSS_BANDS && !permute_done && (opencv_order || order)) {
+        const int cvOrder[4] = {2, 1, 0, 3};
+        Device::get().check(oip_permute_u16x4(ctx, d_img, (size_t)width * height, order ? order : cvOrder));
+        mark = 0;                                                      // (the permutation is younger than the mark)
+    }
+    TiffWriterU16 tw(path, width, height, spp, false, compression);
+    const size_t rowSamples = (size_t)width * spp;
+    if (compression == TIFF_NONE) {
+        const uint64_t at = tw.begin_external_payload();
+        Device::get().check(oip_write_device_to_file_at(ctx, d_img, (size_t)height * rowSamples * 2, path.c_str(), (size_t)at, mark));
+        tw.end_external_payload();
+    } else {
+        const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
+        std::unique_ptr<uint16_t[]> host(new uint16_t[(size_t)std::min(chunk, height) * rowSamples]);
+        for (long r0 = 0; r0 < height; r0 += chunk) {
+            const long nr = std::min(chunk, height - r0);
+            Device::get().check(oip_download_staged_after(ctx, host.get(), d_img + (size_t)r0 * rowSamples, (size_t)nr * rowSamples * 2, mark));
+            tw.write_rows(host.get(), nr);
+        }
+    }
+    tw.close();
+}
+
+
 // ---- ImageOperations (imageop.h:33-568, hot-path subset) -----------------------------------------
 struct RRCParam { double k; double b; };     // imageop.h:26-29
 
@@ -408,17 +442,8 @@ public:
         OLOG("Begin stitching two images ...");
         stop_watch sw;
         Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, pixelPerLine, imageLines, foldColPixels));
-        if (outputIsTiff) {                                            // 1-band GTiff (imageop.h:316-328), row blocks as they come down
-            TiffWriterU16 tw(outputFilePath, outputFullLinePixels, imageLines, 1, false, tiff_compression(TIFF_NONE));
-            const long chunk = std::max<long>(1, (long)(((size_t)64 << 20) / ((size_t)outputFullLinePixels * 2)));
-            std::vector<uint16_t> rows((size_t)chunk * outputFullLinePixels);
-            for (long r0 = 0; r0 < imageLines; r0 += chunk) {
-                const long n = std::min(chunk, imageLines - r0);
-                Device::get().check(oip_download_staged(Device::get().ctx(), rows.data(), dout.p + (size_t)r0 * outputFullLinePixels,
-                                                        (size_t)n * outputFullLinePixels * 2));
-                tw.write_rows(rows.data(), n);
-            }
-            tw.close();
+        if (outputIsTiff) {                                            // 1-band GTiff (imageop.h:316-328), straight from the device
+            write_tiff_from_device(outputFilePath, dout.p, outputFullLinePixels, imageLines, 1, tiff_compression(TIFF_NONE), false);
         } else {
             dout.save_file(outputFilePath, nout);
         }
@@ -744,14 +769,13 @@ public:
             OLOG("DoInterBandAlignment(): done.");
             return;
         }
-        std::unique_ptr<uint16_t[]> h(new uint16_t[(size_t)rows * Wb * MSS_BANDS]);
-        out.download(h.get(), (size_t)rows * Wb * MSS_BANDS);
+        Device::get().check(oip_sync(Device::get().ctx()));
         double es = sw.tick();
         OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", es, processed, rows);
         // preproc.h:167-185 WriteAlignedMSS_TIFF: 4-channel 16-bit TIFF, samples in OpenCV's on-disk order
         auto save = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
         OLOG("Outputing aligned TIFF image (%d x %ld x 4) to [%s] ...", Wb, rows, save.c_str());
-        write_tiff_u16(save, h.get(), Wb, rows, MSS_BANDS, true, tiff_compression(TIFF_LZW));
+        write_tiff_from_device(save, out.p, Wb, rows, MSS_BANDS, tiff_compression(TIFF_LZW), true);
         OLOG("Output done.");
         if (autoUnloadRawMSS) mPlanes.release();
         OLOG("DoInterBandAlignment(): done.");
@@ -890,9 +914,19 @@ public:
             }
         });
         double tCorrDone = 0.0, tAlignDone = 0.0;
-        std::string alignedPath;
-        std::unique_ptr<TiffWriterU16> tiff;               // (declared before the writers: their jobs use it)
+        // the product file exists from the start (its blocks are reserved while the strip is still being read); a run that fails
+        // takes it away again
+        struct ProductGuard {
+            std::string path;
+            bool done = false;
+            ~ProductGuard() { if (!done && !path.empty()) ::remove(path.c_str()); }
+        } productGuard;
+        const std::string alignedPath = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
+        const int comp = tiff_compression(TIFF_LZW);
+        std::unique_ptr<TiffWriterU16> tiff(new TiffWriterU16(alignedPath, Wb, outRows, MSS_BANDS, false, comp));   // (declared before the writers: their jobs use it)
+        productGuard.path = alignedPath;
         JobThread panWriter, productWriter;
+        if (comp == TIFF_NONE) { TiffWriterU16 *twp = tiff.get(); productWriter.post([twp] { twp->preallocate(); }); }
         struct Joiner {                                    // whatever happens below, the threads are stopped and joined
             std::thread &reader; std::atomic<bool> &cancel;
             ~Joiner() { cancel = true; if (reader.joinable()) reader.join(); }
@@ -1004,9 +1038,6 @@ public:
                 ck(oip_permute_u16x4(ctx, out.p, (size_t)outRows * Wb, fileOrder));
                 long mark = 0;
                 ck(oip_compute_mark(ctx, &mark));
-                alignedPath = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
-                const int comp = tiff_compression(TIFF_LZW);
-                tiff.reset(new TiffWriterU16(alignedPath, Wb, outRows, MSS_BANDS, false, comp));
                 TiffWriterU16 *tw = tiff.get();
                 const uint16_t *img = out.p;
                 const size_t rowSamples = (size_t)Wb * MSS_BANDS;
@@ -1045,6 +1076,7 @@ public:
         panWriter.finish();
         if (o.writeRrcPan) OLOG("Written to file [%s].", rrcPanPath.c_str());
         productWriter.finish();
+        productGuard.done = true;
         const double tAll = seconds_since(t0);
         mMssBil.release();
         mPlanes.release();
@@ -1184,10 +1216,8 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         // the raw CCD-2 samples are corrected on load by the resampling kernel itself (either accumulate mode): one pass over the strip
         ck(oip_remap_shift_rrc_bicubic_u16_window(ctx, p2.p, 0, L, kb.p, st.p, ow, fold, W - fold, 0, L, W, L, dx, dy, OIP_REMAP_SECTION_ROWS,
                                                   OIP_REMAP_ROW_GUARD, o.fp16acc ? 1 : 0));
-        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
-        st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
-        write_tiff_u16(outPAN, h.get(), (int)ow, L, 1, false, tiff_compression(TIFF_NONE));
+        write_tiff_from_device(outPAN, st.p, (int)ow, L, 1, tiff_compression(TIFF_NONE), false);
         OLOG("Fused task (PAN only) done in %.3f seconds.", total.tick());
         return;
     }
@@ -1212,10 +1242,8 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         const size_t nout = (size_t)2 * (W - fold) * L;
         DevBuf<uint16_t> st(nout);
         ck(oip_stitch_rows_u16(ctx, p1.p, p2s.p, st.p, W, L, fold));
-        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
-        st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
-        write_tiff_u16(outPAN, h.get(), 2 * (W - fold), L, 1, false, tiff_compression(TIFF_NONE));
+        write_tiff_from_device(outPAN, st.p, 2 * (W - fold), L, 1, tiff_compression(TIFF_NONE), false);
     }
     // ---- step 3: inter-band alignment per CCD, PAN taken from the device
     DevBuf<uint16_t> aligned[2];
@@ -1239,16 +1267,14 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         const size_t nout = (size_t)2 * (W4 - fold4) * arows[0];
         DevBuf<uint16_t> st(nout);
         ck(oip_stitch_rows_u16(ctx, aligned[0].p, aligned[1].p, st.p, W4, arows[0], fold4));
-        std::unique_ptr<uint16_t[]> h(new uint16_t[nout]);
-        st.download(h.get(), nout);
         OLOG("Write stitched image to file '%s' ...", outMSS.c_str());
         const int ow = 2 * (Wb - fold);
         if (!o.useGDAL && nout < 4000000000ull) {
-            write_tiff_u16(outMSS, h.get(), ow, arows[0], MSS_BANDS, true, tiff_compression(TIFF_LZW));          // as cv::imwrite of the stitched Mat
+            write_tiff_from_device(outMSS, st.p, ow, arows[0], MSS_BANDS, tiff_compression(TIFF_LZW), true);     // as cv::imwrite of the stitched Mat
         } else {
             int order[4];
             for (int b = 0; b < 4; ++b) order[b] = o.bandMap ? o.bandMap[b] - 1 : b;  // band b <- Mat channel map[b]-1
-            write_tiff_u16_mapped(outMSS, h.get(), ow, arows[0], order, tiff_compression(TIFF_LZW));
+            write_tiff_from_device(outMSS, st.p, ow, arows[0], MSS_BANDS, tiff_compression(TIFF_LZW), false, order);
         }
     }
     OLOG("Fused task done in %.3f seconds.", total.tick());

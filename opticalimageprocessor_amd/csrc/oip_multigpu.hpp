@@ -29,8 +29,62 @@
 #include <mutex>
 #include <thread>
 
+#include <dlfcn.h>
+
 #include "oip_host.hpp"
 #include "oip_rankguard.hpp"
+
+// RCCL is loaded when the first --gpus run asks for it, not with the executable: librccl.so is 570 MB of code objects for
+// every architecture, and mapping, relocating and registering it costs every single-GPU `oip` run its start-up time
+// (measured: DESIGN.md 4.5).  Types come from <rccl/rccl.h>; the entry points are resolved from librccl.so.1 on first use.
+namespace OIPGPU {
+struct RcclApi {
+    decltype(&::ncclCommInitAll) CommInitAll;
+    decltype(&::ncclCommDestroy) CommDestroy;
+    decltype(&::ncclCommAbort) CommAbort;
+    decltype(&::ncclGroupStart) GroupStart;
+    decltype(&::ncclGroupEnd) GroupEnd;
+    decltype(&::ncclSend) Send;
+    decltype(&::ncclRecv) Recv;
+    decltype(&::ncclAllGather) AllGather;
+    decltype(&::ncclGetErrorString) GetErrorString;
+    static RcclApi &get()
+    {
+        static RcclApi a;
+        return a;
+    }
+private:
+    RcclApi()
+    {
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) throw std::runtime_error(std::string("--gpus needs RCCL: ") + dlerror());
+        auto sym = [&](const char *name) {
+            void *p = dlsym(h, name);
+            if (!p) throw std::runtime_error(std::string("librccl.so.1 lacks ") + name);
+            return p;
+        };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    }
+};
+}  // namespace OIPGPU
+#define ncclCommInitAll ::OIPGPU::RcclApi::get().CommInitAll
+#define ncclCommDestroy ::OIPGPU::RcclApi::get().CommDestroy
+#define ncclCommAbort ::OIPGPU::RcclApi::get().CommAbort
+#define ncclGroupStart ::OIPGPU::RcclApi::get().GroupStart
+#define ncclGroupEnd ::OIPGPU::RcclApi::get().GroupEnd
+#define ncclSend ::OIPGPU::RcclApi::get().Send
+#define ncclRecv ::OIPGPU::RcclApi::get().Recv
+#define ncclAllGather ::OIPGPU::RcclApi::get().AllGather
+#define ncclGetErrorString ::OIPGPU::RcclApi::get().GetErrorString
 
 namespace OIPGPU {
 

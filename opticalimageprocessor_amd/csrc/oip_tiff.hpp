@@ -23,11 +23,15 @@
 // reproduces that, so files written here round-trip through cv::imread exactly like the reference's.
 #pragma once
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -303,7 +307,9 @@ public:
     void close()
     {
         if (!mF) return;
+        wait_write();
         if (mRowsDone != mH || !mPending.empty()) { fclose(mF); mF = nullptr; throw std::logic_error("TiffWriterU16: rows missing"); }
+        if (mPositioned && fseeko(mF, (off_t)mPos, SEEK_SET) != 0) { fclose(mF); mF = nullptr; throw std::runtime_error("TiffWriterU16: seek failed"); }
         if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
         // out-of-line arrays first
         const uint64_t nstrips = mStripOff.size();
@@ -355,8 +361,22 @@ public:
         mF = nullptr;
     }
 
-    ~TiffWriterU16() { if (mF) fclose(mF); }
+    ~TiffWriterU16()
+    {
+        try { wait_write(); } catch (...) {}
+        if (mF) fclose(mF);
+    }
     bool bigtiff() const { return mBig; }
+
+    // Reserve the file's blocks ahead of the pixels (uncompressed files: header + payload are known up front).  On tmpfs and
+    // on extent file systems allocating the pages is the larger part of a buffered write: a product writer
+    // that is idle while the strip is still being read does it then, and the payload write that follows is a copy.  Best effort.
+    void preallocate()
+    {
+        if (mComp != TIFF_NONE || !mF) return;
+        fflush(mF);
+        (void)posix_fallocate(fileno(mF), 0, (off_t)(mPos + mRowBytes * (uint64_t)mH));
+    }
 
     // Uncompressed files only: the whole pixel payload (height x width x spp samples, already in FILE sample order) is written
     // by someone else at the returned byte offset -- the staging layer, straight from HBM (oip_write_device_to_file_at) --
@@ -400,15 +420,36 @@ private:
             }
             tiffdetail::lzw_encode((const uint8_t *)buf.get(), (size_t)n * rw * 2, enc[k]);
         });
+        // the batch goes to the file on a thread of its own (positioned writes) while the caller brings down and encodes the
+        // next one; the previous batch's write is waited for -- and its error raised -- first
+        wait_write();
+        auto job = std::make_shared<std::vector<tiffdetail::LzwStrip>>(std::move(enc));
+        std::vector<uint64_t> at((size_t)nstrips);
         for (long k = 0; k < nstrips; ++k) {
-            if (mPos & 1) { const unsigned char z = 0; put(&z, 1); ++mPos; }
-            if (!mBig && mPos + enc[k].size() > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
+            if (mPos & 1) ++mPos;                                       // strips start on even offsets (the gap reads as zero)
+            if (!mBig && mPos + (*job)[k].size() > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
+            at[(size_t)k] = mPos;
             mStripOff.push_back(mPos);
-            mStripLen.push_back(enc[k].size());
-            put(enc[k].data(), enc[k].size());
-            mPos += enc[k].size();
+            mStripLen.push_back((*job)[k].size());
+            mPos += (*job)[k].size();
         }
+        if (fflush(mF) != 0) throw std::runtime_error("TiffWriterU16: write failed");
+        mPositioned = true;
+        const int fd = fileno(mF);
+        mWrite = std::async(std::launch::async, [fd, job, at] {
+            for (size_t k = 0; k < job->size(); ++k) {
+                const uint8_t *p = (*job)[k].data();
+                size_t n = (*job)[k].size(), w = 0;
+                while (w < n) {
+                    const ssize_t r = pwrite(fd, p + w, n - w, (off_t)(at[k] + w));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) throw std::runtime_error("TiffWriterU16: write failed");
+                    w += (size_t)r;
+                }
+            }
+        });
     }
+    void wait_write() { if (mWrite.valid()) mWrite.get(); }
 
     void swap_row(const uint16_t *src, uint16_t *dst) const
     {
@@ -442,6 +483,8 @@ private:
     uint64_t mPos = 0;
     std::vector<uint64_t> mStripOff, mStripLen;
     std::vector<uint16_t> mPending;
+    std::future<void> mWrite;           // the batch of encoded strips being written
+    bool mPositioned = false;           // positioned writes have moved past the FILE's own position
 };
 
 // Reader for little-endian, chunky, unsigned 16-bit strip TIFF / BigTIFF, uncompressed or LZW (predictor 1 or
@@ -591,9 +634,7 @@ inline void write_tiff_u16(const std::string &path, const uint16_t *data, int wi
                            int compression = TIFF_NONE)
 {
     TiffWriterU16 w(path, width, height, spp, opencv_order, compression);
-    const long chunk = std::max<long>(1, (long)(((size_t)64 << 20) / ((size_t)width * spp * 2)));
-    for (long r = 0; r < height; r += chunk)
-        w.write_rows(data + (size_t)r * width * spp, height - r < chunk ? height - r : chunk);
+    w.write_rows(data, height);             // (batches its strips itself: 2 per encoder thread at a time)
     w.close();
 }
 

@@ -198,6 +198,16 @@ __device__ __forceinline__ void align_load_raw6(const uint16_t *__restrict__ pl,
     const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pl);
     const long e0 = row * Wb + c0;
     const long d0 = e0 >> 1;
+    if (row >= 0 && (row + 2) * Wb <= nelem) {
+        // every line but the last of the buffer (uniform over the wave: the line comes from the row table and the section base):
+        // the six dwords end inside the next line at the latest -- one 64-bit address and six immediate offsets instead of a
+        // 64-bit add, a compare and two selects per dword (what remap.hip's load_raw6 dropped in round 3: a quarter of that
+        // kernel's vector instructions)
+        const uint32_t *q = p32 + d0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = q[i];
+        return;
+    }
     const long dmax = (nelem - 1) >> 1;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {

@@ -497,6 +497,16 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
 }
 
 // RRC on load, both accumulate modes (the block comment "RRC on load" above the fp16 helpers describes the kernel)
+// IMO::InplaceRRC's pixel with or without the range test of the conversion (SAFE: the caller has proved |k s + b| < 2^31)
+template <bool SAFE> __device__ __forceinline__ unsigned rrc_px_t(double k, double b, unsigned s)
+{
+    if constexpr (!SAFE) return oip_rrc_px(k, b, s);
+    else {
+        const double v = __dadd_rn(__dmul_rn(k, (double)s), b);
+        return (unsigned)(int)v & 0xffffu;
+    }
+}
+
 template <bool F16>          // F16: the fp16-accumulate sums of remap_shift8_f16_kernel on the corrected samples
 __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                      const RowInfo *__restrict__ rows, int W, long out_rows,
@@ -510,8 +520,17 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
     const int cc = cbase + (int)threadIdx.x * 8;                     // the lane's chunk of source columns
     const bool chunk_ok = cc >= 0 && cc + 8 <= W;                    // W % 8 == 0: a chunk is inside the line or outside it
     double2 q[8];
+    bool in_range = true;                         // |k| 65535 + |b| < 2^31 for the lane's columns: k s + b converts without the range test
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
+    for (int j = 0; j < 8; ++j) {
+        q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
+        in_range = in_range && __dadd_rn(__dmul_rn(fabs(q[j].x), 65535.0), fabs(q[j].y)) < 2147483648.0;
+    }
+    // The double -> uint16_t cast of IMO::InplaceRRC (oip_rrc_px) tests both bounds before it converts: two fp64 compares and a
+    // select per sample, 24 of the ~430 vector instructions of a line in a kernel that is bound by them.  When every pair of
+    // the workgroup's columns keeps k s + b inside the int32 range for any 16-bit s -- every real LUT does -- the loop is
+    // instantiated without the test (same bits: the test could never fire); otherwise with it.
+    const bool safe_lut = __syncthreads_and(in_range) != 0;
     const int x0 = X0 + (int)threadIdx.x * 8;
     int c0 = 0, fx0 = 0;
     const bool active = (int)threadIdx.x < kLdsOut && x0 < W && x0 + 8 > dw.col0 && shift_group_regular(x0, W, dx, &c0, &fx0);
@@ -524,6 +543,8 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
+    auto body = [&](auto safe_tag) __attribute__((always_inline)) {
+    constexpr bool SAFE = decltype(safe_tag)::value;
     float win[F16 ? 1 : 4][11];                   // tap line t at unrolled step k lives in slot (k+t)&3
     oip_h2 E[F16 ? 4 : 1][6], O[F16 ? 4 : 1][5];
     typename std::conditional<F16, oip_h2, float>::type w2d[16];
@@ -534,10 +555,10 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
         return v;
     };
     auto stage = [&](uint4 v, int slot) __attribute__((always_inline)) {
-        v.x = oip_rrc_px(q[0].x, q[0].y, v.x & 0xffffu) | (oip_rrc_px(q[1].x, q[1].y, v.x >> 16) << 16);
-        v.y = oip_rrc_px(q[2].x, q[2].y, v.y & 0xffffu) | (oip_rrc_px(q[3].x, q[3].y, v.y >> 16) << 16);
-        v.z = oip_rrc_px(q[4].x, q[4].y, v.z & 0xffffu) | (oip_rrc_px(q[5].x, q[5].y, v.z >> 16) << 16);
-        v.w = oip_rrc_px(q[6].x, q[6].y, v.w & 0xffffu) | (oip_rrc_px(q[7].x, q[7].y, v.w >> 16) << 16);
+        v.x = rrc_px_t<SAFE>(q[0].x, q[0].y, v.x & 0xffffu) | (rrc_px_t<SAFE>(q[1].x, q[1].y, v.x >> 16) << 16);
+        v.y = rrc_px_t<SAFE>(q[2].x, q[2].y, v.y & 0xffffu) | (rrc_px_t<SAFE>(q[3].x, q[3].y, v.y >> 16) << 16);
+        v.z = rrc_px_t<SAFE>(q[4].x, q[4].y, v.z & 0xffffu) | (rrc_px_t<SAFE>(q[5].x, q[5].y, v.z >> 16) << 16);
+        v.w = rrc_px_t<SAFE>(q[6].x, q[6].y, v.w & 0xffffu) | (rrc_px_t<SAFE>(q[7].x, q[7].y, v.w >> 16) << 16);
         reinterpret_cast<uint4 *>(lds[p])[threadIdx.x] = v;
         __syncthreads();
         if (active) {
@@ -643,179 +664,10 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
             }
         }
     }
-}
-
-
-// ---- RRC on load, wave-local form (round 4) ------------------------------------------------------------------------
-// The LDS form above pays one workgroup barrier and an LDS round trip per source line, and PMC says its waves spend 42 % of
-// their cycles waiting on that chain.  A lane's 11 samples lie in its own corrected 16-byte chunk and in the chunks of the
-// next two lanes (c0 - chunk start = o is the same for every regular group of a call: the host puts the few groups whose
-// rounding of x + dx disagrees on the fix-up list), so the neighbours' dwords come over the lanes of the WAVE -- five
-// v_mov_b32_dpp wave_shl:1 (or ds_bpermute) per line instead of a store, a barrier and six loads -- and nothing couples the
-// four waves of a workgroup any more: no LDS, no barrier.  A wave fetches and corrects 64 chunks and resamples the 62
-// groups whose taps it holds (lanes 62 and 63 only supply taps: 3 % of the loads and corrections are done twice).
-// D0 = o >> 1: first dword of the window inside the lane's chunk; the parity of o selects the half-word phase (expand_*).
-constexpr int kWaveOut = 62;
-
-template <bool DPP> __device__ __forceinline__ uint32_t next_lane(uint32_t v)
-{
-    if constexpr (DPP) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-    else return (uint32_t)__shfl_down((int)v, 1, 64);
-}
-
-template <bool F16, int D0, bool DPP, int OCC>
-__global__ __launch_bounds__(kBlock, OCC) void remap_shift8_rrcw_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
-                                                                      const RowInfo *__restrict__ rows, int W, long out_rows,
-                                                                      long src_elems, double dx, const float *__restrict__ tab1d,
-                                                                      int rows_per_block, const double2 *__restrict__ kb, int ixw8, int ixk)
-{
-    const int lane = threadIdx.x & 63;
-    const int X0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * kWaveOut * 8;      // first output column of the wave
-    if (X0 >= W || X0 + kWaveOut * 8 <= dw.col0) return;              // nothing of this wave is stored (uniform over the wave)
-    const int x0 = X0 + lane * 8;
-    const int cc = x0 + ixw8;                                        // the lane's chunk of source columns (a multiple of 8)
-    const bool chunk_ok = cc >= 0 && cc + 8 <= W;
-    double2 q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = chunk_ok ? kb[cc + j] : make_double2(0.0, 0.0);
-    int c0 = 0, fx0 = 0;
-    const bool active = lane < kWaveOut && x0 < W && x0 + 8 > dw.col0 && shift_group_regular(x0, W, dx, &c0, &fx0) && c0 == x0 + ixk;
-    const long r0 = (long)blockIdx.y * rows_per_block;
-    long r1 = r0 + rows_per_block;
-    if (r1 > out_rows) r1 = out_rows;
-    const long src_lines = src_elems / W;
-    float wx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
-
-    float win[F16 ? 1 : 4][11];                   // tap line t at unrolled step k lives in slot (k+t)&3
-    oip_h2 E[F16 ? 4 : 1][6], O[F16 ? 4 : 1][5];
-    typename std::conditional<F16, oip_h2, float>::type w2d[16];
-    auto fetch = [&](long row) __attribute__((always_inline)) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (chunk_ok && row >= 0 && row < src_lines) v = *reinterpret_cast<const uint4 *>(src + row * W + cc);
-        return v;
     };
-    // every lane of the wave takes part (the neighbour exchange reads all lanes); only the sums and the store are per lane
-    auto stage = [&](uint4 v, int slot) __attribute__((always_inline)) {
-        uint32_t D[9];
-        D[0] = oip_rrc_px(q[0].x, q[0].y, v.x & 0xffffu) | (oip_rrc_px(q[1].x, q[1].y, v.x >> 16) << 16);
-        D[1] = oip_rrc_px(q[2].x, q[2].y, v.y & 0xffffu) | (oip_rrc_px(q[3].x, q[3].y, v.y >> 16) << 16);
-        D[2] = oip_rrc_px(q[4].x, q[4].y, v.z & 0xffffu) | (oip_rrc_px(q[5].x, q[5].y, v.z >> 16) << 16);
-        D[3] = oip_rrc_px(q[6].x, q[6].y, v.w & 0xffffu) | (oip_rrc_px(q[7].x, q[7].y, v.w >> 16) << 16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) D[4 + i] = (D0 + 5 >= 4 + i) ? next_lane<DPP>(D[i]) : 0u;
-        D[8] = D0 + 5 >= 8 ? next_lane<DPP>(D[4]) : 0u;
-        uint32_t w[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = D[D0 + i];
-        if constexpr (F16) expand_h(w, ixk, E[slot], O[slot]);       // (only the parity of c0 = x0 + ixk is used, x0 is even)
-        else expand_f32(w, ixk, win[slot]);
-    };
-    int cur_fy = -1;
-    long r = r0;
-    while (r < r1) {
-        const RowInfo h = rows[r];
-        if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
-        long qline = h.src[3];
-        uint4 qa, qb;
-        {
-            const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
-            qa = fetch(qline);
-            qb = fetch(qline + 1);
-            stage(f0, 0);
-            stage(f1, 1);
-            stage(f2, 2);
-        }
-        int cur1 = h.src[0], cur2 = h.src[1], cur3 = h.src[2];
-        bool run = true;
-        while (run) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (r >= r1) { run = false; break; }
-                const RowInfo ri = rows[r];
-                if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
-                stage(qa, (k + 3) & 3);
-                qa = qb;
-                qline += 1;
-                qb = fetch(qline + 1);
-                cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
-                const long rr_ = r;
-                ++r;
-                if (!active) continue;
-                if (ri.fy != cur_fy) {
-                    cur_fy = ri.fy;
-#pragma unroll
-                    for (int ky = 0; ky < 4; ++ky) {
-                        const float wy = tab1d[cur_fy * 4 + ky];
-#pragma unroll
-                        for (int kx = 0; kx < 4; ++kx) {
-                            if constexpr (F16) {
-                                const _Float16 hh = (_Float16)__fmul_rn(wy, wx[kx]);
-                                w2d[ky * 4 + kx] = oip_h2{hh, hh};
-                            } else {
-                                w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
-                            }
-                        }
-                    }
-                }
-                unsigned out[8];
-                if constexpr (F16) {
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
-                        oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
-                            acc = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc);
-                            acc = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc);
-                            acc = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc);
-                            acc = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc);
-                        }
-                        out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
-                        out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float *L = win[(k + t) & 3];
-                            float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
-                            sum = t == 0 ? rr : __fadd_rn(sum, rr);
-                        }
-                        out[j] = oip_sat_u16(sum);
-                    }
-                }
-                uint4 o;
-                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
-                uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
-                if (x0 >= dw.col0 && dw.vec) {
-                    *reinterpret_cast<uint4 *>(drow) = o;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
-                }
-            }
-        }
-    }
+    if (safe_lut) body(std::true_type{}); else body(std::false_type{});
 }
 
-typedef void (*RrcWaveKernel)(const uint16_t *, uint16_t *, DstWin, const RowInfo *, int, long, long, double, const float *, int, const double2 *, int, int);
-template <bool F16, bool DPP, int OCC> static RrcWaveKernel rrcw_kernel(int d0)
-{
-    switch (d0) {
-        case 0: return remap_shift8_rrcw_kernel<F16, 0, DPP, OCC>;
-        case 1: return remap_shift8_rrcw_kernel<F16, 1, DPP, OCC>;
-        case 2: return remap_shift8_rrcw_kernel<F16, 2, DPP, OCC>;
-        default: return remap_shift8_rrcw_kernel<F16, 3, DPP, OCC>;
-    }
-}
 
 // fix-up A: irregular 8-column groups, all lines.  blockIdx.x = index into `groups`; the 256
 // lanes are 8 columns x 32 line sub-ranges.
@@ -949,36 +801,13 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
     if (kb && !lds) v8 = false;
     const long fl = (long)floor(dx);
     const int ixmin8 = (int)(8 * ((fl - 2 >= 0 ? fl - 2 : fl - 2 - 7) / 8));
-    // RRC on load comes in two forms (OIP_REMAP_RRC_FORM): "wave" (default) exchanges the neighbours' samples over the lanes of
-    // the wave -- it needs the offset c0 - x0 of the tap window to be ONE value for the call's regular groups; the few groups
-    // whose rounding of x + dx gives another go to the fix-up list -- "lds" stages every line through the workgroup's LDS.
-    int wave_form = 0;                                // 0: LDS form, 1: wave form with DPP, 2: wave form with ds_bpermute
-    if (lds) {
-        const char *e = getenv("OIP_REMAP_RRC_FORM");
-        wave_form = e && !strcmp(e, "lds") ? 0 : (e && !strcmp(e, "bpermute") ? 2 : 1);
-    }
-    int ixk = 0, ixw8 = 0;
-    if (wave_form) {
-        int votes[3] = {0, 0, 0};                     // c0 - x0 is floor(dx) - 1 up to the rounding of (float)(x + dx)
-        for (int gidx = 0; gidx < W / 8; ++gidx) {
-            int a0, f0;
-            if (!shift_group_regular(gidx * 8, W, dx, &a0, &f0)) continue;
-            const long d = (long)a0 - gidx * 8 - (fl - 2);
-            if (d >= 0 && d < 3) ++votes[d];
-        }
-        const int best = votes[1] >= votes[0] && votes[1] >= votes[2] ? 1 : (votes[0] >= votes[2] ? 0 : 2);
-        ixk = (int)(fl - 2) + best;
-        ixw8 = 8 * (ixk >= 0 ? ixk / 8 : -((-ixk + 7) / 8));
-    }
     // irregular 8-column groups (host arithmetic identical to the kernel's)
     std::vector<int> bad_groups;
     if (v8)
         for (int gidx = 0; gidx < W / 8; ++gidx) {
             int a0, f0;
             if (!shift_group_regular(gidx * 8, W, dx, &a0, &f0)) { bad_groups.push_back(gidx); continue; }
-            if (wave_form) {
-                if (a0 != gidx * 8 + ixk) bad_groups.push_back(gidx);      // (the kernel skips it by the same test)
-            } else if (lds) {                         // the taps of a regular group lie inside its block's 2048 staged columns
+            if (lds) {                                // the taps of a regular group lie inside its block's 2048 staged columns
                 const int li = a0 - (gidx / kLdsOut * kLdsOut * 8 + ixmin8);
                 if (li < 0 || li + 10 >= kBlock * 8) return oip_fail(ctx, OIP_E_RUNTIME, "remap: staged columns do not cover group %d", gidx);
             }
@@ -1008,7 +837,6 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_bicubic_u16: too many section-border lines");
     if (v8) {
         int gx = lds ? (W / 8 + kLdsOut - 1) / kLdsOut : (W / 8 + kBlock - 1) / kBlock;
-        if (wave_form) gx = (W / 8 + (kBlock / 64) * kWaveOut - 1) / ((kBlock / 64) * kWaveOut);
         long want = (long)ctx->cu_count * (lds ? 12 : 16) / gx;      // 12..96 (RRC form), 16..48 (plain): the step takes the same time
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
@@ -1018,18 +846,7 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         if (gy > 65535) { gy = 65535; rpb = ((out_rows + gy - 1) / gy + 3) / 4 * 4; gy = (out_rows + rpb - 1) / rpb; }
         {
             OipProfScope prof(ctx, lds ? (f16acc ? "remap_shift8_rrc_f16_kernel" : "remap_shift8_rrc_kernel") : (f16acc ? "remap_shift8_f16_kernel" : "remap_shift8_kernel"));
-            if (wave_form) {
-                const int d0 = (ixk - ixw8) >> 1;
-                const char *eo = getenv("OIP_REMAP_RRC_OCC");            // experiment switch: 4 waves per SIMD (a few spilled registers)
-                const bool occ4 = eo && atoi(eo) == 4;
-                RrcWaveKernel k;
-                if (occ4) k = f16acc ? (wave_form == 1 ? rrcw_kernel<true, true, 4>(d0) : rrcw_kernel<true, false, 4>(d0))
-                                     : (wave_form == 1 ? rrcw_kernel<false, true, 4>(d0) : rrcw_kernel<false, false, 4>(d0));
-                else k = f16acc ? (wave_form == 1 ? rrcw_kernel<true, true, 3>(d0) : rrcw_kernel<true, false, 3>(d0))
-                                : (wave_form == 1 ? rrcw_kernel<false, true, 3>(d0) : rrcw_kernel<false, false, 3>(d0));
-                hipLaunchKernelGGL(k, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
-                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixw8, ixk);
-            } else if (lds && f16acc)
+            if (lds && f16acc)
                 hipLaunchKernelGGL(remap_shift8_rrc_kernel<true>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
                                    out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
             else if (f16acc)

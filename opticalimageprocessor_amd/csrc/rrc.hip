@@ -204,6 +204,71 @@ __global__ __launch_bounds__(kBlock) void mss_split_rrc_kernel(const uint16_t *_
     }
 }
 
+// The same split walked FLAT over the destination planes (round 4): a band plane is a contiguous bw x lines raster whose
+// 15000-byte lines (bw = 7500) are not multiples of 16, so the line-owned kernel above can only store 8 bytes per lane and
+// its waves write half-filled cache-line sectors.  Here a plane is an array of 4-pixel UNITS (bw % 4 == 0: a unit never
+// straddles a line); a lane owns a 16-byte CHUNK = two units of the plane's 1 KiB-aligned frame (a = units between the frame
+// and the plane's first pixel), a wave stores one aligned KiB, and a lane advances by sr chunks with 2 sr a multiple of the
+// units per line, so its 8 columns -- its LUT registers -- never change.  The two units of a chunk may lie on consecutive
+// BIL lines: two 8-byte loads.  blockIdx.z = band.
+template <bool RRC>
+__global__ __launch_bounds__(kBlock) void mss_split_flat_kernel(const uint16_t *__restrict__ bil, uint16_t *__restrict__ planes,
+                                                                size_t plane_stride, int w, int upl, long lines, const double2 *__restrict__ kb,
+                                                                long sr, long nsuper, long super_per_block)
+{
+    const int band = blockIdx.z;
+    const long g0 = (long)blockIdx.x * kBlock + threadIdx.x;
+    if (g0 >= sr) return;
+    uint16_t *plane = planes + (size_t)band * plane_stride;
+    const long a = (long)(((uintptr_t)plane & 1023) >> 3);          // units
+    const long U = (long)upl * lines;                                 // units of the plane
+    uint2 *frame = reinterpret_cast<uint2 *>(plane) - a;             // unit g of the frame is unit g - a of the plane
+    // the columns of the lane's two units (fixed: 2 sr is a multiple of upl)
+    long u0 = 2 * g0 - a;
+    int c0 = (int)(((u0 % upl) + upl) % upl), c1 = c0 + 1 == upl ? 0 : c0 + 1;
+    double k[8], b[8];
+    if (RRC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double2 p0 = kb[band * (upl * 4) + c0 * 4 + i], p1 = kb[band * (upl * 4) + c1 * 4 + i];
+            k[i] = p0.x; b[i] = p0.y; k[4 + i] = p1.x; b[4 + i] = p1.y;
+        }
+    }
+    const long s0 = (long)blockIdx.y * super_per_block;
+    long s1 = s0 + super_per_block;
+    if (s1 > nsuper) s1 = nsuper;
+    const long lines_per_step = 2 * sr / upl;
+    // unit u of the plane = BIL line u / upl, columns band * bw + 4 (u % upl)
+    long u = u0 + 2 * s0 * sr;
+    long r0 = (u - c0) / upl;                                        // line of unit u (exact: u - c0 is a multiple of upl, also below 0)
+    const int wrap = c1 == 0 ? 1 : 0;                                // the second unit starts the next line
+    const uint2 *src0 = reinterpret_cast<const uint2 *>(bil + (long)band * upl * 4 + c0 * 4), *src1 = reinterpret_cast<const uint2 *>(bil + (long)band * upl * 4 + c1 * 4);
+    const long wq = w / 4;                                           // BIL line pitch in units
+    for (long q = s0; q < s1; q += kRowsInFlight) {
+        uint2 v0[kRowsInFlight], v1[kRowsInFlight];
+        bool ok0[kRowsInFlight], ok1[kRowsInFlight];
+#pragma unroll
+        for (int t = 0; t < kRowsInFlight; ++t) {
+            const long ut = u + 2 * t * sr, rt = r0 + t * lines_per_step;
+            ok0[t] = q + t < s1 && ut >= 0 && ut < U;
+            ok1[t] = q + t < s1 && ut + 1 >= 0 && ut + 1 < U;
+            if (ok0[t]) v0[t] = src0[rt * wq];
+            if (ok1[t]) v1[t] = src1[(rt + wrap) * wq];
+        }
+#pragma unroll
+        for (int t = 0; t < kRowsInFlight; ++t) {
+            const long gt = 2 * (g0 + (q + t) * sr);
+            uint4 o = make_uint4(v0[t].x, v0[t].y, v1[t].x, v1[t].y);
+            if (RRC) o = rrc_vec<8>(o, k, b);
+            if (ok0[t] && ok1[t]) *reinterpret_cast<uint4 *>(frame + gt) = o;
+            else if (ok0[t]) frame[gt] = make_uint2(o.x, o.y);
+            else if (ok1[t]) frame[gt + 1] = make_uint2(o.z, o.w);
+        }
+        u += 2 * kRowsInFlight * sr;
+        r0 += kRowsInFlight * lines_per_step;
+    }
+}
+
 template <bool RRC>
 __global__ __launch_bounds__(kBlock) void mss_split_rrc_scalar_kernel(const uint16_t *__restrict__ bil,
                                                                       uint16_t *__restrict__ planes,
@@ -410,7 +475,30 @@ extern "C" int oip_mss_split_rrc_u16(oip_ctx *ctx, const uint16_t *d_bil, uint16
     const double2 *kb = reinterpret_cast<const double2 *>(d_kb4);
     const bool fast = (w % 8 == 0) && (bw % 4 == 0) && (w == bw * 4) && (((uintptr_t)d_bil & 15) == 0) &&
                       (((uintptr_t)d_planes & 7) == 0) && (plane_stride % 4 == 0);
-    if (fast) {
+    // the flat form (16-byte stores, aligned KiB per wave) wherever its index arithmetic holds; OIP_MSS_SPLIT_FLAT=0: the line-owned kernel
+    const char *ef = getenv("OIP_MSS_SPLIT_FLAT");
+    const int upl = bw / 4;
+    long sr = 0;
+    if (fast && !(ef && atoi(ef) == 0)) {
+        long g = upl % 2 == 0 ? upl / 2 : upl, t = 64, base = g;
+        while (t) { long r = g % t; g = t; t = r; }
+        sr = base / g * 64;                                          // lcm(upl / gcd(upl, 2), 64): 2 sr units = whole lines
+        if (sr > (1L << 22)) sr = 0;                                 // absurd widths: the line-owned kernel
+    }
+    if (fast && sr > 0) {
+        const long U = (long)upl * lines;
+        const long nsuper = (U + 127 + 2 * sr - 1) / (2 * sr) + 1;   // chunks g = g0 + q sr cover units up to U + a (a < 128)
+        long spb = 16;
+        long gy = (nsuper + spb - 1) / spb;
+        if (gy > 65535) { gy = 65535; spb = (nsuper + gy - 1) / gy; spb = (spb + kRowsInFlight - 1) / kRowsInFlight * kRowsInFlight; gy = (nsuper + spb - 1) / spb; }
+        const long gx = (sr + kBlock - 1) / kBlock;
+        if (kb)
+            hipLaunchKernelGGL(mss_split_flat_kernel<true>, dim3((unsigned)gx, (unsigned)gy, OIP_MSS_BANDS), dim3(kBlock), 0, ctx->stream, d_bil, d_planes,
+                               plane_stride, w, upl, lines, kb, sr, nsuper, spb);
+        else
+            hipLaunchKernelGGL(mss_split_flat_kernel<false>, dim3((unsigned)gx, (unsigned)gy, OIP_MSS_BANDS), dim3(kBlock), 0, ctx->stream, d_bil, d_planes,
+                               plane_stride, w, upl, lines, kb, sr, nsuper, spb);
+    } else if (fast) {
         int gx = (w / 8 + kBlock - 1) / kBlock, gy;
         long rpb;
         row_blocks(ctx, gx, lines, &rpb, &gy);

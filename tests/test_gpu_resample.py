@@ -259,6 +259,36 @@ def test_remap_window_equals_remap_then_stitch(ctx, W, fold, dx, dy, f16):
     assert torch.equal(part.view(torch.int16), want[o0:o0 + n].view(torch.int16))
 
 
+def test_remap_rrc_on_load_with_a_lut_that_leaves_the_int32_range(ctx):
+    """remap_shift8_rrc_kernel drops the range test of IMO::InplaceRRC's double -> uint16_t cast when every (k, b) pair of a
+    workgroup's columns keeps k s + b inside int32 (round 4).  Here some columns do not: k = 40000 (k s wraps past 2^31 for
+    s > 53687: the x86 conversion gives 0x80000000 -> low half 0), a NaN gain, a hugely negative bias -- in one workgroup's
+    columns only, so that the launch runs BOTH instantiations of the loop.  Reference: oip_rrc_u16 (bit-exact against the
+    reference's own loop, tests/golden) followed by the plain window call."""
+    import torch
+    W, L, fold, dx, dy = 4096, 33000, 64, 2.37, -1.4
+    rng = _rng(91)
+    kb = np.stack([1.0 + rng.integers(-3, 4, W) / 64.0, rng.integers(-8, 9, W) / 4.0], 1)
+    kb[2100, 0] = 40000.0
+    kb[2101, 0] = np.nan
+    kb[2102, 1] = -3.0e9
+    kb[2103] = (-70000.0, 5.0)
+    d_kb = ctx.upload_kb(kb)
+    raw = _cuda(rng.integers(0, 65536, (L, W), dtype=np.uint16))
+    corrected = torch.empty_like(raw)
+    ctx.rrc_u16(raw, corrected, W, L, d_kb)
+    P = 2 * (W - fold)
+    for f16 in (False, True):
+        want = torch.zeros(L, P, dtype=torch.uint16, device="cuda")
+        ctx.remap_shift_bicubic_u16_window(corrected, want, P, fold, W - fold, W, L, dx, dy, f16acc=f16)
+        got = torch.zeros_like(want)
+        ctx.remap_shift_rrc_bicubic_u16_window(raw, d_kb, got, P, fold, W - fold, W, L, dx, dy, f16acc=f16)
+        ctx.sync()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), f16
+    c = corrected.cpu().numpy()
+    assert (c[:, 2101] == 0).all() and (c[:, 2100] == 0).any() and (c[:, 2100] != 0).any()      # NaN -> 0; the wrap does occur
+
+
 def test_remap_rrc_on_load_with_a_misaligned_source(ctx):
     """oip_remap_shift_rrc_bicubic_u16_window stages 16-byte chunks of the raw lines through LDS; a source that is only 4-byte
     aligned takes the general kernel (which corrects on load as well) in fp32 -- same bits -- and is refused in the

@@ -504,6 +504,10 @@ def cli_default_action(env, d, kb_mss, threshold):
             args += ["--rrc-msb%d" % (b + 1), "MSS.B%d.csv" % (b + 1)]
         runs = {}
         same = None
+        # what a process pays before and after its work: `oip --version` (exec, dynamic linking, static initialisers, exit -- no GPU)
+        t1 = time.perf_counter()
+        subprocess.run([exe, "--version"], cwd=tmp, capture_output=True)
+        startup_ms = (time.perf_counter() - t1) * 1e3
         plan = [("raw", {"OIP_TIFF_COMPRESS": "none"}, []), ("raw_again", {"OIP_TIFF_COMPRESS": "none"}, []),
                 ("raw_rrcpan", {"OIP_TIFF_COMPRESS": "none"}, ["--write-rrcpan"]), ("lzw", {}, []),
                 ("steps_raw", {"OIP_TIFF_COMPRESS": "none", "OIP_PIPELINE": "0"}, [])]
@@ -538,7 +542,7 @@ def cli_default_action(env, d, kb_mss, threshold):
                 del got
             runs[name] = rec
         best = min((runs[k] for k in ("raw", "raw_again") if runs[k]["exit"] == 0), key=lambda r_: r_["wall_ms"], default=None)
-        out = {"runs": runs, "aligned_product_equals_resident_step": same, "inputs_written_s": t_inputs, "tmp": base,
+        out = {"runs": runs, "version_only_ms": startup_ms, "aligned_product_equals_resident_step": same, "inputs_written_s": t_inputs, "tmp": base,
                "bytes_in": int((pb + mb) * W * 2), "what": ("wall time of the `oip` executable (process start, HIP initialisation, file reads, "
                "kernels, product writes) on %dx%d PAN + MSS files in tmpfs; log_seconds = the log's TIMING line, seconds since the action "
                "started (products_written: everything on disk)" % (W, pb))}

@@ -175,12 +175,56 @@ constexpr int kTicketRing = 64;
 
 }  // namespace
 
+// ---- pinned slots ---------------------------------------------------------------------------------------------------
+// hipHostMalloc pins 4 KiB pages one by one: 48-60 ms for the ring's 128 MiB on the GPU box (OIP_STAGE_TRACE), all of it in
+// front of the first byte a fresh process moves.  An anonymous mapping backed by transparent huge pages
+// (/sys/kernel/mm/transparent_hugepage/enabled = madvise on the box) registered with hipHostRegister pins 2 MiB pages
+// instead.  OIP_STAGE_PIN=malloc keeps hipHostMalloc; any failure of the huge-page route falls back to it as well.
+struct PinnedSlot {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void *map = nullptr;            // non-null: our own mapping, registered (else hipHostMalloc)
+    size_t map_bytes = 0;
+};
+static bool pinned_alloc(PinnedSlot *s, size_t bytes)
+{
+    const char *e = getenv("OIP_STAGE_PIN");
+    if (!(e && !strcmp(e, "malloc"))) {
+        const size_t huge = (size_t)2 << 20;
+        const size_t len = bytes + huge;
+        void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            char *al = (char *)(((uintptr_t)m + huge - 1) & ~(uintptr_t)(huge - 1));
+            madvise(al, bytes, MADV_HUGEPAGE);
+            for (size_t o = 0; o < bytes; o += 4096) al[o] = 0;                 // fault it in (a huge page per first touch)
+            if (hipHostRegister(al, bytes, hipHostRegisterDefault) == hipSuccess) {
+                s->p = al; s->bytes = bytes; s->map = m; s->map_bytes = len;
+                return true;
+            }
+            (void)hipGetLastError();
+            munmap(m, len);
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return false;
+    s->p = p; s->bytes = bytes; s->map = nullptr; s->map_bytes = 0;
+    return true;
+}
+static void pinned_free(PinnedSlot *s)
+{
+    if (!s->p) return;
+    if (s->map) { hipHostUnregister(s->p); munmap(s->map, s->map_bytes); }
+    else hipHostFree(s->p);
+    s->p = nullptr;
+}
+
 // the staging state lives behind the context (opaque to the other translation units)
 struct oip_stage_state {
     hipStream_t stream = nullptr;
     hipStream_t rrc_stream = nullptr;       // second stream of oip_rrc_u16_host (up and down transfers of neighbouring blocks overlap)
     std::mutex ring_mu;                     // one caller per lane at a time
     void *slot[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+    PinnedSlot slot_mem[kSlots];
     hipEvent_t slot_free[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // recorded after the DMA that last used the slot
     bool slot_used[kSlots] = {false, false, false, false};
     int next = 0;
@@ -193,6 +237,7 @@ struct oip_stage_state {
         std::mutex mu;
         hipStream_t stream = nullptr;
         void *slot[2] = {nullptr, nullptr};
+        PinnedSlot slot_mem[2];
         hipEvent_t slot_free[2] = {nullptr, nullptr};
         bool slot_used[2] = {false, false};
         int next = 0;
@@ -226,11 +271,12 @@ static int stage_init(oip_ctx *ctx)
         hipStreamCreateWithFlags(&s->down[1].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->rrc_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
     for (int i = 0; i < kSlots; ++i) {
-        if (hipHostMalloc(&s->slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess ||
+        if (!pinned_alloc(&s->slot_mem[i], kSlotBytes) ||
             hipEventCreateWithFlags(&s->slot_free[i], hipEventDisableTiming) != hipSuccess) {
             delete s;
             return oip_fail(ctx, OIP_E_NOMEM, "pinned staging ring (%d x %zu MiB) failed", kSlots, kSlotBytes >> 20);
         }
+        s->slot[i] = s->slot_mem[i].p;
     }
     for (int i = 0; i < kTicketRing; ++i)
         if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess ||
@@ -245,8 +291,9 @@ static int stage_init(oip_ctx *ctx)
             if (hipEventCreateWithFlags(&d.slot_free[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
     ctx->stage = s;
     if (getenv("OIP_STAGE_TRACE"))
-        fprintf(stderr, "oip staging: ring of %d x %zu MiB pinned in %.1f ms\n", kSlots, kSlotBytes >> 20,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count());
+        fprintf(stderr, "oip staging: ring of %d x %zu MiB pinned in %.1f ms (%s)\n", kSlots, kSlotBytes >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init).count(),
+                s->slot_mem[0].map ? "huge pages, hipHostRegister" : "hipHostMalloc");
     return OIP_OK;
 }
 
@@ -254,8 +301,10 @@ static int stage_init(oip_ctx *ctx)
 static int down_lane_ready(oip_ctx *ctx, oip_stage_state::DownLane &d)
 {
     for (int i = 0; i < 2; ++i)
-        if (!d.slot[i] && hipHostMalloc(&d.slot[i], kSlotBytes, hipHostMallocDefault) != hipSuccess)
-            return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
+        if (!d.slot[i]) {
+            if (!pinned_alloc(&d.slot_mem[i], kSlotBytes)) return oip_fail(ctx, OIP_E_NOMEM, "pinned download slots failed");
+            d.slot[i] = d.slot_mem[i].p;
+        }
     return OIP_OK;
 }
 
@@ -266,12 +315,12 @@ void oip_stage_destroy(oip_ctx *ctx)
     if (s->stream) hipStreamSynchronize(s->stream);
     for (auto &d : s->down) if (d.stream) { hipStreamSynchronize(d.stream); hipStreamDestroy(d.stream); }
     if (s->rrc_stream) { hipStreamSynchronize(s->rrc_stream); hipStreamDestroy(s->rrc_stream); }
-    for (int i = 0; i < kSlots; ++i) { if (s->slot[i]) hipHostFree(s->slot[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
+    for (int i = 0; i < kSlots; ++i) { pinned_free(&s->slot_mem[i]); if (s->slot_free[i]) hipEventDestroy(s->slot_free[i]); }
     for (int i = 0; i < kTicketRing; ++i) { hipEventDestroy(s->ticket_ev[i]); hipEventDestroy(s->mark_ev[i]); }
     if (s->compute_ev) hipEventDestroy(s->compute_ev);
     for (auto &d : s->down) {
         if (d.compute_ev) hipEventDestroy(d.compute_ev);
-        for (int i = 0; i < 2; ++i) { if (d.slot[i]) hipHostFree(d.slot[i]); if (d.slot_free[i]) hipEventDestroy(d.slot_free[i]); }
+        for (int i = 0; i < 2; ++i) { pinned_free(&d.slot_mem[i]); if (d.slot_free[i]) hipEventDestroy(d.slot_free[i]); }
     }
     if (s->d_kb) hipFree(s->d_kb);
     if (s->stream) hipStreamDestroy(s->stream);

@@ -133,6 +133,16 @@ int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, cons
  * written block by block as its lines become final -- <pan>.RRC.RAW while the strip is still being read, the pixel payload
  * of an uncompressed TIFF (oip_tiff.hpp) behind its header.  mark: 0, or a mark of the compute stream to wait for. */
 int oip_write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, size_t file_offset, long mark);
+/* A product file PREPARED ahead of its pixels: created, its blocks reserved (a full file system fails at open, cleanly) and
+ * mapped with its pages populated -- by a thread that has time for it, e.g. while the strip is still being read -- so that
+ * the later write is HBM -> pinned slot -> parallel memory copies into pages that exist (on page-cache-backed files several
+ * times the rate of allocating them during the write, which is what bounds WriteBufferToFile's loop, imageop.h:84-97).
+ * The file is not truncated: a header written before stays.  bytes: the final size of the file.  A sink whose reservation or
+ * mapping failed (or OIP_FILE_WRITE=pwrite) writes through pwrite.  mark as oip_write_device_to_file_at. */
+typedef struct oip_file_sink oip_file_sink;
+int oip_file_sink_open(oip_ctx *ctx, const char *path, size_t bytes, oip_file_sink **out);
+int oip_file_sink_write(oip_ctx *ctx, oip_file_sink *sink, size_t file_offset, const void *d_src, size_t bytes, long mark);
+int oip_file_sink_close(oip_ctx *ctx, oip_file_sink *sink);
 /* A MARK names the compute-stream work enqueued so far (an event from a ring of 64; taken by the compute thread, e.g. right
  * after the RRC kernel of a line block).  A download-lane transfer given the mark starts once that work is done, not after
  * what the compute thread enqueued later (a 12-ms correlation batch, say).  A mark that has left the ring means "everything

@@ -65,6 +65,9 @@ _SIGS = {
     "oip_read_file_to_device": ([_vp, _cp, _sz, _sz, _vp, C.POINTER(_sz), _lp], _i),
     "oip_write_device_to_file": ([_vp, _vp, _sz, _cp, _i], _i),
     "oip_write_device_to_file_at": ([_vp, _vp, _sz, _cp, _sz, _l], _i),
+    "oip_file_sink_open": ([_vp, _cp, _sz, C.POINTER(_vp)], _i),
+    "oip_file_sink_write": ([_vp, _vp, _sz, _vp, _sz, _l], _i),
+    "oip_file_sink_close": ([_vp, _vp], _i),
     "oip_compute_mark": ([_vp, _lp], _i),
     "oip_compute_mark_sync": ([_vp, _l], _i),
     "oip_download_staged_after": ([_vp, _vp, _vp, _sz, _l], _i),
@@ -307,6 +310,17 @@ class Context:
 
     def write_device_to_file_at(self, d_src, nbytes, path, file_offset, mark=0, byte_offset=0):
         self._ck(self.lib.oip_write_device_to_file_at(self.h, _ptr(d_src) + byte_offset, nbytes, os.fsencode(path), file_offset, mark))
+
+    def file_sink_open(self, path, nbytes):
+        h = C.c_void_p()
+        self._ck(self.lib.oip_file_sink_open(self.h, os.fsencode(path), nbytes, C.byref(h)))
+        return h
+
+    def file_sink_write(self, sink, file_offset, d_src, nbytes, mark=0, byte_offset=0):
+        self._ck(self.lib.oip_file_sink_write(self.h, sink, file_offset, _ptr(d_src) + byte_offset, nbytes, mark))
+
+    def file_sink_close(self, sink):
+        self._ck(self.lib.oip_file_sink_close(self.h, sink))
 
     def compute_mark(self):
         m = C.c_long()

@@ -919,14 +919,31 @@ public:
         struct ProductGuard {
             std::string path;
             bool done = false;
-            ~ProductGuard() { if (!done && !path.empty()) ::remove(path.c_str()); }
+            oip_file_sink *sink = nullptr;         // the product's prepared file (uncompressed products)
+            uint64_t payloadAt = 0;
+            ~ProductGuard()
+            {
+                if (sink) oip_file_sink_close(nullptr, sink);
+                if (!done && !path.empty()) ::remove(path.c_str());
+            }
         } productGuard;
         const std::string alignedPath = IMO::BuildOutputFilePath(mMssFile, ".ALIGNED", ".TIFF");
         const int comp = tiff_compression(TIFF_LZW);
         std::unique_ptr<TiffWriterU16> tiff(new TiffWriterU16(alignedPath, Wb, outRows, MSS_BANDS, false, comp));   // (declared before the writers: their jobs use it)
         productGuard.path = alignedPath;
         JobThread panWriter, productWriter;
-        if (comp == TIFF_NONE) { TiffWriterU16 *twp = tiff.get(); productWriter.post([twp] { twp->preallocate(); }); }
+        const size_t productBytes = (size_t)outRows * Wb * MSS_BANDS * 2;
+        if (comp == TIFF_NONE) {
+            // the writer thread has nothing to do until the fit is in: it prepares the product file -- header out, blocks
+            // reserved, pages mapped and populated (oip_file_sink_open) -- so that the pixels, when they exist, are copied
+            // into pages that exist (the allocation is what bounds a buffered write of a new file)
+            TiffWriterU16 *twp = tiff.get();
+            ProductGuard *pg = &productGuard;
+            productWriter.post([=] {
+                pg->payloadAt = twp->begin_external_payload();
+                Device::get().check(oip_file_sink_open(ctx, alignedPath.c_str(), (size_t)pg->payloadAt + productBytes, &pg->sink));
+            });
+        }
         struct Joiner {                                    // whatever happens below, the threads are stopped and joined
             std::thread &reader; std::atomic<bool> &cancel;
             ~Joiner() { cancel = true; if (reader.joinable()) reader.join(); }
@@ -1039,6 +1056,7 @@ public:
                 long mark = 0;
                 ck(oip_compute_mark(ctx, &mark));
                 TiffWriterU16 *tw = tiff.get();
+                ProductGuard *pg = &productGuard;
                 const uint16_t *img = out.p;
                 const size_t rowSamples = (size_t)Wb * MSS_BANDS;
                 const long rows = outRows;
@@ -1048,8 +1066,10 @@ public:
                     OLOG("Alignment done in %.3f seconds (%ld lines valid of %ld).", tAlignDone, processed, rows);
                     OLOG("Outputing aligned TIFF image (%d x %ld x 4) to [%s] ...", Wb, rows, alignedPath.c_str());
                     if (comp == TIFF_NONE) {
-                        const uint64_t at = tw->begin_external_payload();
-                        Device::get().check(oip_write_device_to_file_at(ctx, img, (size_t)rows * rowSamples * 2, alignedPath.c_str(), (size_t)at, mark));
+                        Device::get().check(oip_file_sink_write(ctx, pg->sink, (size_t)pg->payloadAt, img, (size_t)rows * rowSamples * 2, mark));
+                        oip_file_sink *k = pg->sink;
+                        pg->sink = nullptr;
+                        Device::get().check(oip_file_sink_close(ctx, k));
                         tw->end_external_payload();
                     } else {
                         // strips are encoded as their lines come down: 256 MiB of lines per round
@@ -1075,12 +1095,14 @@ public:
         OLOG("RRC done for MSS bands in %.4f seconds (%.1f MBps).", tComputeDone, mSizeMSS / tComputeDone / 1024.0 / 1024.0);
         panWriter.finish();
         if (o.writeRrcPan) OLOG("Written to file [%s].", rrcPanPath.c_str());
-        productWriter.finish();
-        productGuard.done = true;
-        const double tAll = seconds_since(t0);
+        // the strips are done with: their 9 GB go back while the product is still on its way to the file (releasing them is a
+        // good part of what a process of this size pays at exit)
         mMssBil.release();
         mPlanes.release();
         mPAN.release();
+        productWriter.finish();
+        productGuard.done = true;
+        const double tAll = seconds_since(t0);
         OLOG("DoInterBandAlignment(): done.");
         // one line for harnesses (bench.py's `cli` object): seconds since the action started
         double lane[4] = {0, 0, 0, 0};                       // the reader's own time: in pread (all pool threads), waiting for a ring slot's DMA
@@ -1221,6 +1243,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         OLOG("Fused task (PAN only) done in %.3f seconds.", total.tick());
         return;
     }
+    JobThread panWriter;                       // (declared before the buffers its job shares)
     // DoRRC (both strips, in place) + PreStitch of PAN2
     {
         DevBuf<double> kb((size_t)W * 2);
@@ -1240,10 +1263,15 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
         const int fold = o.foldColsPAN / 2;
         if (fold < 0 || fold >= W) throw std::invalid_argument("fold columns exceed the image width");
         const size_t nout = (size_t)2 * (W - fold) * L;
-        DevBuf<uint16_t> st(nout);
-        ck(oip_stitch_rows_u16(ctx, p1.p, p2s.p, st.p, W, L, fold));
+        auto st = std::make_shared<DevBuf<uint16_t>>(nout);
+        ck(oip_stitch_rows_u16(ctx, p1.p, p2s.p, st->p, W, L, fold));
+        long mark = 0;
+        ck(oip_compute_mark(ctx, &mark));
         OLOG("Write stitched image to file '%s' ...", outPAN.c_str());
-        write_tiff_from_device(outPAN, st.p, 2 * (W - fold), L, 1, tiff_compression(TIFF_NONE), false);
+        // the largest product of the task (4 (W - fold) L bytes) goes out on a writer thread, behind the mark of the stitch
+        // kernel, while the two default actions below run: a new file takes ~6 GB/s whatever else the process does
+        const int comp = tiff_compression(TIFF_NONE);
+        panWriter.post([=] { write_tiff_from_device(outPAN, st->p, 2 * (W - fold), L, 1, comp, false, nullptr, mark); });
     }
     // ---- step 3: inter-band alignment per CCD, PAN taken from the device
     DevBuf<uint16_t> aligned[2];
@@ -1277,6 +1305,7 @@ inline void RunFusedTask(const std::string &pan1, const std::string &pan2, const
             write_tiff_from_device(outMSS, st.p, ow, arows[0], MSS_BANDS, tiff_compression(TIFF_LZW), false, order);
         }
     }
+    panWriter.finish();
     OLOG("Fused task done in %.3f seconds.", total.tick());
 }
 

@@ -582,6 +582,96 @@ static int write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes
     return rc;
 }
 
+// ---- a product file prepared ahead of its pixels --------------------------------------------------------------------
+// What a buffered write of a NEW file costs is allocating its pages, one by one under the inode lock (5-7 GB/s on the box's
+// tmpfs, and no second thread helps: r04_io_probe).  A product whose size is known before its pixels exist -- the aligned
+// image while the strip is still being read -- is prepared by a thread that has nothing else to do then: the file is
+// created, its blocks are reserved (posix_fallocate: a full file system fails HERE, cleanly) and mapped MAP_SHARED |
+// MAP_POPULATE.  When the pixels arrive they go HBM -> pinned slot -> mapping with the slot copied by the pool's threads:
+// plain memory copies into pages that exist, several times the rate of the write() path.  Any step that fails leaves a sink
+// that writes through pwrite instead.
+struct oip_file_sink {
+    int fd = -1;
+    char *map = nullptr;
+    size_t bytes = 0;
+    std::string path;
+};
+
+extern "C" int oip_file_sink_open(oip_ctx *ctx, const char *path, size_t bytes, oip_file_sink **out)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!path || !out) return oip_fail(ctx, OIP_E_INVALID, "oip_file_sink_open: bad argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDWR | O_CREAT | O_CLOEXEC, 0644);       // (no O_TRUNC: a header written before stays)
+    if (fd < 0) return oip_fail(ctx, OIP_E_RUNTIME, "open file [%s] failed: %d", path, errno);
+    oip_file_sink *k = new oip_file_sink();
+    k->fd = fd;
+    k->bytes = bytes;
+    k->path = path;
+    const char *mode = getenv("OIP_FILE_WRITE");
+    if (bytes && !(mode && !strcmp(mode, "pwrite")) && posix_fallocate(fd, 0, (off_t)bytes) == 0) {
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
+        if (m != MAP_FAILED) k->map = (char *)m;
+    }
+    *out = k;
+    return OIP_OK;
+}
+
+extern "C" int oip_file_sink_close(oip_ctx *ctx, oip_file_sink *k)
+{
+    if (!k) return OIP_OK;
+    int rc = OIP_OK;
+    if (k->map) munmap(k->map, k->bytes);
+    if (k->fd >= 0 && close(k->fd) != 0 && ctx) rc = oip_fail(ctx, OIP_E_RUNTIME, "close file [%s] failed: %d", k->path.c_str(), errno);
+    delete k;
+    return rc;
+}
+
+extern "C" int oip_file_sink_write(oip_ctx *ctx, oip_file_sink *k, size_t file_offset, const void *d_src, size_t bytes, long mark)
+{
+    if (!ctx) return OIP_E_INVALID;
+    if (!k || (!d_src && bytes) || file_offset + bytes > k->bytes) return oip_fail(ctx, OIP_E_INVALID, "oip_file_sink_write: bad argument");
+    int rc = stage_init(ctx);
+    if (rc) return rc;
+    oip_stage_state *s = ctx->stage;
+    DownLaneLock lane(s);
+    oip_stage_state::DownLane &d = *lane.d;
+    if ((rc = down_lane_ready(ctx, d))) return rc;
+    if ((rc = down_order(ctx, s, d, mark))) return rc;
+    int prev = -1;
+    size_t prev_bytes = 0, prev_off = 0, done = 0;
+    auto flush = [&](int i, size_t off, size_t n) -> int {
+        if (hipEventSynchronize(d.slot_free[i]) != hipSuccess) return oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+        if (k->map) { CopyPool::get().copy(k->map + file_offset + off, d.slot[i], n); return OIP_OK; }
+        size_t w = 0;
+        while (w < n) {
+            const ssize_t wb = pwrite(k->fd, (const char *)d.slot[i] + w, n - w, (off_t)(file_offset + off + w));
+            if (wb < 0 && errno == EINTR) continue;
+            if (wb <= 0) return oip_fail(ctx, OIP_E_RUNTIME, "write file failed: %d", errno);
+            w += (size_t)wb;
+        }
+        return OIP_OK;
+    };
+    while (done < bytes) {
+        const int i = d.next;
+        d.next ^= 1;
+        if (d.slot_used[i] && hipEventSynchronize(d.slot_free[i]) != hipSuccess) { rc = oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed"); break; }
+        const size_t n = bytes - done < kSlotBytes ? bytes - done : kSlotBytes;
+        if (hipMemcpyAsync(d.slot[i], (const char *)d_src + done, n, hipMemcpyDeviceToHost, d.stream) != hipSuccess) {
+            rc = oip_fail(ctx, OIP_E_DEVICE, "D2H of a staged block failed");
+            break;
+        }
+        hipEventRecord(d.slot_free[i], d.stream);
+        d.slot_used[i] = true;
+        if (prev >= 0 && (rc = flush(prev, prev_off, prev_bytes))) break;
+        prev = i; prev_off = done; prev_bytes = n;
+        done += n;
+    }
+    if (rc == OIP_OK && prev >= 0) rc = flush(prev, prev_off, prev_bytes);
+    if (rc != OIP_OK) hipStreamSynchronize(d.stream);
+    return rc;
+}
+
 extern "C" int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, int append)
 {
     if (!ctx) return OIP_E_INVALID;

@@ -12,10 +12,10 @@ for W in ${WLS:-default prestitch prestitch_fused rrc}; do   # WLS: subset of wo
   echo "== bench $W"; date
   timeout -k 10 700 python3 bench.py $F --steps 10 --warmup 2 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
   echo "== kernel trace $W"; date
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py $F --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs > $OUT/bench_${W}_under_rocprof.json 2> $OUT/trace_$W.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py $F --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs --no-cli > $OUT/bench_${W}_under_rocprof.json 2> $OUT/trace_$W.err
   for C in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $C $W"; date
-    timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -o pmc -- python3 bench.py $F --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs > /dev/null 2> $OUT/pmc_${C}_$W.err
+    timeout -k 10 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_${C}_$W -o pmc -- python3 bench.py $F --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs --no-cli > /dev/null 2> $OUT/pmc_${C}_$W.err
   done
 done
 if [ -z "$SKIP_EXTRAS" ]; then

@@ -108,3 +108,40 @@ def test_permute_u16x4_in_place(ctx):
             assert np.array_equal(d.cpu().numpy(), img[:, order]), (npix, order)
     with pytest.raises(ValueError, match="outside 0..3"):
         ctx.permute_u16x4(torch.zeros(8, dtype=torch.uint16, device="cuda"), 2, [0, 1, 2, 4])
+
+
+@pytest.mark.parametrize("mode", ["", "pwrite"])
+def test_file_sink_prepared_ahead_of_its_pixels(ctx, tmp_path, mode, monkeypatch):
+    """oip_file_sink_*: a product file created, reserved and mapped before its pixels exist (the aligned image while the strip is
+    still being read), then filled HBM -> pinned slot -> mapping by parallel copies.  A header written before the sink is opened
+    stays, the payload lands at its offset behind a mark of the compute stream, bytes behind the payload (a TIFF directory)
+    can be appended afterwards; OIP_FILE_WRITE=pwrite takes the fallback route with the same result."""
+    import torch
+    if mode:
+        monkeypatch.setenv("OIP_FILE_WRITE", mode)
+    rng = np.random.default_rng(11)
+    W, H = 4096, 5000
+    src = torch.from_numpy(rng.integers(0, 4096, (H, W), dtype=np.uint16)).cuda()
+    dkb = ctx.upload_kb(np.stack([np.full(W, 1.0), np.full(W, 5.0)], 1))
+    p = str(tmp_path / "product.bin")
+    header = b"HEADER16" * 2
+    with open(p, "wb") as f:
+        f.write(header)
+    nbytes = H * W * 2
+    sink = ctx.file_sink_open(p, len(header) + nbytes)
+    assert os.path.getsize(p) == len(header) + nbytes                    # reserved up front
+    dst = torch.zeros_like(src)
+    ctx.rrc_u16(src, dst, W, H, dkb)
+    mark = ctx.compute_mark()
+    half = (H // 2) * W * 2
+    ctx.file_sink_write(sink, len(header) + half, dst, nbytes - half, mark=mark, byte_offset=half)      # second half first
+    ctx.file_sink_write(sink, len(header), dst, half, mark=mark)
+    with pytest.raises(ValueError):
+        ctx.file_sink_write(sink, len(header) + 1, dst, nbytes)            # past the end of the sink
+    ctx.file_sink_close(sink)
+    with open(p, "ab") as f:
+        f.write(b"TAIL")
+    raw = open(p, "rb").read()
+    assert raw[:len(header)] == header and raw[-4:] == b"TAIL" and len(raw) == len(header) + nbytes + 4
+    got = np.frombuffer(raw, np.uint16, count=H * W, offset=len(header)).reshape(H, W)
+    assert np.array_equal(got, (src.cpu().numpy().astype(np.int64) + 5).astype(np.uint16))

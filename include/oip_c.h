@@ -134,8 +134,8 @@ int oip_write_device_to_file(oip_ctx *ctx, const void *d_src, size_t bytes, cons
  * of an uncompressed TIFF (oip_tiff.hpp) behind its header.  mark: 0, or a mark of the compute stream to wait for. */
 int oip_write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes, const char *path, size_t file_offset, long mark);
 /* A product file PREPARED ahead of its pixels: created, its blocks reserved (a full file system fails at open, cleanly) and
- * mapped with its pages populated -- by a thread that has time for it, e.g. while the strip is still being read -- so that
- * the later write is HBM -> pinned slot -> parallel memory copies into pages that exist (on page-cache-backed files several
+ * mapped -- by a thread that has time for it, e.g. while the strip is still being read -- so that the later write is
+ * HBM -> pinned slot -> parallel memory copies into pages that exist (on page-cache-backed files several
  * times the rate of allocating them during the write, which is what bounds WriteBufferToFile's loop, imageop.h:84-97).
  * The file is not truncated: a header written before stays.  bytes: the final size of the file.  A sink whose reservation or
  * mapping failed (or OIP_FILE_WRITE=pwrite) writes through pwrite.  mark as oip_write_device_to_file_at. */

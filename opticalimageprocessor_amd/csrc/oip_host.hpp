@@ -26,6 +26,7 @@
 #include <deque>
 #include <filesystem>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -250,6 +251,36 @@ template <typename T> struct DevBuf {              // RAII device buffer
 constexpr int BYTES_PER_PIXEL = 2;
 constexpr int MSS_BANDS = OIP_MSS_BANDS;
 
+// rows x rowSamples u16 in HBM -> the writer, 256 MiB of lines at a time, the next block coming down (staging download lane)
+// while the strips of the current one are encoded (a few threads) and the previous one's are written (TiffWriterU16's own
+// thread): download || encode || write
+inline void tiff_rows_from_device(TiffWriterU16 &tw, const uint16_t *d_img, long rows, size_t rowSamples, long mark)
+{
+    oip_ctx *ctx = Device::get().ctx();
+    const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
+    const size_t cap = (size_t)std::min(chunk, rows) * rowSamples;
+    std::unique_ptr<uint16_t[]> buf[2] = {std::unique_ptr<uint16_t[]>(new uint16_t[cap]), std::unique_ptr<uint16_t[]>(rows > chunk ? new uint16_t[cap] : nullptr)};
+    auto fetch = [&](long r0, uint16_t *dst) {
+        const long nr = std::min(chunk, rows - r0);
+        return oip_download_staged_after(ctx, dst, d_img + (size_t)r0 * rowSamples, (size_t)nr * rowSamples * 2, mark);
+    };
+    Device::get().check(fetch(0, buf[0].get()));
+    int cur = 0;
+    for (long r0 = 0; r0 < rows; r0 += chunk) {
+        const long nr = std::min(chunk, rows - r0);
+        std::future<int> next;
+        if (r0 + chunk < rows) next = std::async(std::launch::async, fetch, r0 + chunk, buf[cur ^ 1].get());
+        try {
+            tw.write_rows(buf[cur].get(), nr);
+        } catch (...) {
+            if (next.valid()) next.wait();
+            throw;
+        }
+        if (next.valid()) Device::get().check(next.get());
+        cur ^= 1;
+    }
+}
+
 // A TIFF product whose pixels are in HBM (rows x width x spp u16, interleaved).  Uncompressed: the pixel payload goes from
 // the device into the file behind the header (TiffWriterU16::begin_external_payload + oip_write_device_to_file_at) -- no
 // strip-sized heap copy, as the reference's cv::imwrite / GDAL paths make (imageop.h:316-328, preproc.h:167-185).  LZW: the
@@ -272,13 +303,7 @@ inline void write_tiff_from_device(const std::string &path, uint16_t *d_img, int
         Device::get().check(oip_write_device_to_file_at(ctx, d_img, (size_t)height * rowSamples * 2, path.c_str(), (size_t)at, mark));
         tw.end_external_payload();
     } else {
-        const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
-        std::unique_ptr<uint16_t[]> host(new uint16_t[(size_t)std::min(chunk, height) * rowSamples]);
-        for (long r0 = 0; r0 < height; r0 += chunk) {
-            const long nr = std::min(chunk, height - r0);
-            Device::get().check(oip_download_staged_after(ctx, host.get(), d_img + (size_t)r0 * rowSamples, (size_t)nr * rowSamples * 2, mark));
-            tw.write_rows(host.get(), nr);
-        }
+        tiff_rows_from_device(tw, d_img, height, rowSamples, mark);
     }
     tw.close();
 }
@@ -1072,14 +1097,7 @@ public:
                         Device::get().check(oip_file_sink_close(ctx, k));
                         tw->end_external_payload();
                     } else {
-                        // strips are encoded as their lines come down: 256 MiB of lines per round
-                        const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
-                        std::vector<uint16_t> host((size_t)std::min(chunk, rows) * rowSamples);
-                        for (long r0 = 0; r0 < rows; r0 += chunk) {
-                            const long nr = std::min(chunk, rows - r0);
-                            Device::get().check(oip_download_staged_after(ctx, host.data(), img + (size_t)r0 * rowSamples, (size_t)nr * rowSamples * 2, mark));
-                            tw->write_rows(host.data(), nr);
-                        }
+                        tiff_rows_from_device(*tw, img, rows, rowSamples, mark);     // download || encode || write
                     }
                     tw->close();
                     OLOG("Output done.");

@@ -586,9 +586,9 @@ static int write_device_to_file_at(oip_ctx *ctx, const void *d_src, size_t bytes
 // What a buffered write of a NEW file costs is allocating its pages, one by one under the inode lock (5-7 GB/s on the box's
 // tmpfs, and no second thread helps: r04_io_probe).  A product whose size is known before its pixels exist -- the aligned
 // image while the strip is still being read -- is prepared by a thread that has nothing else to do then: the file is
-// created, its blocks are reserved (posix_fallocate: a full file system fails HERE, cleanly) and mapped MAP_SHARED |
-// MAP_POPULATE.  When the pixels arrive they go HBM -> pinned slot -> mapping with the slot copied by the pool's threads:
-// plain memory copies into pages that exist, several times the rate of the write() path.  Any step that fails leaves a sink
+// created, its blocks are reserved (posix_fallocate: a full file system fails HERE, cleanly) and mapped MAP_SHARED.  When
+// the pixels arrive they go HBM -> pinned slot -> mapping with the slot copied by the pool's threads: memory copies into
+// pages that exist (first touches map them, in parallel), several times the rate of the write() path.  Any step that fails leaves a sink
 // that writes through pwrite instead.
 struct oip_file_sink {
     int fd = -1;
@@ -610,8 +610,22 @@ extern "C" int oip_file_sink_open(oip_ctx *ctx, const char *path, size_t bytes, 
     k->path = path;
     const char *mode = getenv("OIP_FILE_WRITE");
     if (bytes && !(mode && !strcmp(mode, "pwrite")) && posix_fallocate(fd, 0, (off_t)bytes) == 0) {
-        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd, 0);
-        if (m != MAP_FAILED) k->map = (char *)m;
+        // NOT MAP_POPULATE: populating 1.5 GB holds the process's mmap_lock for ~0.2 s and every thread that maps, unmaps or
+        // faults meanwhile -- the reader, the compute thread's allocations -- stands still (measured: the second correlation
+        // section started 230 ms late).  The reserved pages are mapped by the copy threads' own first touches instead, which
+        // run in parallel; OIP_SINK_POPULATE=1 populates ahead in 16 MiB steps (MADV_POPULATE_WRITE) for comparison.
+        void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m != MAP_FAILED) {
+            k->map = (char *)m;
+            const char *pop = getenv("OIP_SINK_POPULATE");
+#ifdef MADV_POPULATE_WRITE
+            if (pop && atoi(pop) == 1)
+                for (size_t o = 0; o < bytes; o += (size_t)16 << 20)
+                    if (madvise(k->map + o, bytes - o < ((size_t)16 << 20) ? bytes - o : ((size_t)16 << 20), MADV_POPULATE_WRITE) != 0) break;
+#else
+            (void)pop;
+#endif
+        }
     }
     *out = k;
     return OIP_OK;

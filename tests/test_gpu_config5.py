@@ -254,3 +254,29 @@ def test_two_ranks_prestitch_stitch_equals_one_rank_on_the_gpu(tmp_path, what):
     assert abs(one["shift"][0] - 3) < 0.3 and abs(one["shift"][1] + 2) < 0.3
     assert np.array_equal(np.concatenate([p["prestt"] for p in parts], 0), one["prestt"])
     assert np.array_equal(np.concatenate([p["stitched"] for p in parts], 0), one["stitched"])
+
+
+def test_bench_starts_its_own_ranks_and_reports_stage_times():
+    """`python bench.py --gpus 2` as the driver calls it -- no launcher, WORLD_SIZE unset: the parent (which never touches the GPU)
+    starts the two ranks itself and relays rank 0's line.  On this one-GPU box the ranks share the card and
+    gloo stages the transfers through the host (OIP_BENCH_BACKEND=gloo): a rehearsal of the plumbing, not a measurement -- the
+    line must say so, carry the per-rank stage times of one instrumented step next to the placement model's prediction
+    (`config.multi_gpu`, item 6) and stay under 8 KB."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OIP_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--lines", "65536", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8192, (len(lines), [len(x) for x in lines])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    mg = line["config"]["multi_gpu"]
+    assert "rehearsal" in mg["mode"] and len(mg["predicted_correlation_finish_us"]) == 2 and len(mg["measured_correlation_finish_us"]) == 2
+    for k in ("rrc_ms", "correlate_resident_ms", "allgather_ms", "halo_ms", "align_ms", "step_ms"):
+        assert len(mg["measured_ms"][k]) == 2, k
+    assert all(v > 0 for v in mg["measured_ms"]["step_ms"])

@@ -25,7 +25,8 @@ class OipError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_PKG, "lib", "liboipgpu.so")
+    # OIP_LIBRARY: another build of the same library (A/B experiments on one box: profiles/experiments/*.sh)
+    return os.environ.get("OIP_LIBRARY") or os.path.join(_PKG, "lib", "liboipgpu.so")
 
 
 def build(jobs: int = 8, quiet: bool = True) -> None:

@@ -29,26 +29,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(to_v(a)), "v"(to_v(b)), "v"(t));
     return to_f2(r);
 }
-// Two independent products as ONE block, the two multiplies ahead of the two multiply-adds.  A v_pk_fma_f32 that reads the
-// result of the v_pk_mul_f32 right before it needs a wait state (the compiler puts an s_nop 0 between the two halves of every
-// cmul: 258 of them in corr_rows_up_kernel, whose waves are bound by instruction issue); with a second product in between the
-// slot does work.  Same arithmetic per product: results are bit-identical to two cmul calls.
-#ifndef OIP_FFT_NO_CMUL2
-__device__ __forceinline__ void cmul2(float2 a1, float2 b1, float2 a2, float2 b2, float2 *r1, float2 *r2)
-{
-    oip_v2f t1, t2, o1, o2;
-    asm("v_pk_mul_f32 %0, %4, %5 op_sel_hi:[0,1]\n\t"
-        "v_pk_mul_f32 %1, %6, %7 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\t"
-        "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
-        : "=&v"(t1), "=&v"(t2), "=&v"(o1), "=&v"(o2)
-        : "v"(to_v(a1)), "v"(to_v(b1)), "v"(to_v(a2)), "v"(to_v(b2)));
-    *r1 = to_f2(o1);
-    *r2 = to_f2(o2);
-}
-#else
-__device__ __forceinline__ void cmul2(float2 a1, float2 b1, float2 a2, float2 b2, float2 *r1, float2 *r2);
-#endif
 // m + (-i) u = (m.x + u.y, m.y - u.x)
 __device__ __forceinline__ float2 cadd_rot(float2 m, float2 u)
 {
@@ -71,14 +51,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 }
 __device__ __forceinline__ float2 cadd_rot(float2 m, float2 u) { return make_float2(m.x + u.y, m.y - u.x); }
 __device__ __forceinline__ float2 csub_rot(float2 m, float2 u) { return make_float2(m.x - u.y, m.y + u.x); }
-#endif
-#if defined(OIP_FFT_NO_ASM) || defined(OIP_FFT_NO_CMUL2)
-__device__ __forceinline__ void cmul2(float2 a1, float2 b1, float2 a2, float2 b2, float2 *r1, float2 *r2)
-{
-    const float2 p = cmul(a1, b1), q = cmul(a2, b2);
-    *r1 = p;
-    *r2 = q;
-}
 #endif
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -490,17 +462,15 @@ template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
                 const int k = b % Ns;
                 if (Ns > 1) {
                     const float2 w1 = tw[k * TWSTEP];
-                    // (independent products go in pairs: cmul2)
                     if (A == 1) {
                         float2 w = w1;
 #pragma unroll
                         for (int m = 1; m < R; ++m) {
-                            if (m + 1 < R) cmul2(x[i][m], w, w, w1, &x[i][m], &w);
-                            else x[i][m] = cmul(x[i][m], w);
+                            x[i][m] = cmul(x[i][m], w);
+                            if (m + 1 < R) w = cmul(w, w1);
                         }
                     } else {
                         constexpr int B = R / A;
-                        static_assert(A % 2 == 1, "pairs below assume an even number of non-trivial n1");
                         float2 wn1[A];                                  // w^n1, n1 < A
                         wn1[0] = make_float2(1.f, 0.f);
                         wn1[1] = w1;
@@ -509,17 +479,13 @@ template <int F, int NT, int NA, int Ns, int R> struct StageAllOps {
                         float2 wa = cmul(wn1[A - 1], w1);               // w^A
                         float2 wan = wa;                                // (w^A)^n2
 #pragma unroll
-                        for (int n1 = 1; n1 < A; n1 += 2) cmul2(x[i][n1], wn1[n1], x[i][n1 + 1], wn1[n1 + 1], &x[i][n1], &x[i][n1 + 1]);
+                        for (int n1 = 1; n1 < A; ++n1) x[i][n1] = cmul(x[i][n1], wn1[n1]);
 #pragma unroll
                         for (int n2 = 1; n2 < B; ++n2) {
-                            float2 t[A];
+                            x[i][A * n2] = cmul(x[i][A * n2], wan);
 #pragma unroll
-                            for (int n1 = 1; n1 < A; n1 += 2) cmul2(wn1[n1], wan, wn1[n1 + 1], wan, &t[n1], &t[n1 + 1]);
-                            if (n2 + 1 < B) cmul2(x[i][A * n2], wan, wan, wa, &x[i][A * n2], &wan);
-                            else x[i][A * n2] = cmul(x[i][A * n2], wan);
-#pragma unroll
-                            for (int n1 = 1; n1 < A; n1 += 2)
-                                cmul2(x[i][n1 + A * n2], t[n1], x[i][n1 + 1 + A * n2], t[n1 + 1], &x[i][n1 + A * n2], &x[i][n1 + 1 + A * n2]);
+                            for (int n1 = 1; n1 < A; ++n1) x[i][n1 + A * n2] = cmul(x[i][n1 + A * n2], cmul(wn1[n1], wan));
+                            if (n2 + 1 < B) wan = cmul(wan, wa);
                         }
                     }
                 }

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 for W in ${WLS:-default prestitch prestitch_fused rrc}; do   # WLS: subset of workloads (a gpurun call is limited to 20 minutes)
   case $W in prestitch_fused) F="--workload prestitch --fused";; *) F="--workload $W";; esac
   echo "== bench $W"; date
-  timeout -k 10 700 python3 bench.py $F --steps 10 --warmup 2 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  timeout -k 10 700 python3 bench.py $F --steps 10 --warmup 2 --full-record $OUT/bench_${W}_full.json > $OUT/bench_$W.json 2> $OUT/bench_$W.err
   echo "== kernel trace $W"; date
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$W -o trace -- python3 bench.py $F --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-configs --no-cli > $OUT/bench_${W}_under_rocprof.json 2> $OUT/trace_$W.err
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -28,6 +28,8 @@ def bench_name(kernel):
         return "fft_pass_ct_kernel_F128_peak"                         # the register-staged peak pass, profiled under the pass's name
     if "align_mss8_kernel" in kernel:
         return "align_mss_kernel"
+    if "mss_split_flat_kernel" in kernel:
+        return "mss_split_rrc_kernel"                                 # the flat form, profiled under the seam's name
     if "resize_cubic_v_x4_kernel" in kernel:
         return "resize_cubic_v_kernel"                                # profiled under the generic kernel's name
     m = re.search(r"([A-Za-z_0-9]+_kernel)\b", kernel)
@@ -44,6 +46,9 @@ for w in ("default", "prestitch", "prestitch_fused", "rrc"):
     b = os.path.join(out, "bench_%s.json" % w)
     if os.path.exists(b):
         shutil.copy(b, os.path.join(prof, "%s_bench_%s.json" % (tag, w)))
+    b = os.path.join(out, "bench_%s_full.json" % w)                   # the verbose record behind the compact stdout line
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(prof, "%s_bench_%s_full.json" % (tag, w)))
     st = glob.glob(os.path.join(out, "trace_%s" % w, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(prof, "%s_%s_kernel_stats.csv" % (tag, w)))

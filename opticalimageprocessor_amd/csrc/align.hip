@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
         for (int k = 0; k < 4; ++k) {
             const long r = rb + k;
             if (r >= r1) break;
-            const AlignRow a = rows[r];
+            const AlignRow a = rows[oip_uniform(r)];
             unsigned out[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             if (a.valid) {                                    // uniform over the wave
                 const double yrel = (double)a.yrel;

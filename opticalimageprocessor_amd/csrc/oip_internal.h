@@ -122,6 +122,12 @@ struct OipProfScope {
 };
 
 // ---- device helpers shared by the resampling kernels -----------------------------------
+// A line index that is the same in every lane, told to the compiler: the per-line row tables are then read with scalar loads
+// (s_load, counted by lgkmcnt) instead of one vector load per lane of the same 16-24 bytes -- whose s_waitcnt vmcnt(0) also
+// waits for every line the kernel has requested ahead (round 4: the row table of remap_shift8_rrc_kernel and
+// align_mss8_kernel came in through global_load_dwordx3/x4 because the compiler could not prove the loop counter uniform).
+__device__ __forceinline__ long oip_uniform(long r) { return (long)__builtin_amdgcn_readfirstlane((int)r); }
+
 // OpenCV cvRound(float): round half to even; v_rndne_f32 + v_cvt_i32_f32
 __device__ __forceinline__ int oip_cvround(float v) { return (int)__builtin_rintf(v); }
 

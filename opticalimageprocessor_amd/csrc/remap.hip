@@ -575,7 +575,7 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
     // are staged at the run's start (k = 0 again), after that every output line stages exactly one new line.
     long r = r0;
     while (r < r1) {
-        const RowInfo h = rows[r];
+        const RowInfo h = rows[oip_uniform(r)];
         if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
         long qline = h.src[3];                    // chunks of source lines qline and qline + 1 are requested ahead (four
         uint4 qa, qb;                             // ahead: the same 4.35 ms; as an array instead of named registers: spills)
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (r >= r1) { run = false; break; }
-                const RowInfo ri = rows[r];
+                const RowInfo ri = rows[oip_uniform(r)];
                 if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
                 stage(qa, (k + 3) & 3);
                 qa = qb;

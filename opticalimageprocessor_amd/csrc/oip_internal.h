@@ -127,6 +127,17 @@ struct OipProfScope {
 // waits for every line the kernel has requested ahead (round 4: the row table of remap_shift8_rrc_kernel and
 // align_mss8_kernel came in through global_load_dwordx3/x4 because the compiler could not prove the loop counter uniform).
 __device__ __forceinline__ long oip_uniform(long r) { return (long)__builtin_amdgcn_readfirstlane((int)r); }
+// One int of a table at a wave-uniform index through the scalar cache, whatever the compiler can prove about aliasing: where
+// a kernel also stores through pointers it was handed in a struct, the compiler reads such a table with a vector load, and the
+// s_waitcnt vmcnt(0) behind it waits for every store and prefetch the wave has in flight.  The table must not be written by the
+// kernel (the scalar cache is not coherent with vector stores).  Waits for the value (lgkmcnt: LDS and scalar loads only).
+__device__ __forceinline__ int oip_sload_i32(const int *__restrict__ table, long index)
+{
+    int v;
+    const int *p = table + oip_uniform(index);
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 
 // OpenCV cvRound(float): round half to even; v_rndne_f32 + v_cvt_i32_f32
 __device__ __forceinline__ int oip_cvround(float v) { return (int)__builtin_rintf(v); }

@@ -1073,10 +1073,12 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         // spilled (a reload is a vector-memory load: younger than the prefetch, it would wait for it) -- and committed at
         // the bottom of this same iteration: three quarters of the iteration run without their registers.
         if (more && !(dbg & 8)) {
-            n1 = ypos[kn];
-            n2 = ypos[M - kn];
-            m1 = narrow_row(kn, n1);
-            m2 = narrow_row(M - kn, n2);
+            // (scalar loads: as vector loads these four look-ups put an s_waitcnt vmcnt(0) -- the stores of store(0) and the
+            // table loads -- in front of the prefetch)
+            n1 = oip_sload_i32(ypos, kn);
+            n2 = oip_sload_i32(ypos, M - kn);
+            m1 = VEXP ? (long)oip_sload_i32(fj.ypos_s, kn % fj.m) : n1;
+            m2 = VEXP ? (long)oip_sload_i32(fj.ypos_s, (M - kn) % fj.m) : n2;
             kyc = kn;
             fetch(tid);
         }
@@ -1217,10 +1219,10 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_v_kernel(VRowsJob 
         const int kn = ky + gridDim.x;
         const bool more = kn <= half;
         if (more && !(dbg & 8)) {
-            n1 = ypos[kn];
-            n2 = ypos[M - kn];
-            m1 = fj.ypos_s[kn % fj.m];
-            m2 = fj.ypos_s[(M - kn) % fj.m];
+            n1 = oip_sload_i32(ypos, kn);
+            n2 = oip_sload_i32(ypos, M - kn);
+            m1 = oip_sload_i32(fj.ypos_s, kn % fj.m);
+            m2 = oip_sload_i32(fj.ypos_s, (M - kn) % fj.m);
             kyc = kn;
             fetch(tid);
         }

@@ -577,12 +577,16 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
     while (r < r1) {
         const RowInfo h = rows[oip_uniform(r)];
         if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
-        long qline = h.src[3];                    // chunks of source lines qline and qline + 1 are requested ahead (four
-        uint4 qa, qb;                             // ahead: the same 4.35 ms; as an array instead of named registers: spills)
+        // The chunks of source lines qline .. qline + 2 are requested ahead.  Round 3 found "four ahead: the same 4.35 ms" --
+        // because the row table came in through a vector load whose s_waitcnt vmcnt(0) waited for every line in flight; with
+        // the table on scalar loads (oip_uniform) the depth counts (named registers: four slots as an array spill 47).
+        long qline = h.src[3];
+        uint4 qa, qb, qc;
         {
             const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
             qa = fetch(qline);
             qb = fetch(qline + 1);
+            qc = fetch(qline + 2);
             stage(f0, 0);
             stage(f1, 1);
             stage(f2, 2);
@@ -597,8 +601,9 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
                 if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
                 stage(qa, (k + 3) & 3);
                 qa = qb;
+                qb = qc;
                 qline += 1;
-                qb = fetch(qline + 1);
+                qc = fetch(qline + 2);
                 cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
                 const long rr_ = r;
                 ++r;

@@ -1073,8 +1073,8 @@ __global__ __launch_bounds__(NT) void corr_rows_up_kernel(UpRowsJob fj, int M, i
         // spilled (a reload is a vector-memory load: younger than the prefetch, it would wait for it) -- and committed at
         // the bottom of this same iteration: three quarters of the iteration run without their registers.
         if (more && !(dbg & 8)) {
-            // (scalar loads: as vector loads these four look-ups put an s_waitcnt vmcnt(0) -- the stores of store(0) and the
-            // table loads -- in front of the prefetch)
+            // (scalar loads: as vector loads these look-ups put an s_waitcnt vmcnt(0) -- the stores of store(0) and the table
+            // loads -- in front of the prefetch.  ABAB on one box: 1.1677 / 1.1696 -> 1.1509 / 1.1427 ms per launch)
             n1 = oip_sload_i32(ypos, kn);
             n2 = oip_sload_i32(ypos, M - kn);
             m1 = VEXP ? (long)oip_sload_i32(fj.ypos_s, kn % fj.m) : n1;
@@ -1219,10 +1219,12 @@ __global__ __launch_bounds__(NT, 2 * NT / 256) void corr_rows_v_kernel(VRowsJob 
         const int kn = ky + gridDim.x;
         const bool more = kn <= half;
         if (more && !(dbg & 8)) {
-            n1 = oip_sload_i32(ypos, kn);
-            n2 = oip_sload_i32(ypos, M - kn);
-            m1 = oip_sload_i32(fj.ypos_s, kn % fj.m);
-            m2 = oip_sload_i32(fj.ypos_s, (M - kn) % fj.m);
+            // (plain loads here: this kernel requests its next lines at the TOP of the iteration, nothing of its own is in
+            // flight yet, and the explicit scalar loads of corr_rows_up_kernel cost it 4.5 % -- 0.740 against 0.708 ms)
+            n1 = ypos[kn];
+            n2 = ypos[M - kn];
+            m1 = fj.ypos_s[kn % fj.m];
+            m2 = fj.ypos_s[(M - kn) % fj.m];
             kyc = kn;
             fetch(tid);
         }

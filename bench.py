@@ -476,7 +476,12 @@ def cli_default_action(env, d, kb_mss, threshold):
     if not os.path.exists(exe):
         return {"error": "lib/oip not built"}
     base = os.environ.get("OIP_BENCH_TMP", "/dev/shm")
-    tmp = tempfile.mkdtemp(prefix="oip_bench_", dir=base if os.path.isdir(base) and os.access(base, os.W_OK) else None)
+    if not (os.path.isdir(base) and os.access(base, os.W_OK)):
+        base = tempfile.gettempdir()
+    need = 2.2 * (pb + mb) * W * 2                      # inputs + the largest set of products, with some room
+    if shutil.disk_usage(base).free < need:
+        return {"error": "not enough room under %s for the strip files (%.0f GB wanted)" % (base, need / 1e9)}
+    tmp = tempfile.mkdtemp(prefix="oip_bench_", dir=base)
     try:
         t0 = time.time()
         host = np.empty((pb, W), np.uint16)
@@ -892,6 +897,11 @@ def compact_line(line, full_path):
         cfg["cli_pipeline_ms"] = {k: round(v["log_seconds"]["products_written"] * 1e3, 1) for k, v in cli["runs"].items() if "log_seconds" in v}
         cfg["cli_read_GBs"] = round(cli["read_GBs"], 1) if cli.get("read_GBs") else None
         cfg["cli_product_equals_resident_step"] = cli.get("aligned_product_equals_resident_step")
+        cfg["cli_note"] = ("wall of the `oip` executable on files in tmpfs, ms per run: raw = uncompressed aligned product (two runs), "
+                           "raw_rrcpan = + <pan>.RRC.RAW, lzw = the reference's LZW product, steps_raw = the step-by-step flow; "
+                           "cli_pipeline_ms = first byte read to products on disk (the log's own clock)")
+    elif cli:
+        cfg["cli_error"] = cli.get("error")
     legs = {}
     for name, e in (line.get("configs") or {}).items():
         dk = e.get("dominant_kernel") or {}
@@ -1037,7 +1047,10 @@ def main():
             line["end_to_end"] = e2e
         if world == 1 and args.workload == "default" and not args.no_cli:
             kb_mss = np.concatenate([synth.lut(W // 4, 10 + b) for b in range(4)], 0)
-            line["cli"] = cli_default_action(env, d, kb_mss, p.threshold)
+            try:
+                line["cli"] = cli_default_action(env, d, kb_mss, p.threshold)
+            except Exception as e:                                  # noqa: BLE001 -- the leg must not take the line with it
+                line["cli"] = {"error": repr(e)[:300]}
         if world == 1 and args.workload == "default" and not args.no_configs and W == 30000 and pb == 100000:
             d = None                        # release the headline workload's rasters before the other configurations
             line["configs"] = config_legs(env, args, line)

@@ -92,8 +92,34 @@ about = ("HBM bytes per launch from rocprofv3 PMC counters on MI355X (gfx950, RO
          "(MI355X_MICROARCH.md, HBM section), WRITE_SIZE is exact.  Kernels whose loads are narrower than 16 B/lane "
          "(align, mss_split, the 2-byte PAN reads of the first FFT pass) are uncalibrated on the read side.  "
          "Raw: profiles/%s_pmc_raw.json" % tag)
+# a collect.sh call covers the workloads named in WLS (a gpurun call is limited to 20 minutes, every call gets a fresh box):
+# workloads this call did not measure keep what the committed files hold for them
+def merged(path, fresh, keep_key=None):
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except ValueError:
+            old = {}
+    out = dict(old)
+    for w, v in fresh.items():
+        if v or w not in out:
+            out[w] = v
+    return out, old
+
+raw_path = os.path.join(root, "profiles", "%s_pmc_raw.json" % tag)
+raw, _ = merged(raw_path, raw)
 json.dump(raw, open(os.path.join(prof, "%s_pmc_raw.json" % tag), "w"), indent=1, sort_keys=True)
-t = {"_about": about, "_source": {w: "profiles/%s_pmc_raw.json" % tag for w in traffic}}
+old_t = {}
+if os.path.exists(os.path.join(root, "profiles", "traffic.json")):
+    old_t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+src = dict(old_t.get("_source", {}))
+for w, v in list(traffic.items()):
+    if v:
+        src[w] = "profiles/%s_pmc_raw.json" % tag
+    elif w in old_t:
+        traffic[w] = old_t[w]
+t = {"_about": about, "_source": src}
 t.update(traffic)
 json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1, sort_keys=True)
 print("summaries written for", tag, {w: len(v) for w, v in traffic.items()})

@@ -257,7 +257,12 @@ constexpr int MSS_BANDS = OIP_MSS_BANDS;
 inline void tiff_rows_from_device(TiffWriterU16 &tw, const uint16_t *d_img, long rows, size_t rowSamples, long mark)
 {
     oip_ctx *ctx = Device::get().ctx();
-    const long chunk = std::max<long>(1, (long)(((size_t)256 << 20) / (rowSamples * 2)));
+    size_t chunkBytes = (size_t)256 << 20;
+    if (const char *e = getenv("OIP_TIFF_CHUNK_MB")) {                 // test hook: several blocks on a small image
+        const long mb = atol(e);
+        if (mb > 0) chunkBytes = (size_t)mb << 20;
+    }
+    const long chunk = std::max<long>(1, (long)(chunkBytes / (rowSamples * 2)));
     const size_t cap = (size_t)std::min(chunk, rows) * rowSamples;
     std::unique_ptr<uint16_t[]> buf[2] = {std::unique_ptr<uint16_t[]>(new uint16_t[cap]), std::unique_ptr<uint16_t[]>(rows > chunk ? new uint16_t[cap] : nullptr)};
     auto fetch = [&](long r0, uint16_t *dst) {

@@ -156,7 +156,9 @@ def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
             _csv(os.path.join(d, "PAN.csv"), _synth.lut(W, 3))
             for b in range(4):
                 _csv(os.path.join(d, "MSS.B%d.csv" % (b + 1)), _synth.lut(W // 4, 20 + b))
-            env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp)
+            # (OIP_TIFF_CHUNK_MB: the LZW product comes down in 1 MiB blocks, so that the download || encode || write overlap of
+            # tiff_rows_from_device runs over many blocks on this small image)
+            env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp, OIP_TIFF_CHUNK_MB="1")
             args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv", "--write-rrcpan",
                     "--slices", "9", "--ibc-sections", "2", "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
             for b in range(4):
@@ -174,6 +176,17 @@ def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
         ta, tb = pick(runs[(comp, "steps")][1]), pick(runs[(comp, "pipe")][1])
         strip = lambda lines: [ln.split(" ", 2)[-1] if "coeff:" in ln else ln for ln in lines]
         assert len(ta) > 20 and strip(ta) == strip(tb)
+    # the LZW product (strips encoded block by block as the lines come down) decodes to the uncompressed product's pixels: it is
+    # read back by `oip stitch` (the product's decoder, pinned against the Python decoder and Pillow in tests/test_cli_cpu.py) and
+    # re-written uncompressed, which the independent reader of tests/_tiff.py compares (its own LZW decoder needs minutes per MB)
+    d = runs[("lzw", "pipe")][0]
+    assert _tiff.read_tags(os.path.join(d, "T_MSS.ALIGNED.TIFF"))[259] == [5] and _tiff.read_tags(os.path.join(d, "T_MSS.ALIGNED.TIFF"))[317] == [2]
+    r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T_MSS.ALIGNED.TIFF", "--fold-cols", "2", "--tiff-compress", "none",
+                        "-o", "roundtrip.TIFF"], cwd=d, env=dict(os.environ, LOGFILE=os.path.join(d, "oip.log")), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    twice, _, _ = _tiff.read_tiff_u16(os.path.join(d, "roundtrip.TIFF"))
+    un, _, _ = _tiff.read_tiff_u16(os.path.join(runs[("none", "pipe")][0], "T_MSS.ALIGNED.TIFF"))
+    assert un.any() and np.array_equal(twice, np.concatenate([un[:, :un.shape[1] - 1], un[:, 1:]], axis=1))
     # errors keep their exit codes in the pipeline: a truncated MSS file (size check, preproc.h:552-572) and too many sections
     d = runs[("none", "pipe")][0]
     env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"))

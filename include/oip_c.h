@@ -112,7 +112,8 @@ int oip_rrc_u16_host(oip_ctx *ctx, uint16_t *buff, int w, long h, const double *
  * while the first drives kernels through the same context: they use streams and pinned slots of their own,
  * set the context's device for the calling thread, and never touch the compute stream's state.  Calls of one
  * lane serialise on a lock (ring lane: read_file / upload_staged / rrc_u16_host; download lane:
- * download_staged[_after] / write_file[_at]), the two lanes run concurrently (full duplex): a reader thread,
+ * download_staged[_after] / write_file[_at] / file_sink_write: three of them, a call takes a free one), ring and download
+ * lanes run concurrently (full duplex): a reader thread,
  * the compute thread and a writer thread form the pipeline of the `oip` CLI's default action.
  * Ordering: downloads and file writes start after the compute-stream work enqueued before the call, or after
  * a MARK of the compute stream (oip_compute_mark) when one is given; UPLOADS DO NOT wait for the compute

@@ -603,6 +603,10 @@ public:
         OLOG("    dx: %.5f, dy: %.5f, r: %.5f", mDeltaX, mDeltaY, mResponse);
     }
 
+    // The three strip-sized products of `prestitch` (.RRC.RAW x 2, .RRC.PRESTT.RAW: 6 GB each at the 30000 x 100000 geometry) go
+    // out on writer threads behind marks of the compute stream, each on a download lane of its own: a NEW file takes 6-7 GB/s
+    // from one writer whatever else the process does, so three files at once are what shortens the command.
+    // Finish() -- called by PreStitch, by the destructor and by the CLI -- waits for them and logs the reference's lines.
     void DoRRC()                                                        // stitcher.h:141-146
     {
         LoadRawOnce();
@@ -610,22 +614,31 @@ public:
         mRrcFilePAN2 = IMO::BuildOutputFilePath(mFilePAN2, ".RRC");
         const size_t npx = (size_t)mW * mLinesPAN;
         DevBuf<double> kb((size_t)mW * 2);
+        oip_ctx *ctx = Device::get().ctx();
         for (int c = 0; c < 2; ++c) {                                   // IMO::DoRRC4RAW on the resident strip
             std::unique_ptr<RRCParam[]> prm(IMO::LoadRRCParamFile((c ? mParamFileRRC2 : mParamFileRRC1).c_str(), mW));
             kb.upload((double *)prm.get(), (size_t)mW * 2);
             DevBuf<uint16_t> &d = c ? mD2 : mD1;
             OLOG("Do inplace RRC ...");
             stop_watch sw;
-            Device::get().check(oip_rrc_u16(Device::get().ctx(), d.p, d.p, mW, (long)mLinesPAN, kb.p));
-            Device::get().check(oip_sync(Device::get().ctx()));
+            Device::get().check(oip_rrc_u16(ctx, d.p, d.p, mW, (long)mLinesPAN, kb.p));
+            Device::get().check(oip_sync(ctx));
             double es = sw.tick();
             OLOG("Done for %zu bytes in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
-            const std::string &save = c ? mRrcFilePAN2 : mRrcFilePAN1;
+            const std::string save = c ? mRrcFilePAN2 : mRrcFilePAN1;
             OLOG("Write RRC result as file \"%s\" ...", save.c_str());
-            sw.tick();
-            d.save_file(save, npx);
-            es = sw.tick();
-            OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
+            long mark = 0;
+            Device::get().check(oip_compute_mark(ctx, &mark));
+            const uint16_t *src = d.p;
+            const size_t bytes = mSizePAN;
+            (void)npx;
+            mWriter[c].post([=] {
+                stop_watch w;
+                { FILE *f = fopen(save.c_str(), "wb"); if (!f) throw std::runtime_error("open file [" + save + "] failed: " + std::to_string(errno)); fclose(f); }
+                Device::get().check(oip_write_device_to_file_at(ctx, src, bytes, save.c_str(), 0, mark));
+                const double s = w.tick();
+                OLOG("%zu bytes written in %.3f seconds (%.1f MBps).", bytes, s, bytes / s / (1024.0 * 1024.0));
+            });
         }
     }
 
@@ -635,17 +648,33 @@ public:
         LoadRawOnce();                                                  // mD2 holds what mRrcFilePAN2 names (raw with --no-rrc)
         mPreSttFilePAN2 = IMO::BuildOutputFilePath(mRrcFilePAN2, ".PRESTT");
         const size_t npx = (size_t)mW * mLinesPAN;
+        oip_ctx *ctx = Device::get().ctx();
         stop_watch sw;
-        DevBuf<uint16_t> dst(npx);
+        mPre.alloc(npx);
         auto fn = fp16acc ? oip_remap_shift_bicubic_u16_f16acc : oip_remap_shift_bicubic_u16;
-        Device::get().check(fn(Device::get().ctx(), mD2.p, 0, mLinesPAN, dst.p, 0, mLinesPAN, mW, mLinesPAN, mDeltaX, mDeltaY,
+        Device::get().check(fn(ctx, mD2.p, 0, mLinesPAN, mPre.p, 0, mLinesPAN, mW, mLinesPAN, mDeltaX, mDeltaY,
                                OIP_REMAP_SECTION_ROWS, OIP_REMAP_ROW_GUARD));
-        dst.save_file(mPreSttFilePAN2, npx);
+        long mark = 0;
+        Device::get().check(oip_compute_mark(ctx, &mark));
+        const std::string save = mPreSttFilePAN2;
+        const uint16_t *src = mPre.p;
+        const size_t bytes = mSizePAN;
+        mWriter[2].post([=] {
+            { FILE *f = fopen(save.c_str(), "wb"); if (!f) throw std::runtime_error("open file [" + save + "] failed: " + std::to_string(errno)); fclose(f); }
+            Device::get().check(oip_write_device_to_file_at(ctx, src, bytes, save.c_str(), 0, mark));
+        });
+        Finish();
         double es = sw.tick();
         OLOG("Pre-stitched PAN2 written to file '%s'.", mPreSttFilePAN2.c_str());
         OLOG("%zu bytes processed & written in %.3f seconds (%.1f MBps).", mSizePAN, es, mSizePAN / es / (1024.0 * 1024.0));
         const int ucut = mDeltaY >= 0.0 ? 0 : (int)(-mDeltaY) + 1, bcut = mDeltaY >= 0.0 ? (int)mDeltaY + 1 : 0;
         return mLinesPAN - (ucut + bcut);        // SectionaryRemap's returned row_offset
+    }
+
+    // every product posted so far is on disk when this returns (the first failure of a writer is re-thrown)
+    void Finish()
+    {
+        for (auto &w : mWriter) w.finish();
     }
 
     double deltaX() const { return mDeltaX; }
@@ -657,7 +686,8 @@ private:
     double mDeltaX = 0, mDeltaY = 0, mResponse = 0;
     size_t mSizePAN = 0;
     int mSections, mLinePerSection, mOverlapCols, mLinesPAN = 0, mW;
-    DevBuf<uint16_t> mD1, mD2;                  // the two strips, resident from the first step that needs them
+    DevBuf<uint16_t> mD1, mD2, mPre;            // the two strips, resident from the first step that needs them; the resampled CCD 2
+    JobThread mWriter[3];                       // (declared after the buffers: joined before they are released)
 };
 
 // ---- PreProcessor (preproc.h:30-599) ---------------------------------------------------------------

@@ -169,6 +169,7 @@ int run_prestitch(const std::vector<std::string> &args, int width)
         if (doRRC) stt.DoRRC();
         stt.PreStitch(p.flag.count("--fp16-accumulate") != 0);      // not in the reference: BASELINE config 5's resampling variant
     }
+    stt.Finish();                                                   // the products' writer threads
     return 0;
 }
 

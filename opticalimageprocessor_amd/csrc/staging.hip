@@ -17,7 +17,7 @@
 // context.  Three lanes, each serialised by its own mutex (a second caller of the same lane waits):
 //   ring lane      oip_read_file_to_device, oip_upload_staged, oip_rrc_u16_host
 //                  (four pinned slots; stream `stream`, oip_rrc_u16_host also `rrc_stream`)
-//   download lanes oip_download_staged[_after], oip_write_device_to_file[_at] (two lanes of two pinned slots and a stream each:
+//   download lanes oip_download_staged[_after], oip_write_device_to_file[_at] (three lanes of two pinned slots and a stream each:
 //                  a call takes a free one, so two products can go out at the same time)
 // so a reader thread and a writer thread run full duplex beside the compute thread.  The state is created once under a lock.
 // A call returns a TICKET; oip_stage_wait(ctx, ticket) makes the compute stream wait -- on the device, not the
@@ -231,8 +231,8 @@ struct oip_stage_state {
     hipEvent_t ticket_ev[kTicketRing];
     hipEvent_t compute_ev = nullptr;        // marks the compute stream's position for uploads
     // the download lanes: each its own two slots, stream and event, so that a download or a file write on one host thread
-    // and an upload on another never touch the same state (full duplex over the link); two of them, so that two products
-    // (different files: writers of ONE file serialise in the kernel anyway) can be written at the same time
+    // and an upload on another never touch the same state (full duplex over the link); three of them, so that the
+    // three strip-sized products of `prestitch` (different files: writers of ONE file serialise in the kernel anyway) go out at once
     struct DownLane {
         std::mutex mu;
         hipStream_t stream = nullptr;
@@ -242,7 +242,7 @@ struct oip_stage_state {
         bool slot_used[2] = {false, false};
         int next = 0;
         hipEvent_t compute_ev = nullptr;
-    } down[2];
+    } down[3];
     // marks of the compute stream (oip_compute_mark): taken by the compute thread, waited for by the download lane
     hipEvent_t mark_ev[kTicketRing];
     std::atomic<long> mark{0};
@@ -269,6 +269,7 @@ static int stage_init(oip_ctx *ctx)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->down[0].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->down[1].stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->down[2].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->rrc_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
     for (int i = 0; i < kSlots; ++i) {
         if (!pinned_alloc(&s->slot_mem[i], kSlotBytes) ||
@@ -283,7 +284,8 @@ static int stage_init(oip_ctx *ctx)
             hipEventCreateWithFlags(&s->mark_ev[i], hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
     if (hipEventCreateWithFlags(&s->compute_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->down[0].compute_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->down[1].compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
+        hipEventCreateWithFlags(&s->down[1].compute_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->down[2].compute_ev, hipEventDisableTiming) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging events"); }
     // (the download lanes pin their slots on first use -- down_lane_ready: a reader that never writes does not pay for them,
     // and a writer thread pins its own while the reader is already moving data)
     for (auto &d : s->down)
@@ -478,9 +480,10 @@ struct DownLaneLock {
     oip_stage_state::DownLane *d;
     explicit DownLaneLock(oip_stage_state *s)
     {
-        if (s->down[0].mu.try_lock()) d = &s->down[0];
-        else if (s->down[1].mu.try_lock()) d = &s->down[1];
-        else { s->down[0].mu.lock(); d = &s->down[0]; }
+        d = nullptr;
+        for (auto &l : s->down)
+            if (l.mu.try_lock()) { d = &l; break; }
+        if (!d) { s->down[0].mu.lock(); d = &s->down[0]; }
     }
     ~DownLaneLock() { d->mu.unlock(); }
 };

@@ -993,6 +993,8 @@ public:
         productGuard.path = alignedPath;
         JobThread panWriter, productWriter;
         const size_t productBytes = (size_t)outRows * Wb * MSS_BANDS * 2;
+        // (an empty transfer: the writer's download lane pins its two slots now, not when the product is waiting for them)
+        productWriter.post([=] { Device::get().check(oip_download_staged_after(ctx, nullptr, nullptr, 0, 0)); });
         if (comp == TIFF_NONE) {
             // the writer thread has nothing to do until the fit is in: it prepares the product file -- header out, blocks
             // reserved, pages mapped and populated (oip_file_sink_open) -- so that the pixels, when they exist, are copied

@@ -271,24 +271,15 @@ static int stage_init(oip_ctx *ctx)
         hipStreamCreateWithFlags(&s->down[1].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->down[2].stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->rrc_stream, hipStreamNonBlocking) != hipSuccess) { delete s; return oip_fail(ctx, OIP_E_DEVICE, "staging stream"); }
-    {
-        // the four slots are pinned side by side (a thread each: faulting the pages in and registering them is the 30-60 ms a
-        // fresh process waits before its first byte moves)
-        bool ok[kSlots];
-        const int dev = ctx->device;
-        std::vector<std::thread> th;
-        for (int i = 1; i < kSlots; ++i)
-            th.emplace_back([s, i, dev, &ok] { ok[i] = hipSetDevice(dev) == hipSuccess && pinned_alloc(&s->slot_mem[i], kSlotBytes); });
-        ok[0] = pinned_alloc(&s->slot_mem[0], kSlotBytes);
-        for (auto &t : th) t.join();
-        for (int i = 0; i < kSlots; ++i) {
-            if (!ok[i] || hipEventCreateWithFlags(&s->slot_free[i], hipEventDisableTiming) != hipSuccess) {
-                for (int j = 0; j < kSlots; ++j) if (ok[j]) pinned_free(&s->slot_mem[j]);
-                delete s;
-                return oip_fail(ctx, OIP_E_NOMEM, "pinned staging ring (%d x %zu MiB) failed", kSlots, kSlotBytes >> 20);
-            }
-            s->slot[i] = s->slot_mem[i].p;
+    // (pinning the four slots on a thread each was measured: the same 33 ms through huge pages, 59-128 ms instead of 43-65
+    // through hipHostMalloc -- the registration serialises in the driver)
+    for (int i = 0; i < kSlots; ++i) {
+        if (!pinned_alloc(&s->slot_mem[i], kSlotBytes) ||
+            hipEventCreateWithFlags(&s->slot_free[i], hipEventDisableTiming) != hipSuccess) {
+            delete s;
+            return oip_fail(ctx, OIP_E_NOMEM, "pinned staging ring (%d x %zu MiB) failed", kSlots, kSlotBytes >> 20);
         }
+        s->slot[i] = s->slot_mem[i].p;
     }
     for (int i = 0; i < kTicketRing; ++i)
         if (hipEventCreateWithFlags(&s->ticket_ev[i], hipEventDisableTiming) != hipSuccess ||

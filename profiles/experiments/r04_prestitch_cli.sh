@@ -1,6 +1,5 @@
 # round 4: wall time of `oip prestitch` on two 30000 x 100000 strips in tmpfs (products: 3 x 6 GB on writer threads, one download
 # lane each); the log's own lines tell how long each product took, the script how long the command took
-set -e
 D=/dev/shm/oip_prestitch
 rm -rf $D; mkdir -p $D
 python - <<'PY'
@@ -22,6 +21,7 @@ for i in 1 2; do
   s=$(date +%s.%N)
   LOGFILE=$D/oip.log $R/opticalimageprocessor_amd/lib/oip prestitch --width 30000 --pan1 C_PAN-1.RAW --pan2 C_PAN-2.RAW --rrc1 P1.csv --rrc2 P2.csv > run$i.log 2>&1
   e=$(date +%s.%N)
+  echo "exit code $?"; tail -3 run$i.log
   python3 -c "print('run $i: wall %.3f s' % ($e - $s))"
   grep -E "bytes written|processed & written|bytes read|dx:" run$i.log
   ls -la *.RRC.RAW *.PRESTT.RAW | awk '{print $5, $9}'

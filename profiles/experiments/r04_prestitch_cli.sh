@@ -19,7 +19,7 @@ cd $D
 for i in 1 2; do
   rm -f *.RRC.RAW *.PRESTT.RAW
   s=$(date +%s.%N)
-  LOGFILE=$D/oip.log $R/opticalimageprocessor_amd/lib/oip prestitch --width 30000 --pan1 C_PAN-1.RAW --pan2 C_PAN-2.RAW --rrc1 P1.csv --rrc2 P2.csv > run$i.log 2>&1
+  LOGFILE=$D/oip.log $R/opticalimageprocessor_amd/lib/oip prestitch --width 30000 --pan1 C_PAN-1.RAW --pan2 C_PAN-2.RAW --rrc1 P1.csv --rrc2 P2.csv -s 6 > run$i.log 2>&1
   e=$(date +%s.%N)
   echo "exit code $?"; tail -3 run$i.log
   python3 -c "print('run $i: wall %.3f s' % ($e - $s))"

@@ -2,7 +2,7 @@
 //
 // `oip --gpus N ...` (default action, BASELINE config 4) and `oip prestitch --gpus N ...` (cross-CCD path,
 // BASELINE config 5).  One process, one host thread and one oip_ctx per GPU, one RCCL communicator per GPU
-// (ncclCommInitAll); librccl is linked into the CLI only, never into liboipgpu.so.  The strip is cut into
+// (ncclCommInitAll); librccl is loaded by the first --gpus run (dlopen, below): neither the CLI nor liboipgpu.so links it.  The strip is cut into
 // scan-line blocks: rank r owns lines [r L/N, (r+1) L/N) of every raster and reads exactly those
 // bytes of the input files.  Three exchange steps, none of them a reduction over pixels -- the same plan as
 // opticalimageprocessor_amd/dist.py, whose gloo tests check it against the single-process result bit for bit;

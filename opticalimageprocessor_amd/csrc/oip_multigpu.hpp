@@ -34,9 +34,11 @@
 #include "oip_host.hpp"
 #include "oip_rankguard.hpp"
 
-// RCCL is loaded when the first --gpus run asks for it, not with the executable: librccl.so is 570 MB of code objects for
-// every architecture, and mapping, relocating and registering it costs every single-GPU `oip` run its start-up time
-// (measured: DESIGN.md 4.5).  Types come from <rccl/rccl.h>; the entry points are resolved from librccl.so.1 on first use.
+// RCCL is loaded when the first --gpus run asks for it, not with the executable: a single-GPU `oip` run then depends on
+// libamdhip64 alone (what liboipgpu.so depends on), and a machine without RCCL can still run it.  It is not a start-up
+// optimisation: an executable linked against the 570 MB librccl.so starts in 13.8 ms, this one in 12.5 ms
+// (profiles/experiments/rccl_link_probe, `--version`, best of five each).  Types come from <rccl/rccl.h>; the entry points
+// are resolved from librccl.so.1 on first use.
 namespace OIPGPU {
 struct RcclApi {
     decltype(&::ncclCommInitAll) CommInitAll;

@@ -193,39 +193,52 @@ struct AlignFix {
     int group, band, ra, rb;
 };
 
-__device__ __forceinline__ void align_load_raw6(const uint16_t *__restrict__ pl, long row, int Wb, int c0, long nelem, uint32_t w[6])
+// Six dwords = the 11 samples a lane's 8 pixels tap on one source line (12 with the sample in front of an odd first column).
+// `lane_base` is the lane's plane advanced to the dword of its first column; widths are even, so a line is a whole number of
+// dwords and the address is one 64-bit multiply-add with the six loads at immediate offsets.  A REGULAR group's window ends
+// inside its own line (ix0 + 11 < Wb below), so no dword can leave the buffer and nothing is clamped: the clamped form this
+// replaces made the compiler carry six separate 64-bit addresses through the merge of its two branches (a fifth of the
+// kernel's vector instructions, and the kernel is bound by their issue rate -- DESIGN 4.1).
+__device__ __forceinline__ void align_load_raw6(const uint32_t *__restrict__ lane_base, long row, int half_pitch, uint32_t w[6])
 {
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(pl);
-    const long e0 = row * Wb + c0;
-    const long d0 = e0 >> 1;
-    if (row >= 0 && (row + 2) * Wb <= nelem) {
-        // every line but the last of the buffer (uniform over the wave: the line comes from the row table and the section base):
-        // the six dwords end inside the next line at the latest -- one 64-bit address and six immediate offsets instead of a
-        // 64-bit add, a compare and two selects per dword (what remap.hip's load_raw6 dropped in round 3: a quarter of that
-        // kernel's vector instructions)
-        const uint32_t *q = p32 + d0;
+    const uint32_t *q = lane_base + row * half_pitch;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = q[i];
-        return;
-    }
-    const long dmax = (nelem - 1) >> 1;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        long di = d0 + i;
-        di = di < 0 ? 0 : (di > dmax ? dmax : di);
-        w[i] = p32[di];
-    }
+    for (int i = 0; i < 6; ++i) w[i] = q[i];
 }
-__device__ __forceinline__ void align_expand(const uint32_t w[6], bool odd, float g[11])
+typedef float oip_f2 __attribute__((ext_vector_type(2)));
+
+// The window of a lane as PAIRS of samples: P[i] = (s[2i], s[2i+1]) in one even-aligned register pair, which is what the packed
+// f32 instructions of gfx950 (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of arithmetic per issue slot) take as an operand.
+__device__ __forceinline__ void align_expand(const uint32_t w[6], bool odd, oip_f2 P[6])
 {
     // samples start at the low half of w[0] for an even first column, at its high half for an odd one: bring the
     // odd case to the even layout with one funnel shift per dword, then one conversion per sample
+    const unsigned sh = odd ? 16u : 0u;
     uint32_t e[6];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) e[i] = odd ? __builtin_amdgcn_alignbit(w[i + 1], w[i], 16) : w[i];
-    e[5] = odd ? (w[5] >> 16) : w[5];
+    for (int i = 0; i < 5; ++i) e[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
+    e[5] = w[5] >> sh;
 #pragma unroll
-    for (int q = 0; q < 11; ++q) g[q] = (q & 1) ? (float)(e[q >> 1] >> 16) : (float)(e[q >> 1] & 0xffffu);
+    for (int i = 0; i < 6; ++i) { P[i].x = (float)(e[i] & 0xffffu); P[i].y = (float)(e[i] >> 16); }
+}
+
+// 8 output pixels of one band as 4 pairs: pixel pair m = (2m, 2m+1) needs the taps (s[2m+kx], s[2m+1+kx]), kx = 0..3 -- the
+// aligned pairs P[m], P[m+1] for kx = 0, 2 and the straddling pairs Q[m] = (P[m].y, P[m+1].x), Q[m+1] for kx = 1, 3 (one
+// v_pk_mov each).  Per pair and tap row 4 packed multiplies and 3 packed adds, each half in oip_bicubic_interior's order:
+// products rounded, row sum left to right, rows added in order (-ffp-contract=off keeps the compiler from fusing them).
+__device__ __forceinline__ void align_row_taps(const oip_f2 P[6], const float *w4, bool first, oip_f2 sum[4])
+{
+    oip_f2 Q[5];
+#pragma unroll
+    for (int m = 0; m < 5; ++m) { Q[m].x = P[m].y; Q[m].y = P[m + 1].x; }
+    const oip_f2 w0 = {w4[0], w4[0]}, w1 = {w4[1], w4[1]}, w2 = {w4[2], w4[2]}, w3 = {w4[3], w4[3]};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        oip_f2 rr = P[m] * w0 + Q[m] * w1;
+        rr = rr + P[m + 1] * w2;
+        rr = rr + Q[m + 1] * w3;
+        sum[m] = first ? rr : sum[m] + rr;
+    }
 }
 
 __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
@@ -244,7 +257,6 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
     if (r1 > out_rows) r1 = out_rows;
     const bool live = x0 < Wb;                    // lanes past the line end still take part in the exchanges
     const uint16_t *pl = planes + (size_t)b * plane_stride;
-    const long nelem = src_rows * (long)Wb;
 
     // x maps of the 8 pixels (preproc.h:447), fp64 left to right, and the column part of the y maps
     OIP_BAND_COEF(bc, co, b)
@@ -274,15 +286,17 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
             prev = c4;
             if (j == 7) c4_last = c4;
         }
-        xreg = xreg && mono && ix0 >= 0 && ix0 + 10 < Wb;
+        xreg = xreg && mono && ix0 >= 0 && ix0 + 11 < Wb;      // + 11: the sixth dword of an even first column stays in the line
     }
     const int c0 = xreg ? ix0 : 0;
     const bool odd = c0 & 1;
+    const uint32_t *lane_base = reinterpret_cast<const uint32_t *>(pl) + (c0 >> 1);
+    const int half_pitch = Wb >> 1;
     float wx[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
-    float win[4][11];
+    oip_f2 win[4][6];
     float w2d[16];
     uint32_t nraw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     long nline = -1;                 // global plane line whose raw dwords are in nraw (-1: none)
@@ -309,15 +323,15 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
                     if (slide) {
                         // rotate: this unrolled step's slot order is (k + t) & 3
                         if (nline == l0 + 3) align_expand(nraw, odd, win[(k + 3) & 3]);
-                        else { uint32_t w[6]; align_load_raw6(pl, l0 + 3, Wb, c0, nelem, w); align_expand(w, odd, win[(k + 3) & 3]); }
+                        else { uint32_t w[6]; align_load_raw6(lane_base, l0 + 3, half_pitch, w); align_expand(w, odd, win[(k + 3) & 3]); }
                     } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) { uint32_t w[6]; align_load_raw6(pl, l0 + t, Wb, c0, nelem, w); align_expand(w, odd, win[(k + t) & 3]); }
+                        for (int t = 0; t < 4; ++t) { uint32_t w[6]; align_load_raw6(lane_base, l0 + t, half_pitch, w); align_expand(w, odd, win[(k + t) & 3]); }
                     }
                     cur_base = a.base; cur_iy = iy;
                     // next line's newest source line, in flight under this line's sums
                     nline = l0 + 4;
-                    if (nline < src_rows) align_load_raw6(pl, nline, Wb, c0, nelem, nraw); else nline = -1;
+                    if (nline < src_rows) align_load_raw6(lane_base, nline, half_pitch, nraw); else nline = -1;
                     if (fy != cur_fy) {
                         cur_fy = fy;
 #pragma unroll
@@ -327,19 +341,11 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
                             for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
                         }
                     }
+                    oip_f2 sum[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float sum = 0.f;
+                    for (int t = 0; t < 4; ++t) align_row_taps(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float *L = win[(k + t) & 3];
-                            float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
-                            sum = t == 0 ? rr : __fadd_rn(sum, rr);
-                        }
-                        out[j] = oip_sat_u16(sum);
-                    }
+                    for (int m = 0; m < 4; ++m) { out[2 * m] = oip_sat_u16(sum[m].x); out[2 * m + 1] = oip_sat_u16(sum[m].y); }
                 } else {
                     // the slot rotation of the unrolled loop assumes one slide per step: a skipped line breaks it
                     cur_iy = INT_MIN;

@@ -205,42 +205,6 @@ __device__ __forceinline__ void align_load_raw6(const uint32_t *__restrict__ lan
 #pragma unroll
     for (int i = 0; i < 6; ++i) w[i] = q[i];
 }
-typedef float oip_f2 __attribute__((ext_vector_type(2)));
-
-// The window of a lane as PAIRS of samples: P[i] = (s[2i], s[2i+1]) in one even-aligned register pair, which is what the packed
-// f32 instructions of gfx950 (v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of arithmetic per issue slot) take as an operand.
-__device__ __forceinline__ void align_expand(const uint32_t w[6], bool odd, oip_f2 P[6])
-{
-    // samples start at the low half of w[0] for an even first column, at its high half for an odd one: bring the
-    // odd case to the even layout with one funnel shift per dword, then one conversion per sample
-    const unsigned sh = odd ? 16u : 0u;
-    uint32_t e[6];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) e[i] = __builtin_amdgcn_alignbit(w[i + 1], w[i], sh);
-    e[5] = w[5] >> sh;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { P[i].x = (float)(e[i] & 0xffffu); P[i].y = (float)(e[i] >> 16); }
-}
-
-// 8 output pixels of one band as 4 pairs: pixel pair m = (2m, 2m+1) needs the taps (s[2m+kx], s[2m+1+kx]), kx = 0..3 -- the
-// aligned pairs P[m], P[m+1] for kx = 0, 2 and the straddling pairs Q[m] = (P[m].y, P[m+1].x), Q[m+1] for kx = 1, 3 (one
-// v_pk_mov each).  Per pair and tap row 4 packed multiplies and 3 packed adds, each half in oip_bicubic_interior's order:
-// products rounded, row sum left to right, rows added in order (-ffp-contract=off keeps the compiler from fusing them).
-__device__ __forceinline__ void align_row_taps(const oip_f2 P[6], const float *w4, bool first, oip_f2 sum[4])
-{
-    oip_f2 Q[5];
-#pragma unroll
-    for (int m = 0; m < 5; ++m) { Q[m].x = P[m].y; Q[m].y = P[m + 1].x; }
-    const oip_f2 w0 = {w4[0], w4[0]}, w1 = {w4[1], w4[1]}, w2 = {w4[2], w4[2]}, w3 = {w4[3], w4[3]};
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        oip_f2 rr = P[m] * w0 + Q[m] * w1;
-        rr = rr + P[m + 1] * w2;
-        rr = rr + Q[m + 1] * w3;
-        sum[m] = first ? rr : sum[m] + rr;
-    }
-}
-
 __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *__restrict__ planes, size_t plane_stride,
                                                                long src_rows, uint16_t *__restrict__ dst,
                                                                const AlignRow *__restrict__ rows, int Wb, long out_rows,
@@ -296,7 +260,7 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
-    oip_f2 win[4][6];
+    oip_f2 win[4][7];
     float w2d[16];
     uint32_t nraw[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     long nline = -1;                 // global plane line whose raw dwords are in nraw (-1: none)
@@ -310,7 +274,7 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
             const long r = rb + k;
             if (r >= r1) break;
             const AlignRow a = rows[oip_uniform(r)];
-            unsigned out[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            uint4 px = make_uint4(0u, 0u, 0u, 0u);            // the band's 8 pixels of this line, 16 bytes in pixel order
             if (a.valid) {                                    // uniform over the wave
                 const double yrel = (double)a.yrel;
                 const int sy0 = oip_cvround((float)__dadd_rn(c4_first, yrel) * 32.0f);
@@ -322,11 +286,11 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
                     const bool slide = a.base == cur_base && iy == cur_iy + 1;
                     if (slide) {
                         // rotate: this unrolled step's slot order is (k + t) & 3
-                        if (nline == l0 + 3) align_expand(nraw, odd, win[(k + 3) & 3]);
-                        else { uint32_t w[6]; align_load_raw6(lane_base, l0 + 3, half_pitch, w); align_expand(w, odd, win[(k + 3) & 3]); }
+                        if (nline == l0 + 3) oip_expand_pairs(nraw, odd, win[(k + 3) & 3]);
+                        else { uint32_t w[6]; align_load_raw6(lane_base, l0 + 3, half_pitch, w); oip_expand_pairs(w, odd, win[(k + 3) & 3]); }
                     } else {
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) { uint32_t w[6]; align_load_raw6(lane_base, l0 + t, half_pitch, w); align_expand(w, odd, win[(k + t) & 3]); }
+                        for (int t = 0; t < 4; ++t) { uint32_t w[6]; align_load_raw6(lane_base, l0 + t, half_pitch, w); oip_expand_pairs(w, odd, win[(k + t) & 3]); }
                     }
                     cur_base = a.base; cur_iy = iy;
                     // next line's newest source line, in flight under this line's sums
@@ -343,9 +307,8 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
                     }
                     oip_f2 sum[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) align_row_taps(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { out[2 * m] = oip_sat_u16(sum[m].x); out[2 * m + 1] = oip_sat_u16(sum[m].y); }
+                    for (int t = 0; t < 4; ++t) oip_row_taps8(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
+                    px = oip_sat_pack8(sum);
                 } else {
                     // the slot rotation of the unrolled loop assumes one slide per step: a skipped line breaks it
                     cur_iy = INT_MIN;
@@ -356,7 +319,7 @@ __global__ __launch_bounds__(kBlock, 3) void align_mss8_kernel(const uint16_t *_
             }
             // d[j] = this band's pixels 2j, 2j+1; transpose over the four 16-lane rows, then lane (row r, group g)
             // holds pixels 2r, 2r+1 of group g for all four bands
-            uint32_t d0 = out[0] | (out[1] << 16), d1 = out[2] | (out[3] << 16), d2 = out[4] | (out[5] << 16), d3 = out[6] | (out[7] << 16);
+            uint32_t d0 = px.x, d1 = px.y, d2 = px.z, d3 = px.w;
             {
                 auto s02 = __builtin_amdgcn_permlane32_swap(d0, d2, false, false);
                 auto s13 = __builtin_amdgcn_permlane32_swap(d1, d3, false, false);
@@ -533,7 +496,8 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
                       (((uintptr_t)d_planes) & 3) == 0 && (plane_stride % 2) == 0 && src_rows * (long)Wb >= 16;
     const int groups = (Wb + 7) / 8;
     int gx = (groups + 63) / 64;                                  // 4 waves x 16 groups per workgroup
-    long want = (long)ctx->cu_count * 16 / gx;
+    static const char *tune = getenv("OIP_TUNE_WG_PER_CU");
+    long want = (long)ctx->cu_count * (tune && atoi(tune) > 0 ? atoi(tune) : 16) / gx;
     if (want < 1) want = 1;
     long rpb = (out_rows + want - 1) / want;
     if (rpb < 32) rpb = 32;

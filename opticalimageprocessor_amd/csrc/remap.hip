@@ -196,7 +196,9 @@ __host__ __device__ inline bool shift_group_regular(int x0, int W, double dx, in
     }
     *ix0_out = ix0;
     *fx0_out = fx0;
-    return regular && ix0 >= 0 && ix0 + 10 < W;      // every tap of every pixel inside the image in x
+    // every tap of every pixel inside the image in x; + 11 (not + 10): the sixth dword a lane reads from an even first column
+    // ends one sample past its last tap, and with it inside the line no load of a regular group can leave the buffer
+    return regular && ix0 >= 0 && ix0 + 11 < W;
 }
 
 // One source line of a lane = 11 consecutive u16 = 6 dwords from a 4-byte aligned address.  The load is split
@@ -204,47 +206,16 @@ __host__ __device__ inline bool shift_group_regular(int x0, int W, double dx, in
 // line's 16-tap sums, so twice the bytes are in flight per wave (these kernels are bound by memory-level
 // parallelism: 1 KiB per wave and line, 16-24 waves per CU, against ~35 KiB per CU that the latency-bandwidth
 // product of HBM asks for).
-__device__ __forceinline__ void load_raw6(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem, uint32_t w[6])
+__device__ __forceinline__ void load_raw6(const uint32_t *__restrict__ lane_base, int row, int half_pitch, uint32_t w[6])
 {
-    // c0: source column of tap 0 of pixel 0 (>= 0).  6 dwords from the dword holding it.
-    const uint32_t *p32 = reinterpret_cast<const uint32_t *>(src);
-    const long e0 = (long)row * W + c0;           // W even: parity of e0 == parity of c0
-    const long d0 = e0 >> 1;
-    if ((long)(row + 2) * W <= nelem) {
-        // every line but the last of the buffer (uniform: the line comes from the row table): the six dwords end inside the
-        // next line at the latest -- one 64-bit address and six immediate offsets.  Clamping every dword index cost a 64-bit
-        // add, a 64-bit compare and two selects per dword: a quarter of the kernel's vector instructions, and the kernel is
-        // bound by them (round 3: 708 -> 530 per line and wave)
-        const uint32_t *q = p32 + d0;
+    // lane_base: the dword holding the lane's first tap column on line 0 (W is even: a line is half_pitch dwords).  A regular
+    // group's six dwords stay inside its line (shift_group_regular), so the address is one 64-bit multiply-add with six
+    // immediate offsets and nothing is clamped.  Round 3 had dropped the per-dword clamps for all lines but the buffer's last
+    // (708 -> 530 vector instructions per line and wave); the remaining two-branch form still made the compiler carry six
+    // 64-bit addresses through the merge (84 v_lshl_add_u64 per line).
+    const uint32_t *q = lane_base + (long)row * half_pitch;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = q[i];
-        return;
-    }
-    const long dmax = (nelem - 1) >> 1;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        long di = d0 + i;
-        w[i] = p32[di > dmax ? dmax : di];
-    }
-}
-
-__device__ __forceinline__ void expand_f32(const uint32_t w[6], int c0, float g[11])
-{
-    if (c0 & 1) {
-#pragma unroll
-        for (int q = 0; q < 11; ++q) g[q] = ((q + 1) & 1) ? (float)(w[(q + 1) >> 1] >> 16) : (float)(w[(q + 1) >> 1] & 0xffffu);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 11; ++q) g[q] = (q & 1) ? (float)(w[q >> 1] >> 16) : (float)(w[q >> 1] & 0xffffu);
-    }
-}
-
-__device__ __forceinline__ void load_src_line11(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
-                                                float g[11])
-{
-    uint32_t w[6];
-    load_raw6(src, row, W, c0, nelem, w);
-    expand_f32(w, c0, g);
+    for (int i = 0; i < 6; ++i) w[i] = q[i];
 }
 
 __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
@@ -263,7 +234,10 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
-    float win[4][11];                             // tap line t at unrolled step k lives in win[(k+t)&3]
+    const uint32_t *lane_base = reinterpret_cast<const uint32_t *>(src) + (c0 >> 1);
+    const int half_pitch = W >> 1;
+    const bool odd = c0 & 1;
+    oip_f2 win[4][7];                             // tap line t at unrolled step k lives in win[(k+t)&3], as sample pairs
     float w2d[16];
     int cur1 = -2, cur2 = -2, cur3 = -2;
     int cur_fy = -1;
@@ -278,18 +252,18 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
             if (ri.flags != 1) { cur1 = cur2 = cur3 = -2; continue; }      // fix-up launch B
             const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
             if (slide) {
-                if (ri.src[3] == nline) expand_f32(nraw, c0, win[(k + 3) & 3]);
-                else load_src_line11(src, ri.src[3], W, c0, src_elems, win[(k + 3) & 3]);
+                if (ri.src[3] == nline) oip_expand_pairs(nraw, odd, win[(k + 3) & 3]);
+                else { uint32_t w[6]; load_raw6(lane_base, ri.src[3], half_pitch, w); oip_expand_pairs(w, odd, win[(k + 3) & 3]); }
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) load_src_line11(src, ri.src[t], W, c0, src_elems, win[(k + t) & 3]);
+                for (int t = 0; t < 4; ++t) { uint32_t w[6]; load_raw6(lane_base, ri.src[t], half_pitch, w); oip_expand_pairs(w, odd, win[(k + t) & 3]); }
             }
             cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
             // the line the next output line will add in the regular case (its taps one line further down)
             nline = -2;
             if (r + 1 < r1 && (long)(ri.src[3] + 1) * W < src_elems) {
                 nline = ri.src[3] + 1;
-                load_raw6(src, nline, W, c0, src_elems, nraw);
+                load_raw6(lane_base, nline, half_pitch, nraw);
             }
             if (ri.fy != cur_fy) {
                 cur_fy = ri.fy;
@@ -300,31 +274,22 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_kernel(const uint16_t 
                     for (int kx = 0; kx < 4; ++kx) w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
                 }
             }
-            unsigned out[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float sum = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float *L = win[(k + t) & 3];
-                    float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
-                    rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
-                    rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
-                    sum = t == 0 ? rr : __fadd_rn(sum, rr);
-                }
-                out[j] = oip_sat_u16(sum);
-            }
             uint4 o;
-            o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-            o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+            {
+                oip_f2 sum[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) oip_row_taps8(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
+                o = oip_sat_pack8(sum);
+            }
             uint16_t *drow = dst + r * dw.pitch + x0 + dw.shift;
             if (x0 >= dw.col0 && dw.vec) {
                 *reinterpret_cast<uint4 *>(drow) = o;
             } else {
                 // the group that straddles col0, or a destination whose 16-byte stores would be misaligned
+                const unsigned d[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
             }
         }
     }
@@ -400,11 +365,11 @@ __device__ __forceinline__ void expand_h(const uint32_t w[6], int c0, oip_h2 E[6
     }
     E[5] = H[5];        // only its first half is ever used (sample 10), and only for even c0; odd c0 never reads E[5]
 }
-__device__ __forceinline__ void load_src_line11_h(const uint16_t *__restrict__ src, int row, int W, int c0, long nelem,
+__device__ __forceinline__ void load_src_line11_h(const uint32_t *__restrict__ lane_base, int row, int half_pitch, int c0,
                                                   oip_h2 E[6], oip_h2 O[5])
 {
     uint32_t w[6];
-    load_raw6(src, row, W, c0, nelem, w);
+    load_raw6(lane_base, row, half_pitch, w);
     expand_h(w, c0, E, O);
 }
 
@@ -424,6 +389,8 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
 #pragma unroll
     for (int j = 0; j < 4; ++j) wx[j] = tab1d[fx0 * 4 + j];
 
+    const uint32_t *lane_base = reinterpret_cast<const uint32_t *>(src) + (c0 >> 1);
+    const int half_pitch = W >> 1;
     oip_h2 E[4][6], O[4][5];                      // tap line t at unrolled step k lives in slot (k+t)&3
     oip_h2 w2d[16];
     int cur1 = -2, cur2 = -2, cur3 = -2;
@@ -440,16 +407,16 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
             const bool slide = cur1 != -2 && ri.src[0] == cur1 && ri.src[1] == cur2 && ri.src[2] == cur3;
             if (slide) {
                 if (ri.src[3] == nline) expand_h(nraw, c0, E[(k + 3) & 3], O[(k + 3) & 3]);
-                else load_src_line11_h(src, ri.src[3], W, c0, src_elems, E[(k + 3) & 3], O[(k + 3) & 3]);
+                else load_src_line11_h(lane_base, ri.src[3], half_pitch, c0, E[(k + 3) & 3], O[(k + 3) & 3]);
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) load_src_line11_h(src, ri.src[t], W, c0, src_elems, E[(k + t) & 3], O[(k + t) & 3]);
+                for (int t = 0; t < 4; ++t) load_src_line11_h(lane_base, ri.src[t], half_pitch, c0, E[(k + t) & 3], O[(k + t) & 3]);
             }
             cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
             nline = -2;
             if (r + 1 < r1 && (long)(ri.src[3] + 1) * W < src_elems) {
                 nline = ri.src[3] + 1;
-                load_raw6(src, nline, W, c0, src_elems, nraw);
+                load_raw6(lane_base, nline, half_pitch, nraw);
             }
             if (ri.fy != cur_fy) {
                 cur_fy = ri.fy;
@@ -545,7 +512,7 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
 
     auto body = [&](auto safe_tag) __attribute__((always_inline)) {
     constexpr bool SAFE = decltype(safe_tag)::value;
-    float win[F16 ? 1 : 4][11];                   // tap line t at unrolled step k lives in slot (k+t)&3
+    oip_f2 win[F16 ? 1 : 4][7];                   // tap line t at unrolled step k lives in slot (k+t)&3, as sample pairs
     oip_h2 E[F16 ? 4 : 1][6], O[F16 ? 4 : 1][5];
     typename std::conditional<F16, oip_h2, float>::type w2d[16];
     int p = 0;
@@ -566,7 +533,7 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
 #pragma unroll
             for (int i = 0; i < 6; ++i) w[i] = lds[p][d0 + i];
             if constexpr (F16) expand_h(w, c0, E[slot], O[slot]);
-            else expand_f32(w, c0, win[slot]);
+            else oip_expand_pairs(w, c0 & 1, win[slot]);
         }
         p ^= 1;
     };
@@ -624,8 +591,9 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
                         }
                     }
                 }
-                unsigned out[8];
+                uint4 o;
                 if constexpr (F16) {
+                    unsigned out[8];
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
                         oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
@@ -640,31 +608,22 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
                         out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
                         out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
                     }
+                    o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+                    o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
                 } else {
+                    oip_f2 sum[4];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float *L = win[(k + t) & 3];
-                            float rr = __fadd_rn(__fmul_rn(L[j], w2d[t * 4 + 0]), __fmul_rn(L[j + 1], w2d[t * 4 + 1]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 2], w2d[t * 4 + 2]));
-                            rr = __fadd_rn(rr, __fmul_rn(L[j + 3], w2d[t * 4 + 3]));
-                            sum = t == 0 ? rr : __fadd_rn(sum, rr);
-                        }
-                        out[j] = oip_sat_u16(sum);
-                    }
+                    for (int t = 0; t < 4; ++t) oip_row_taps8(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
+                    o = oip_sat_pack8(sum);
                 }
-                uint4 o;
-                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
                 uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
                 if (x0 >= dw.col0 && dw.vec) {
                     *reinterpret_cast<uint4 *>(drow) = o;
                 } else {
+                    const unsigned d[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
                 }
             }
         }
@@ -842,7 +801,9 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_bicubic_u16: too many section-border lines");
     if (v8) {
         int gx = lds ? (W / 8 + kLdsOut - 1) / kLdsOut : (W / 8 + kBlock - 1) / kBlock;
-        long want = (long)ctx->cu_count * (lds ? 12 : 16) / gx;      // 12..96 (RRC form), 16..48 (plain): the step takes the same time
+        static const char *tune = getenv("OIP_TUNE_WG_PER_CU");
+        const int per_cu = tune && atoi(tune) > 0 ? atoi(tune) : (lds ? 12 : 16);
+        long want = (long)ctx->cu_count * per_cu / gx;      // 12..96 (RRC form), 16..48 (plain): the step takes the same time
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
         if (rpb < 32) rpb = 32;

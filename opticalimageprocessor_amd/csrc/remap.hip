@@ -512,121 +512,141 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
 
     auto body = [&](auto safe_tag) __attribute__((always_inline)) {
     constexpr bool SAFE = decltype(safe_tag)::value;
-    oip_f2 win[F16 ? 1 : 4][7];                   // tap line t at unrolled step k lives in slot (k+t)&3, as sample pairs
+    oip_f2 win[F16 ? 1 : 4][7];                   // tap line t at step k of a quad lives in slot (k+t)&3, as sample pairs
     oip_h2 E[F16 ? 4 : 1][6], O[F16 ? 4 : 1][5];
     typename std::conditional<F16, oip_h2, float>::type w2d[16];
-    int p = 0;
     auto fetch = [&](long row) __attribute__((always_inline)) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (chunk_ok && row >= 0 && row < src_lines) v = *reinterpret_cast<const uint4 *>(src + row * W + cc);
         return v;
     };
-    auto stage = [&](uint4 v, int slot) __attribute__((always_inline)) {
+    // correct the lane's chunk, put it into LDS buffer `buf`, and after the barrier read the lane's 11 samples into window slot
+    // `slot`.  Both indices are compile-time constants at every call (see the buffer rule at `prime`).
+    auto stage = [&](uint4 v, int slot, int buf) __attribute__((always_inline)) {
         v.x = rrc_px_t<SAFE>(q[0].x, q[0].y, v.x & 0xffffu) | (rrc_px_t<SAFE>(q[1].x, q[1].y, v.x >> 16) << 16);
         v.y = rrc_px_t<SAFE>(q[2].x, q[2].y, v.y & 0xffffu) | (rrc_px_t<SAFE>(q[3].x, q[3].y, v.y >> 16) << 16);
         v.z = rrc_px_t<SAFE>(q[4].x, q[4].y, v.z & 0xffffu) | (rrc_px_t<SAFE>(q[5].x, q[5].y, v.z >> 16) << 16);
         v.w = rrc_px_t<SAFE>(q[6].x, q[6].y, v.w & 0xffffu) | (rrc_px_t<SAFE>(q[7].x, q[7].y, v.w >> 16) << 16);
-        reinterpret_cast<uint4 *>(lds[p])[threadIdx.x] = v;
+        reinterpret_cast<uint4 *>(lds[buf])[threadIdx.x] = v;
         __syncthreads();
         if (active) {
             uint32_t w[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) w[i] = lds[p][d0 + i];
+            for (int i = 0; i < 6; ++i) w[i] = lds[buf][d0 + i];
             if constexpr (F16) expand_h(w, c0, E[slot], O[slot]);
             else oip_expand_pairs(w, c0 & 1, win[slot]);
         }
-        p ^= 1;
     };
+    // Everything that steers the loop is wave-uniform and lives in scalar registers: the row table comes in through scalar loads
+    // (oip_uniform) and the state below only ever takes values from it.  (The form this replaces -- a nested run / unrolled-by-4
+    // loop left through breaks, with the inactive lanes skipping the sums through `continue` -- made the compiler keep the line
+    // counter, the window state and a loop-state variable in VECTOR registers and rotate a three-deep chunk queue with 16 moves
+    // per line: about 100 of the 1500 issue cycles of a line.)
     int cur_fy = -1;
-    // A run = consecutive regular output lines whose 4-line windows slide by one source line.  Its first three tap lines
-    // are staged at the run's start (k = 0 again), after that every output line stages exactly one new line.
-    long r = r0;
-    while (r < r1) {
-        const RowInfo h = rows[oip_uniform(r)];
-        if (h.flags != 1) { ++r; continue; }                           // fix-up launch B
-        // The chunks of source lines qline .. qline + 2 are requested ahead.  Round 3 found "four ahead: the same 4.35 ms" --
-        // because the row table came in through a vector load whose s_waitcnt vmcnt(0) waited for every line in flight; with
-        // the table on scalar loads (oip_uniform) the depth counts (named registers: four slots as an array spill 47).
-        long qline = h.src[3];
-        uint4 qa, qb, qc;
-        {
-            const uint4 f0 = fetch(h.src[0]), f1 = fetch(h.src[1]), f2 = fetch(h.src[2]);
-            qa = fetch(qline);
-            qb = fetch(qline + 1);
-            qc = fetch(qline + 2);
-            stage(f0, 0);
-            stage(f1, 1);
-            stage(f2, 2);
-        }
-        int cur1 = h.src[0], cur2 = h.src[1], cur3 = h.src[2];
-        bool run = true;
-        while (run) {
+    int cur1 = -2, cur2 = -2, cur3 = -2;          // the three newest tap lines in the window, when `primed`
+    int qline = -2;                               // source line whose chunk is in qa; qb, qc, qd hold the next three
+    bool primed = false;                          // the window is at step 0 of a quad
+    uint4 qa = make_uint4(0u, 0u, 0u, 0u), qb = qa, qc = qa, qd = qa;
+    // LDS buffer rule: a write to buffer b must follow the barrier of a stage into b ^ 1 (every reader of the previous use of b
+    // has passed it).  A quad stages into 1, 0, 1, 0 and prime into 0, 1, 0 behind a barrier of its own, so whatever ran before,
+    // the next stage call is allowed to write where it does.
+    auto prime = [&](const RowInfo &a) __attribute__((always_inline)) {
+        __syncthreads();
+        const uint4 f0 = fetch(a.src[0]), f1 = fetch(a.src[1]), f2 = fetch(a.src[2]);
+        qline = a.src[3];
+        qa = fetch(qline); qb = fetch((long)qline + 1); qc = fetch((long)qline + 2); qd = fetch((long)qline + 3);
+        stage(f0, 0, 0);
+        stage(f1, 1, 1);
+        stage(f2, 2, 0);
+        cur1 = a.src[0]; cur2 = a.src[1]; cur3 = a.src[2];
+        primed = true;
+    };
+    // output line rr_ at step k of a quad: stage its newest tap line (in `qk`), request the chunk four lines on into the same
+    // register, then the 16-tap sums of the active lanes
+    auto line = [&](auto ktag, const RowInfo &ri, long rr_, uint4 &qk) __attribute__((always_inline)) {
+        constexpr int k = decltype(ktag)::value;
+        stage(qk, (k + 3) & 3, (k + 1) & 1);
+        qk = fetch((long)qline + 4);
+        qline += 1;
+        cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
+        if (active) {
+            if (ri.fy != cur_fy) {
+                cur_fy = ri.fy;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (r >= r1) { run = false; break; }
-                const RowInfo ri = rows[oip_uniform(r)];
-                if (ri.flags != 1 || ri.src[0] != cur1 || ri.src[1] != cur2 || ri.src[2] != cur3 || ri.src[3] != qline) { run = false; break; }
-                stage(qa, (k + 3) & 3);
-                qa = qb;
-                qb = qc;
-                qline += 1;
-                qc = fetch(qline + 2);
-                cur1 = ri.src[1]; cur2 = ri.src[2]; cur3 = ri.src[3];
-                const long rr_ = r;
-                ++r;
-                if (!active) continue;
-                if (ri.fy != cur_fy) {
-                    cur_fy = ri.fy;
+                for (int ky = 0; ky < 4; ++ky) {
+                    const float wy = tab1d[cur_fy * 4 + ky];
 #pragma unroll
-                    for (int ky = 0; ky < 4; ++ky) {
-                        const float wy = tab1d[cur_fy * 4 + ky];
-#pragma unroll
-                        for (int kx = 0; kx < 4; ++kx) {
-                            if constexpr (F16) {
-                                const _Float16 h = (_Float16)__fmul_rn(wy, wx[kx]);
-                                w2d[ky * 4 + kx] = oip_h2{h, h};
-                            } else {
-                                w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
-                            }
+                    for (int kx = 0; kx < 4; ++kx) {
+                        if constexpr (F16) {
+                            const _Float16 h = (_Float16)__fmul_rn(wy, wx[kx]);
+                            w2d[ky * 4 + kx] = oip_h2{h, h};
+                        } else {
+                            w2d[ky * 4 + kx] = __fmul_rn(wy, wx[kx]);
                         }
                     }
-                }
-                uint4 o;
-                if constexpr (F16) {
-                    unsigned out[8];
-#pragma unroll
-                    for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
-                        oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
-                            acc = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc);
-                            acc = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc);
-                            acc = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc);
-                            acc = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc);
-                        }
-                        out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
-                        out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
-                    }
-                    o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-                    o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
-                } else {
-                    oip_f2 sum[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) oip_row_taps8(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
-                    o = oip_sat_pack8(sum);
-                }
-                uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
-                if (x0 >= dw.col0 && dw.vec) {
-                    *reinterpret_cast<uint4 *>(drow) = o;
-                } else {
-                    const unsigned d[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (x0 + j >= dw.col0) drow[j] = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
                 }
             }
+            uint4 o;
+            if constexpr (F16) {
+                unsigned out[8];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
+                    oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
+                        acc = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc);
+                        acc = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc);
+                        acc = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc);
+                        acc = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc);
+                    }
+                    out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
+                    out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
+                }
+                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
+                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+            } else {
+                oip_f2 sum[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) oip_row_taps8(win[(k + t) & 3], w2d + t * 4, t == 0, sum);
+                o = oip_sat_pack8(sum);
+            }
+            uint16_t *drow = dst + rr_ * dw.pitch + x0 + dw.shift;
+            if (x0 >= dw.col0 && dw.vec) {
+                *reinterpret_cast<uint4 *>(drow) = o;
+            } else {
+                const unsigned d[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
+            }
         }
+    };
+    auto follows = [](const RowInfo &n, const RowInfo &p) __attribute__((always_inline)) {     // n's window = p's, one line down
+        return n.flags == 1 && n.src[0] == p.src[1] && n.src[1] == p.src[2] && n.src[2] == p.src[3] && n.src[3] == p.src[3] + 1;
+    };
+    long r = r0;
+    while (r < r1) {
+        const RowInfo a = rows[oip_uniform(r)];
+        if (a.flags != 1) { ++r; primed = false; continue; }             // fix-up launch B
+        if (r + 4 <= r1) {
+            // a quad: four consecutive regular lines whose windows slide by one source line each -- all but a handful of lines
+            const RowInfo b = rows[oip_uniform(r + 1)], c = rows[oip_uniform(r + 2)], d = rows[oip_uniform(r + 3)];
+            if (follows(b, a) && follows(c, b) && follows(d, c)) {
+                if (!(primed && a.src[0] == cur1 && a.src[1] == cur2 && a.src[2] == cur3 && a.src[3] == qline)) prime(a);
+                line(std::integral_constant<int, 0>{}, a, r, qa);
+                line(std::integral_constant<int, 1>{}, b, r + 1, qb);
+                line(std::integral_constant<int, 2>{}, c, r + 2, qc);
+                line(std::integral_constant<int, 3>{}, d, r + 3, qd);
+                r += 4;
+                continue;
+            }
+        }
+        // a line that is not part of a quad (before a section border, the last lines of the block): window staged afresh
+        prime(a);
+        line(std::integral_constant<int, 0>{}, a, r, qa);
+        primed = false;
+        ++r;
     }
     };
     if (safe_lut) body(std::true_type{}); else body(std::false_type{});

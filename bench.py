@@ -120,6 +120,7 @@ def algorithmic_bytes(W, pb, M, N, base_rows, base_cols, out_rows_local, rows_ar
         # raw CCD 2 in (corrected on load), the right half of the stitched raster out: 2 B read per source pixel of the columns
         # that are stored + 2 B written
         "remap_shift8_rrc_kernel": 4.0 * (W - 100) * pb,
+        "remap_shift8_rrc_f16_kernel": 4.0 * (W - 100) * pb,
     }
     return d
 

@@ -496,8 +496,7 @@ extern "C" int oip_align_mss_bicubic_u16x4(oip_ctx *ctx, const uint16_t *d_plane
                       (((uintptr_t)d_planes) & 3) == 0 && (plane_stride % 2) == 0 && src_rows * (long)Wb >= 16;
     const int groups = (Wb + 7) / 8;
     int gx = (groups + 63) / 64;                                  // 4 waves x 16 groups per workgroup
-    static const char *tune = getenv("OIP_TUNE_WG_PER_CU");
-    long want = (long)ctx->cu_count * (tune && atoi(tune) > 0 ? atoi(tune) : 16) / gx;
+    long want = (long)ctx->cu_count * 16 / gx;                    // 3..48 per CU: flat within 3 % (r04_grid_sweep.txt)
     if (want < 1) want = 1;
     long rpb = (out_rows + want - 1) / want;
     if (rpb < 32) rpb = 32;

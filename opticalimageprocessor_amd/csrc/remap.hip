@@ -352,18 +352,37 @@ __device__ __forceinline__ oip_h2 h2_from_biased_pair(uint32_t w)
 }
 __device__ __forceinline__ void expand_h(const uint32_t w[6], int c0, oip_h2 E[6], oip_h2 O[5])
 {
-    oip_h2 H[6], S[5];
+    // odd first column: one funnel shift per dword brings the line to the even layout (as oip_expand_pairs does) -- selecting
+    // between the two layouts after the conversion cost ten v_cndmask per line
+    const unsigned sh = (c0 & 1) ? 16u : 0u;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) H[i] = h2_from_biased_pair(w[i]);
+    for (int i = 0; i < 5; ++i) E[i] = h2_from_biased_pair(__builtin_amdgcn_alignbit(w[i + 1], w[i], sh));
+    E[5] = h2_from_biased_pair(w[5] >> sh);       // only its first half (sample 10) is used, through O[4]
 #pragma unroll
-    for (int i = 0; i < 5; ++i) S[i] = h2_shift(H[i], H[i + 1]);
-    const bool odd = c0 & 1;
+    for (int i = 0; i < 5; ++i) O[i] = h2_shift(E[i], E[i + 1]);
+}
+// The 8 fp16 sums (acc[p] = pixels 2p, 2p+1) biased back, saturated and packed.  (float)acc + 2048 is exact in f32 for every
+// fp16 value that can round to a different integer than its neighbour (|acc| >= 0.5 has an ulp >= 2^-11; below that the sum
+// stays strictly inside (2047.5, 2048.5)), so adding 2048 + 1.5 * 2^23 in one step rounds exactly as rintf((float)acc + 2048)
+// does and leaves the integer in the low bits (oip_sat_pack8's trick); the integer clamp maps +inf to 65535 and -inf to 0 as
+// the fminf / fmaxf pair it replaces did.  A NaN sum -- not reachable: 16 products of int16 samples with weights whose
+// magnitudes add up to 1.6 stay far below fp16's 65504 -- would saturate by its sign bit.
+__device__ __forceinline__ uint4 h2_sat_pack8(const oip_h2 acc[4])
+{
+    unsigned c[8];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        E[i] = odd ? S[i] : H[i];
-        O[i] = odd ? H[i + 1] : S[i];
+    for (int p = 0; p < 4; ++p) {
+        const int lo = (int)__float_as_uint((float)acc[p].x + (12582912.0f + (float)kF16Bias));
+        const int hi = (int)__float_as_uint((float)acc[p].y + (12582912.0f + (float)kF16Bias));
+        c[2 * p] = (unsigned)(lo < 0x4B400000 ? 0x4B400000 : (lo > 0x4B40FFFF ? 0x4B40FFFF : lo));
+        c[2 * p + 1] = (unsigned)(hi < 0x4B400000 ? 0x4B400000 : (hi > 0x4B40FFFF ? 0x4B40FFFF : hi));
     }
-    E[5] = H[5];        // only its first half is ever used (sample 10), and only for even c0; odd c0 never reads E[5]
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(c[1], c[0], 0x05040100u);
+    o.y = __builtin_amdgcn_perm(c[3], c[2], 0x05040100u);
+    o.z = __builtin_amdgcn_perm(c[5], c[4], 0x05040100u);
+    o.w = __builtin_amdgcn_perm(c[7], c[6], 0x05040100u);
+    return o;
 }
 __device__ __forceinline__ void load_src_line11_h(const uint32_t *__restrict__ lane_base, int row, int half_pitch, int c0,
                                                   oip_h2 E[6], oip_h2 O[5])
@@ -431,33 +450,29 @@ __global__ __launch_bounds__(kBlock, 4) void remap_shift8_f16_kernel(const uint1
                     }
                 }
             }
-            unsigned out[8];
+            oip_h2 acc[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {             // output pixels 2p, 2p+1
-                oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
+                acc[p] = oip_h2{(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
-                    acc = __builtin_elementwise_fma(Et[p], w2d[t * 4 + 0], acc);
-                    acc = __builtin_elementwise_fma(Ot[p], w2d[t * 4 + 1], acc);
-                    acc = __builtin_elementwise_fma(Et[p + 1], w2d[t * 4 + 2], acc);
-                    acc = __builtin_elementwise_fma(Ot[p + 1], w2d[t * 4 + 3], acc);
+                    acc[p] = __builtin_elementwise_fma(Et[p], w2d[t * 4 + 0], acc[p]);
+                    acc[p] = __builtin_elementwise_fma(Ot[p], w2d[t * 4 + 1], acc[p]);
+                    acc[p] = __builtin_elementwise_fma(Et[p + 1], w2d[t * 4 + 2], acc[p]);
+                    acc[p] = __builtin_elementwise_fma(Ot[p + 1], w2d[t * 4 + 3], acc[p]);
                 }
-                // bias back in f32; clamp before the conversion: inf -> 65535, NaN -> 0 (fmaxf returns the non-NaN operand)
-                out[2 * p] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
-                out[2 * p + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
             }
-            uint4 o;
-            o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-            o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+            const uint4 o = h2_sat_pack8(acc);
             uint16_t *drow = dst + r * dw.pitch + x0 + dw.shift;
             if (x0 >= dw.col0 && dw.vec) {
                 *reinterpret_cast<uint4 *>(drow) = o;
             } else {
                 // the group that straddles col0, or a destination whose 16-byte stores would be misaligned
+                const unsigned d[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)out[j];
+                    if (x0 + j >= dw.col0) drow[j] = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
             }
         }
     }
@@ -474,7 +489,11 @@ template <bool SAFE> __device__ __forceinline__ unsigned rrc_px_t(double k, doub
     }
 }
 
-template <bool F16>          // F16: the fp16-accumulate sums of remap_shift8_f16_kernel on the corrected samples
+// F16: the fp16-accumulate sums of remap_shift8_f16_kernel on the corrected samples.  (The same staging WITHOUT the correction,
+// for plain calls, was measured again with this loop: 2.70 ms f32 / 2.65 fp16 against the register-window kernels' 2.55 / 2.70 on
+// two 30000 x 100000 segments -- every form of this pass now sits at 4.5-4.8 TB/s, 85 % of what the plain copy kernels reach,
+// and the plain calls keep the register form.)
+template <bool F16>
 __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, DstWin dw,
                                                                      const RowInfo *__restrict__ rows, int W, long out_rows,
                                                                      long src_elems, double dx, const float *__restrict__ tab1d,
@@ -494,9 +513,8 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
         in_range = in_range && __dadd_rn(__dmul_rn(fabs(q[j].x), 65535.0), fabs(q[j].y)) < 2147483648.0;
     }
     // The double -> uint16_t cast of IMO::InplaceRRC (oip_rrc_px) tests both bounds before it converts: two fp64 compares and a
-    // select per sample, 24 of the ~430 vector instructions of a line in a kernel that is bound by them.  When every pair of
-    // the workgroup's columns keeps k s + b inside the int32 range for any 16-bit s -- every real LUT does -- the loop is
-    // instantiated without the test (same bits: the test could never fire); otherwise with it.
+    // select per sample.  When every pair of the workgroup's columns keeps k s + b inside the int32 range for any 16-bit s --
+    // every real LUT does -- the loop is instantiated without the test (same bits: the test could never fire); otherwise with it.
     const bool safe_lut = __syncthreads_and(in_range) != 0;
     const int x0 = X0 + (int)threadIdx.x * 8;
     int c0 = 0, fx0 = 0;
@@ -588,23 +606,20 @@ __global__ __launch_bounds__(kBlock, 3) void remap_shift8_rrc_kernel(const uint1
             }
             uint4 o;
             if constexpr (F16) {
-                unsigned out[8];
+                oip_h2 acc[4];
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp) {          // output pixels 2pp, 2pp+1 (remap_shift8_f16_kernel's sums)
-                    oip_h2 acc = {(_Float16)0.f, (_Float16)0.f};
+                    acc[pp] = oip_h2{(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const oip_h2 *Et = E[(k + t) & 3], *Ot = O[(k + t) & 3];
-                        acc = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc);
-                        acc = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc);
-                        acc = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc);
-                        acc = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc);
+                        acc[pp] = __builtin_elementwise_fma(Et[pp], w2d[t * 4 + 0], acc[pp]);
+                        acc[pp] = __builtin_elementwise_fma(Ot[pp], w2d[t * 4 + 1], acc[pp]);
+                        acc[pp] = __builtin_elementwise_fma(Et[pp + 1], w2d[t * 4 + 2], acc[pp]);
+                        acc[pp] = __builtin_elementwise_fma(Ot[pp + 1], w2d[t * 4 + 3], acc[pp]);
                     }
-                    out[2 * pp] = oip_sat_u16(fminf(fmaxf((float)acc.x + (float)kF16Bias, 0.f), 65535.f));
-                    out[2 * pp + 1] = oip_sat_u16(fminf(fmaxf((float)acc.y + (float)kF16Bias, 0.f), 65535.f));
                 }
-                o.x = out[0] | (out[1] << 16); o.y = out[2] | (out[3] << 16);
-                o.z = out[4] | (out[5] << 16); o.w = out[6] | (out[7] << 16);
+                o = h2_sat_pack8(acc);
             } else {
                 oip_f2 sum[4];
 #pragma unroll
@@ -821,9 +836,8 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
         return oip_fail(ctx, OIP_E_UNSUPPORTED, "oip_remap_shift_bicubic_u16: too many section-border lines");
     if (v8) {
         int gx = lds ? (W / 8 + kLdsOut - 1) / kLdsOut : (W / 8 + kBlock - 1) / kBlock;
-        static const char *tune = getenv("OIP_TUNE_WG_PER_CU");
-        const int per_cu = tune && atoi(tune) > 0 ? atoi(tune) : (lds ? 12 : 16);
-        long want = (long)ctx->cu_count * per_cu / gx;      // 12..96 (RRC form), 16..48 (plain): the step takes the same time
+        // workgroups per CU: 5..48 measured again in round 4 (profiles/experiments/r04_grid_sweep.txt): flat within 3 %
+        long want = (long)ctx->cu_count * (lds ? 12 : 16) / gx;
         if (want < 1) want = 1;
         long rpb = (out_rows + want - 1) / want;
         if (rpb < 32) rpb = 32;
@@ -835,12 +849,12 @@ static int remap_shift_impl(oip_ctx *ctx, const uint16_t *d_src, long src_row0, 
             if (lds && f16acc)
                 hipLaunchKernelGGL(remap_shift8_rrc_kernel<true>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
                                    out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
-            else if (f16acc)
-                hipLaunchKernelGGL(remap_shift8_f16_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
-                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
             else if (lds)
                 hipLaunchKernelGGL(remap_shift8_rrc_kernel<false>, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W,
                                    out_rows, src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb, kb, ixmin8);
+            else if (f16acc)
+                hipLaunchKernelGGL(remap_shift8_f16_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
+                                   src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);
             else
                 hipLaunchKernelGGL(remap_shift8_kernel, dim3(gx, (unsigned)gy), dim3(kBlock), 0, ctx->stream, d_src, d_dst, dw, rows, W, out_rows,
                                    src_rows * (long)W, dx, ctx->d_tab1d, (int)rpb);

@@ -2,7 +2,7 @@
 for i in 1 2; do
   for lib in new base; do
     if [ $lib = base ]; then export OIP_LIBRARY=$PWD/profiles/experiments/liboipgpu_base.so; else unset OIP_LIBRARY; fi
-    for mode in "" "--fused" "--fp16-accumulate"; do
+    for mode in "" "--fp16-accumulate"; do
       timeout -k 10 300 python bench.py --workload prestitch $mode --steps 6 --warmup 2 --no-cpu-baseline --full-record gpurun_out/r04_ab.json > /dev/null 2> gpurun_out/r04_ab.err || tail -3 gpurun_out/r04_ab.err
       python - <<PY
 import json

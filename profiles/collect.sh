@@ -20,6 +20,7 @@ for W in ${WLS:-default prestitch prestitch_fused rrc}; do   # WLS: subset of wo
 done
 if [ -z "$SKIP_EXTRAS" ]; then
 echo "== prestitch, fp16-accumulate variant"; timeout -k 10 300 python3 bench.py --workload prestitch --fp16-accumulate --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_prestitch_f16.json 2> $OUT/bench_prestitch_f16.err || true
+echo "== prestitch, fused passes, fp16-accumulate variant"; timeout -k 10 300 python3 bench.py --workload prestitch --fused --fp16-accumulate --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_prestitch_fused_f16.json 2> $OUT/bench_prestitch_fused_f16.err || true
 echo "== staging probe"; timeout -k 10 300 python3 profiles/experiments/staging_probe.py > $OUT/staging_probe.txt 2>&1 || true
 echo "== 12288-wide bench"; timeout -k 10 300 python3 bench.py --width 12288 --steps 10 --warmup 2 --no-end-to-end --no-configs --no-cpu-baseline > $OUT/bench_w12288.json 2> $OUT/bench_w12288.err || true
 fi

@@ -327,6 +327,19 @@ int oip_stitch_rows_u16(oip_ctx *ctx, const uint16_t *d_left, const uint16_t *d_
  * device, its lines go from HBM into the TIFF's pixel payload without a host pass.  d_img 16-byte aligned. */
 int oip_permute_u16x4(oip_ctx *ctx, uint16_t *d_img, size_t npixels, const int *order);
 
+/* The strips of an LZW TIFF product, encoded on the device (cv::imwrite's TIFF encoder behind preproc.h:167-185 and GDAL's
+ * COMPRESS=LZW PREDICTOR=2 behind imageop.h:460-567 do this on the host, strip by strip).  d_img: rows x width x spp u16,
+ * interleaved, in file sample order (oip_permute_u16x4 first where cv::imwrite / a band map reorder); spp 1 or 4; strip k
+ * holds rows [k rows_per_strip, (k + 1) rows_per_strip).  Every strip is the horizontal-predictor differences of its rows
+ * through TIFF 6.0's LZW as libtiff writes it (MSB-first 9..12-bit codes, ClearCode first, early change, EndOfInformation).
+ * The encoded strips are packed into d_payload at even offsets in strip order; strip_off / strip_len (host arrays, one
+ * entry per strip) say where, *payload_bytes is the end of the last one.  payload_cap >= oip_tiff_lzw_worst_bytes().
+ * Synchronises the context's stream. */
+size_t oip_tiff_lzw_worst_bytes(long rows, int width, int spp, long rows_per_strip);
+int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long rows, int width, int spp, long rows_per_strip,
+                            uint8_t *d_payload, size_t payload_cap, uint64_t *strip_off, uint64_t *strip_len,
+                            size_t *payload_bytes);
+
 /* ---- instrumentation --------------------------------------------------------------- */
 /* name + accumulated device time of the kernels launched through this context since the
  * last reset, measured with HIP events on the context's stream (off by default). */

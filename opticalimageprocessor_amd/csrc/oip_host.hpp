@@ -254,6 +254,13 @@ constexpr int MSS_BANDS = OIP_MSS_BANDS;
 // rows x rowSamples u16 in HBM -> the writer, 256 MiB of lines at a time, the next block coming down (staging download lane)
 // while the strips of the current one are encoded (a few threads) and the previous one's are written (TiffWriterU16's own
 // thread): download || encode || write
+// OIP_TIFF_GPU_LZW=0: LZW strips on the host's threads (the encoder of oip_tiff.hpp; same file bytes) -- test and A/B knob
+inline bool gpu_lzw()
+{
+    static const bool on = [] { const char *e = getenv("OIP_TIFF_GPU_LZW"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 inline void tiff_rows_from_device(TiffWriterU16 &tw, const uint16_t *d_img, long rows, size_t rowSamples, long mark)
 {
     oip_ctx *ctx = Device::get().ctx();
@@ -307,6 +314,18 @@ inline void write_tiff_from_device(const std::string &path, uint16_t *d_img, int
         const uint64_t at = tw.begin_external_payload();
         Device::get().check(oip_write_device_to_file_at(ctx, d_img, (size_t)height * rowSamples * 2, path.c_str(), (size_t)at, mark));
         tw.end_external_payload();
+    } else if (gpu_lzw()) {
+        // the strips are encoded where the image is (csrc/tifflzw.hip) and leave the device packed, as one block
+        const long rps = tw.rows_per_strip();
+        const size_t nstrips = (size_t)((height + rps - 1) / rps);
+        DevBuf<uint8_t> payload(oip_tiff_lzw_worst_bytes(height, width, spp, rps));
+        std::vector<uint64_t> off(nstrips), len(nstrips);
+        size_t bytes = 0;
+        // (the encoder runs on the compute stream: everything the image waits for is ahead of it there)
+        Device::get().check(oip_tiff_lzw_strips_u16(ctx, d_img, height, width, spp, rps, payload.p, payload.n, off.data(), len.data(), &bytes));
+        const uint64_t at = tw.begin_external_strips();
+        Device::get().check(oip_write_device_to_file_at(ctx, payload.p, (bytes + 1) & ~(size_t)1, path.c_str(), (size_t)at, 0));
+        tw.end_external_strips(off.data(), len.data(), nstrips, bytes);
     } else {
         tiff_rows_from_device(tw, d_img, height, rowSamples, mark);
     }

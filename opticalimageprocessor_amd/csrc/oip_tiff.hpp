@@ -45,34 +45,35 @@ enum TiffCompression { TIFF_NONE = 1, TIFF_LZW = 5 };
 
 namespace tiffdetail {
 
-// threads of the strip encoder / decoder: half the host's threads, at most 32 (OIP_TIFF_THREADS overrides, up to 128) -- LZW is
+// threads of the strip encoder / decoder: half the host's threads, at most 64 (OIP_TIFF_THREADS overrides, up to 128) -- LZW is
 // the one stage of a compressed product that stays on the CPU, ~100 MB/s per thread
 inline int worker_count()
 {
     static const int n = [] {
         const char *e = getenv("OIP_TIFF_THREADS");
         int v = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
-        const int cap = e ? 128 : 32;
+        const int cap = e ? 128 : 64;
         return v < 1 ? 1 : (v > cap ? cap : v);
     }();
     return n;
 }
 
-// run fn(i) for i in [0, n) on a few threads
-template <typename F> inline void parallel_for(size_t n, F fn)
+// run fn(i, t) for i in [0, n) on a few threads; t < worker_count() is the index of the thread that runs it
+template <typename F> inline void parallel_for_t(size_t n, F fn)
 {
     const int nt = (int)std::min<size_t>(n, (size_t)worker_count());
-    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i, 0); return; }
     std::vector<std::thread> th;
     std::vector<std::string> errs(nt);
     for (int t = 0; t < nt; ++t)
         th.emplace_back([&, t] {
-            try { for (size_t i = t; i < n; i += nt) fn(i); }
+            try { for (size_t i = t; i < n; i += nt) fn(i, t); }
             catch (const std::exception &e) { errs[t] = e.what(); }
         });
     for (auto &x : th) x.join();
     for (auto &e : errs) if (!e.empty()) throw std::runtime_error(e);
 }
+template <typename F> inline void parallel_for(size_t n, F fn) { parallel_for_t(n, [&](size_t i, int) { fn(i); }); }
 
 // The string table of the encoder: open addressing over 16384 slots (4x the 4094 entries), a slot = (generation << 20) |
 // (prefix code << 8) | byte.  ClearCode starts a new GENERATION instead of wiping the table -- sensor data barely compresses
@@ -97,14 +98,16 @@ struct LzwStrip {
     size_t size() const { return n; }
 };
 
-inline void lzw_encode(const uint8_t *src, size_t n, LzwStrip &out)
+// worst case of an encoded strip: one 12-bit code per byte, plus Clear / EOI codes
+inline size_t lzw_worst(size_t n) { return n + n / 2 + n / 1024 + 64; }
+
+// encodes n bytes into dst (lzw_worst(n) bytes); returns the encoded size
+inline size_t lzw_encode_to(const uint8_t *src, size_t n, uint8_t *dst)
 {
     static thread_local std::unique_ptr<LzwTable> tab;  // ~96 KB, once per encoding thread
     if (!tab) tab.reset(new LzwTable());
     tab->clear();
-    // worst case: one 12-bit code per byte, plus Clear / EOI codes
-    out.p.reset(new uint8_t[n + n / 2 + n / 1024 + 64]);
-    uint8_t *o = out.p.get();
+    uint8_t *o = dst;
     uint64_t acc = 0;
     int nbits = 0;
     auto put = [&](unsigned code, int width) {
@@ -117,8 +120,7 @@ inline void lzw_encode(const uint8_t *src, size_t n, LzwStrip &out)
     if (n == 0) {
         put(257, width);
         if (nbits > 0) *o++ = (uint8_t)(acc << (8 - nbits));
-        out.n = (size_t)(o - out.p.get());
-        return;
+        return (size_t)(o - dst);
     }
     uint32_t gen = tab->gen << 20;
     int ent = src[0];
@@ -154,7 +156,12 @@ inline void lzw_encode(const uint8_t *src, size_t n, LzwStrip &out)
     else if (next == (1 << width) && width < 12) ++width;
     put(257, width);
     if (nbits > 0) *o++ = (uint8_t)(acc << (8 - nbits));
-    out.n = (size_t)(o - out.p.get());
+    return (size_t)(o - dst);
+}
+inline void lzw_encode(const uint8_t *src, size_t n, LzwStrip &out)
+{
+    out.p.reset(new uint8_t[lzw_worst(n)]);
+    out.n = lzw_encode_to(src, n, out.p.get());
 }
 
 // returns the number of bytes produced (at most cap); throws on a corrupt stream
@@ -242,10 +249,16 @@ public:
         // classic TIFF offsets are 32 bit.  LZW can also GROW a strip: at worst one 12-bit code per byte (x1.5), so the
         // choice is made on the worst case and a classic file can never overflow half-way (BigTIFF is always valid).
         const size_t worst = compression == TIFF_LZW ? data + data / 2 : data;
-        mBig = worst + (size_t)height * 16 / 64 + 16384 > 0xFFFFF000ull;      // header, page-aligned payload, strip tables, directory
-        mRowsPerStrip = (long)((8u << 20) / mRowBytes);
+        // Strips: 8 MiB uncompressed (their offsets are arithmetic); LZW: whole rows up to 64 KiB (cv::imwrite and GDAL write 8
+        // KB strips; libtiff's table restarts every ~5 KB of sensor data, so the strip size does not change the ratio).  An
+        // LZW strip is the unit of parallel work of whoever encodes it: a lane of the device encoder (csrc/tifflzw.hip: 25000
+        // strips for a 7500 x 25000 x 4 product), a thread of the host encoder below -- both write the same strips, so a file
+        // is the same bytes whoever encoded it.
+        mRowsPerStrip = compression == TIFF_LZW ? (long)((64u << 10) / mRowBytes) : (long)((8u << 20) / mRowBytes);
         if (mRowsPerStrip < 1) mRowsPerStrip = 1;
         if (mRowsPerStrip > height) mRowsPerStrip = height;
+        const size_t nstrips = ((size_t)height + mRowsPerStrip - 1) / mRowsPerStrip;
+        mBig = worst + nstrips * 16 + 16384 > 0xFFFFF000ull;                  // header, page-aligned payload, strip tables, directory
         mF = fopen(path.c_str(), "wb");
         if (!mF) throw std::runtime_error("open file [" + path + "] failed");
         if (mBig) {
@@ -292,7 +305,8 @@ public:
             }
         }
         const long full = (count - r) / mRowsPerStrip;
-        const long batch = 2 * (long)tiffdetail::worker_count();
+        // a batch: a few strips per worker thread and at least 64 MiB of rows, so that a batch is worth the threads it starts
+        const long batch = std::max<long>(2 * (long)tiffdetail::worker_count(), (long)(((size_t)64 << 20) / (mRowBytes * (size_t)mRowsPerStrip)) + 1);
         for (long k0 = 0; k0 < full; k0 += batch) {
             const long nk = std::min(batch, full - k0);
             encode_strips(rows + (size_t)(r + k0 * mRowsPerStrip) * rw, nk * mRowsPerStrip);
@@ -401,45 +415,80 @@ public:
         if (fseeko(mF, (off_t)mPos, SEEK_SET) != 0) throw std::runtime_error("TiffWriterU16: seek failed");
     }
 
+    // LZW files whose strips were encoded elsewhere (the device: oip_tiff_lzw_strips_u16 on an image in file sample order):
+    // the packed strips are written by the caller at the offset begin_external_strips() returns -- where write_rows() would
+    // have put the first one -- and end_external_strips() takes their offsets inside that block and their sizes.
+    long rows_per_strip() const { return mRowsPerStrip; }
+    uint64_t begin_external_strips()
+    {
+        if (mComp != TIFF_LZW || mRowsDone != 0) throw std::logic_error("TiffWriterU16: external strips need an empty LZW file");
+        if (mSwap) throw std::logic_error("TiffWriterU16: external strips are written in file sample order");
+        if (fflush(mF) != 0) throw std::runtime_error("TiffWriterU16: write failed");
+        return mPos;
+    }
+    void end_external_strips(const uint64_t *off, const uint64_t *len, size_t n, uint64_t payload_bytes)
+    {
+        if (n != (size_t)((mH + mRowsPerStrip - 1) / mRowsPerStrip)) throw std::logic_error("TiffWriterU16: strip count");
+        if (!mBig && mPos + payload_bytes > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
+        for (size_t k = 0; k < n; ++k) {
+            if ((off[k] & 1) || off[k] + len[k] > payload_bytes) throw std::logic_error("TiffWriterU16: strip outside its payload");
+            mStripOff.push_back(mPos + off[k]);
+            mStripLen.push_back(len[k]);
+        }
+        mPos += payload_bytes;
+        mRowsDone = mH;
+        mPositioned = true;
+    }
+
 private:
-    // encode `nrows` rows (whole strips, the last one possibly short) on a few threads and append them to the file
+    // encode `nrows` rows (whole strips, the last one possibly short) on a few threads and append them to the file.
+    // No allocation per strip: a worker copies + differences a strip in a scratch buffer of its own and encodes it into its
+    // region of one of two arenas that alternate between batches (the previous batch is still being written from the other).
+    // Per-strip `new` of 1 + 1.5 MB on 32-64 threads made the encoder wait for the kernel's page-fault and unmap paths
+    // instead of coding (round 4: the LZW product did not get faster with more threads or smaller strips until this went).
     void encode_strips(const uint16_t *rows, long nrows)
     {
         const size_t rw = (size_t)mW * mSpp;
         const long nstrips = (nrows + mRowsPerStrip - 1) / mRowsPerStrip;
-        std::vector<tiffdetail::LzwStrip> enc((size_t)nstrips);
-        tiffdetail::parallel_for((size_t)nstrips, [&](size_t k) {
+        const size_t stripBytes = (size_t)mRowsPerStrip * rw * 2, worst = tiffdetail::lzw_worst(stripBytes);
+        Arena &ar = mArena[mArenaCur];
+        mArenaCur ^= 1;
+        if (ar.cap < (size_t)nstrips * worst) { ar.p.reset(new uint8_t[(size_t)nstrips * worst]); ar.cap = (size_t)nstrips * worst; }
+        if (mScratch.size() < (size_t)tiffdetail::worker_count()) mScratch.resize((size_t)tiffdetail::worker_count());
+        std::vector<size_t> len((size_t)nstrips);
+        uint8_t *base = ar.p.get();
+        tiffdetail::parallel_for_t((size_t)nstrips, [&](size_t k, int t) {
             const long r0 = (long)k * mRowsPerStrip;
             const long n = std::min<long>(mRowsPerStrip, nrows - r0);
-            std::unique_ptr<uint16_t[]> buf(new uint16_t[(size_t)n * rw]);
+            if (!mScratch[(size_t)t]) mScratch[(size_t)t].reset(new uint16_t[(size_t)mRowsPerStrip * rw]);
+            uint16_t *buf = mScratch[(size_t)t].get();
             for (long r = 0; r < n; ++r) {
                 const uint16_t *src = rows + (size_t)(r0 + r) * rw;
-                uint16_t *d = buf.get() + (size_t)r * rw;
+                uint16_t *d = buf + (size_t)r * rw;
                 if (mSwap) swap_row(src, d); else memcpy(d, src, rw * 2);
                 tiffdetail::predictor2_encode(d, (size_t)mW, mSpp);
             }
-            tiffdetail::lzw_encode((const uint8_t *)buf.get(), (size_t)n * rw * 2, enc[k]);
+            len[k] = tiffdetail::lzw_encode_to((const uint8_t *)buf, (size_t)n * rw * 2, base + k * worst);
         });
         // the batch goes to the file on a thread of its own (positioned writes) while the caller brings down and encodes the
         // next one; the previous batch's write is waited for -- and its error raised -- first
         wait_write();
-        auto job = std::make_shared<std::vector<tiffdetail::LzwStrip>>(std::move(enc));
         std::vector<uint64_t> at((size_t)nstrips);
         for (long k = 0; k < nstrips; ++k) {
             if (mPos & 1) ++mPos;                                       // strips start on even offsets (the gap reads as zero)
-            if (!mBig && mPos + (*job)[k].size() > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
+            if (!mBig && mPos + len[(size_t)k] > 0xFFFFF000ull) throw std::runtime_error("TiffWriterU16: classic TIFF overflow");
             at[(size_t)k] = mPos;
             mStripOff.push_back(mPos);
-            mStripLen.push_back((*job)[k].size());
-            mPos += (*job)[k].size();
+            mStripLen.push_back(len[(size_t)k]);
+            mPos += len[(size_t)k];
         }
         if (fflush(mF) != 0) throw std::runtime_error("TiffWriterU16: write failed");
         mPositioned = true;
         const int fd = fileno(mF);
-        mWrite = std::async(std::launch::async, [fd, job, at] {
-            for (size_t k = 0; k < job->size(); ++k) {
-                const uint8_t *p = (*job)[k].data();
-                size_t n = (*job)[k].size(), w = 0;
+        mWrite = std::async(std::launch::async, [fd, base, worst, len, at] {
+            for (size_t k = 0; k < len.size(); ++k) {
+                const uint8_t *p = base + k * worst;
+                size_t n = len[k], w = 0;
                 while (w < n) {
                     const ssize_t r = pwrite(fd, p + w, n - w, (off_t)(at[k] + w));
                     if (r < 0 && errno == EINTR) continue;
@@ -480,6 +529,10 @@ private:
     int mComp;
     size_t mRowBytes = 0;
     long mRowsPerStrip = 1, mRowsDone = 0;
+    struct Arena { std::unique_ptr<uint8_t[]> p; size_t cap = 0; };
+    Arena mArena[2];                                    // encoded strips of the batch being encoded / being written
+    int mArenaCur = 0;
+    std::vector<std::unique_ptr<uint16_t[]>> mScratch;  // one strip of differenced samples per worker
     uint64_t mPos = 0;
     std::vector<uint64_t> mStripOff, mStripLen;
     std::vector<uint16_t> mPending;

@@ -158,7 +158,10 @@ def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
                 _csv(os.path.join(d, "MSS.B%d.csv" % (b + 1)), _synth.lut(W // 4, 20 + b))
             # (OIP_TIFF_CHUNK_MB: the LZW product comes down in 1 MiB blocks, so that the download || encode || write overlap of
             # tiff_rows_from_device runs over many blocks on this small image)
-            env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp, OIP_TIFF_CHUNK_MB="1")
+            # The step-by-step run encodes its LZW strips on the host's threads (OIP_TIFF_GPU_LZW=0), the pipelined one on the
+            # device (csrc/tifflzw.hip): the byte comparison below is also the device encoder against the host encoder.
+            env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp, OIP_TIFF_CHUNK_MB="1",
+                       OIP_TIFF_GPU_LZW=pl)
             args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv", "--write-rrcpan",
                     "--slices", "9", "--ibc-sections", "2", "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
             for b in range(4):

@@ -1,0 +1,78 @@
+"""The device LZW strip encoder (csrc/tifflzw.hip, oip_tiff_lzw_strips_u16) against an independent restatement of TIFF 6.0
+sections 13 (LZW as libtiff writes it) and 14 (horizontal predictor): tests/_tiff.py::lzw_encode -- a dictionary of byte strings,
+nothing in common with the open-addressing coders of the product -- on the predictor-2 byte stream of every strip, bit for bit.
+The reference encodes these strips on the host through cv::imwrite (preproc.h:167-185) and GDAL (imageop.h:460-567)."""
+import numpy as np
+import pytest
+import torch
+
+import _tiff
+
+pytestmark = pytest.mark.gpu
+
+
+def _image(kind, rows, width, spp, seed):
+    rng = np.random.default_rng(seed)
+    n = rows * width * spp
+    if kind == "noise12":                      # sensor-like: barely compresses, the table fills every ~5 KB
+        a = np.clip(rng.normal(1800.0, 300.0, n), 64, 4095).astype(np.uint16)
+    elif kind == "noise16":                    # nothing repeats: a code per byte, ClearCode every 3836 bytes
+        a = rng.integers(0, 65536, n, dtype=np.uint16)
+    elif kind == "ramp":                       # constant differences: long matches, slow code-width growth
+        a = (np.arange(n, dtype=np.uint64) * 3 % 65536).astype(np.uint16)
+    elif kind == "constant":
+        a = np.full(n, 4242, dtype=np.uint16)
+    else:                                      # smooth scene + a little noise
+        x = np.arange(n, dtype=np.float64)
+        a = (2000 + 800 * np.sin(x / 977.0) + rng.integers(0, 4, n)).astype(np.uint16)
+    return a.reshape(rows, width * spp)
+
+
+def _predict(block, spp):
+    """TIFF predictor 2 on 16-bit samples, row by row, as the little-endian byte stream the coder sees"""
+    d = block.astype(np.uint16).copy()
+    d[:, spp:] = (block[:, spp:].astype(np.int32) - block[:, :-spp].astype(np.int32)).astype(np.uint16)
+    return d.astype("<u2").tobytes()
+
+
+@pytest.mark.parametrize("rows,width,spp,rps,kind", [
+    (40, 720, 4, 11, "noise12"),               # 63 KB strips of 11 rows, the last one short
+    (9, 7500, 4, 1, "scene"),                  # the product's own strips: one 60000-byte row each
+    (6, 2048, 1, 3, "ramp"),                   # one sample per pixel
+    (5, 1000, 4, 2, "constant"),
+    (3, 16384, 4, 1, "noise16"),               # 128 KB strips: ~34 table generations each
+    (150, 64, 4, 1, "noise12"),                # 150 small strips: three workgroups of lanes
+    (4, 33, 1, 4, "scene"),                    # odd widths, an odd number of bytes per strip is likely
+])
+def test_device_lzw_strips_equal_the_independent_coder(ctx, rows, width, spp, rps, kind):
+    oip = ctx
+    img = _image(kind, rows, width, spp, seed=rows * 31 + width)
+    d_img = torch.from_numpy(img.view(np.int16)).cuda()
+    cap = oip.tiff_lzw_worst_bytes(rows, width, spp, rps)
+    d_pay = torch.full((cap,), 0xEE, dtype=torch.uint8, device="cuda")
+    off, ln, total = oip.tiff_lzw_strips(d_img, rows, width, spp, rps, d_pay)
+    pay = d_pay.cpu().numpy()
+    nstrips = (rows + rps - 1) // rps
+    assert len(off) == nstrips and off[0] == 0 and total == off[-1] + ln[-1] and total <= cap
+    pos = 0
+    for k in range(nstrips):
+        want = _tiff.lzw_encode(_predict(img[k * rps:(k + 1) * rps], spp))
+        assert off[k] % 2 == 0 and off[k] == pos + (pos & 1), k
+        got = pay[int(off[k]):int(off[k] + ln[k])].tobytes()
+        assert got == want, (k, len(got), len(want))
+        if ln[k] % 2 and k + 1 < nstrips:
+            assert pay[int(off[k] + ln[k])] == 0          # the pad byte between an odd strip and the next
+        pos = int(off[k] + ln[k])
+    # and the streams decode (the independent decoder) to the predictor bytes
+    k = nstrips - 1
+    assert _tiff.lzw_decode(pay[int(off[k]):int(off[k] + ln[k])].tobytes()) == _predict(img[k * rps:(k + 1) * rps], spp)
+
+
+def test_device_lzw_rejects_bad_arguments(ctx):
+    oip = ctx
+    d_img = torch.zeros(64 * 4, dtype=torch.int16, device="cuda")
+    d_pay = torch.zeros(16, dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):
+        oip.tiff_lzw_strips(d_img, 1, 64, 3, 1, d_pay)               # spp 3
+    with pytest.raises(ValueError):
+        oip.tiff_lzw_strips(d_img, 1, 64, 4, 1, d_pay)               # payload too small

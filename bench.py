@@ -533,6 +533,8 @@ def cli_default_action(env, d, kb_mss, threshold):
                     kv = dict(x.split("=", 1) for x in ln.split()[2:])
                     rec["correlation_calls_start_plus_ms"] = kv.pop("correlation_calls_ms", None)
                     rec["log_seconds"] = {k: float(v) for k, v in kv.items()}
+                if ln.startswith("TIMING tiff_lzw"):                       # the device strip encoder's own split (csrc/oip_host.hpp)
+                    rec["tiff_lzw_seconds"] = {k: float(v) for k, v in (x.split("=", 1) for x in ln.split()[2:])}
             if r.returncode != 0:
                 rec["tail"] = (r.stdout + r.stderr)[-400:]
             if r.stderr.strip():

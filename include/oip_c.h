@@ -334,11 +334,13 @@ int oip_permute_u16x4(oip_ctx *ctx, uint16_t *d_img, size_t npixels, const int *
  * through TIFF 6.0's LZW as libtiff writes it (MSB-first 9..12-bit codes, ClearCode first, early change, EndOfInformation).
  * The encoded strips are packed into d_payload at even offsets in strip order; strip_off / strip_len (host arrays, one
  * entry per strip) say where, *payload_bytes is the end of the last one.  payload_cap >= oip_tiff_lzw_worst_bytes().
- * Synchronises the context's stream. */
+ * d_scratch: NULL (the call allocates and frees its own) or >= oip_tiff_lzw_scratch_bytes() of device memory, 8-byte aligned,
+ * that a caller who knows the product's geometry early prepares off the critical path.  Synchronises the context's stream. */
 size_t oip_tiff_lzw_worst_bytes(long rows, int width, int spp, long rows_per_strip);
+size_t oip_tiff_lzw_scratch_bytes(long rows, int width, int spp, long rows_per_strip);
 int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long rows, int width, int spp, long rows_per_strip,
                             uint8_t *d_payload, size_t payload_cap, uint64_t *strip_off, uint64_t *strip_len,
-                            size_t *payload_bytes);
+                            size_t *payload_bytes, void *d_scratch, size_t scratch_bytes);
 
 /* ---- instrumentation --------------------------------------------------------------- */
 /* name + accumulated device time of the kernels launched through this context since the

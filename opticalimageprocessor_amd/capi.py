@@ -74,7 +74,8 @@ _SIGS = {
     "oip_download_staged_after": ([_vp, _vp, _vp, _sz, _l], _i),
     "oip_permute_u16x4": ([_vp, _vp, _sz, C.POINTER(_i)], _i),
     "oip_tiff_lzw_worst_bytes": ([_l, _i, _i, _l], _sz),
-    "oip_tiff_lzw_strips_u16": ([_vp, _vp, _l, _i, _i, _l, _vp, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(_sz)], _i),
+    "oip_tiff_lzw_scratch_bytes": ([_l, _i, _i, _l], _sz),
+    "oip_tiff_lzw_strips_u16": ([_vp, _vp, _l, _i, _i, _l, _vp, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(_sz), _vp, _sz], _i),
     "oip_upload_staged": ([_vp, _vp, _vp, _sz, _lp], _i),
     "oip_upload_staged_2d": ([_vp, _vp, _sz, _vp, _sz, _sz, _sz, _lp], _i),
     "oip_download_staged": ([_vp, _vp, _vp, _sz], _i),
@@ -337,15 +338,20 @@ class Context:
         o = (C.c_int * 4)(*[int(v) for v in order])
         self._ck(self.lib.oip_permute_u16x4(self.h, _ptr(img), npixels, o))
 
-    def tiff_lzw_strips(self, img, rows, width, spp, rows_per_strip, payload):
+    def tiff_lzw_strips(self, img, rows, width, spp, rows_per_strip, payload, scratch=None):
         """LZW strips (predictor 2) of a device image into `payload` (device, uint8); returns (offsets, lengths, payload_bytes)"""
         n = (rows + rows_per_strip - 1) // rows_per_strip
         off = (C.c_uint64 * n)()
         ln = (C.c_uint64 * n)()
         total = C.c_size_t()
         self._ck(self.lib.oip_tiff_lzw_strips_u16(self.h, _ptr(img), rows, width, spp, rows_per_strip, _ptr(payload),
-                                                  payload.numel() * payload.element_size(), off, ln, C.byref(total)))
+                                                  payload.numel() * payload.element_size(), off, ln, C.byref(total),
+                                                  _ptr(scratch) if scratch is not None else None,
+                                                  scratch.numel() * scratch.element_size() if scratch is not None else 0))
         return np.array(off[:], dtype=np.uint64), np.array(ln[:], dtype=np.uint64), total.value
+
+    def tiff_lzw_scratch_bytes(self, rows, width, spp, rows_per_strip):
+        return int(self.lib.oip_tiff_lzw_scratch_bytes(rows, width, spp, rows_per_strip))
 
     def tiff_lzw_worst_bytes(self, rows, width, spp, rows_per_strip):
         return int(self.lib.oip_tiff_lzw_worst_bytes(rows, width, spp, rows_per_strip))

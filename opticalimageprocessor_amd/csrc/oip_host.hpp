@@ -293,6 +293,61 @@ inline void tiff_rows_from_device(TiffWriterU16 &tw, const uint16_t *d_img, long
     }
 }
 
+// An LZW product whose pixels are in HBM, in file sample order: the strips are encoded where the image is (csrc/tifflzw.hip:
+// a lane per strip) and leave the device packed, as one block that goes into the file behind the header.  The encoder runs on
+// the compute stream: everything the image waits for is ahead of it there.
+// TiffLzwPrep: what a caller that knows the product's geometry before its pixels exist prepares meanwhile (the pipelined
+// default action, on its product writer's thread while the strip is still being read): the device buffers, and the file with
+// the worst-case size reserved and mapped -- writing a NEW file is bound by the allocation of its pages; the
+// file is cut back to the encoded size afterwards.
+struct TiffLzwPrep {
+    DevBuf<uint8_t> payload, scratch;
+    oip_file_sink *sink = nullptr;
+    uint64_t payloadAt = 0;
+    void prepare(TiffWriterU16 &tw, const std::string &path, int width, long height, int spp, bool withSink)
+    {
+        const long rps = tw.rows_per_strip();
+        payload.alloc(oip_tiff_lzw_worst_bytes(height, width, spp, rps));
+        scratch.alloc(oip_tiff_lzw_scratch_bytes(height, width, spp, rps));
+        if (withSink) {
+            payloadAt = tw.begin_external_strips();
+            Device::get().check(oip_file_sink_open(Device::get().ctx(), path.c_str(), (size_t)payloadAt + payload.n, &sink));
+        }
+    }
+    ~TiffLzwPrep() { if (sink) oip_file_sink_close(nullptr, sink); }
+};
+
+inline void tiff_lzw_from_device(TiffWriterU16 &tw, const std::string &path, const uint16_t *d_img, int width, long height, int spp,
+                                 TiffLzwPrep *prep = nullptr)
+{
+    oip_ctx *ctx = Device::get().ctx();
+    stop_watch sw;
+    const long rps = tw.rows_per_strip();
+    const size_t nstrips = (size_t)((height + rps - 1) / rps);
+    TiffLzwPrep own;
+    if (!prep) { prep = &own; prep->payload.alloc(oip_tiff_lzw_worst_bytes(height, width, spp, rps)); }
+    std::vector<uint64_t> off(nstrips), len(nstrips);
+    size_t bytes = 0;
+    const double tAlloc = sw.tick();
+    Device::get().check(oip_tiff_lzw_strips_u16(ctx, d_img, height, width, spp, rps, prep->payload.p, prep->payload.n, off.data(), len.data(), &bytes,
+                                                prep->scratch.p, prep->scratch.n));
+    const double tEncode = sw.tick();
+    const size_t even = (bytes + 1) & ~(size_t)1;
+    if (prep->sink) {
+        Device::get().check(oip_file_sink_write(ctx, prep->sink, (size_t)prep->payloadAt, prep->payload.p, even, 0));
+        oip_file_sink *k = prep->sink;
+        prep->sink = nullptr;
+        Device::get().check(oip_file_sink_close(ctx, k));
+        if (::truncate(path.c_str(), (off_t)(prep->payloadAt + even)) != 0) throw errno_error("truncate() of the TIFF product failed");
+    } else {
+        const uint64_t at = tw.begin_external_strips();
+        Device::get().check(oip_write_device_to_file_at(ctx, prep->payload.p, even, path.c_str(), (size_t)at, 0));
+    }
+    tw.end_external_strips(off.data(), len.data(), nstrips, bytes);
+    const double tWrite = sw.tick();
+    RLOG("TIMING tiff_lzw strips=%zu alloc=%.4f encode=%.4f write=%.4f bytes=%zu prepared=%d", nstrips, tAlloc, tEncode, tWrite, bytes, prep != &own);
+}
+
 // A TIFF product whose pixels are in HBM (rows x width x spp u16, interleaved).  Uncompressed: the pixel payload goes from
 // the device into the file behind the header (TiffWriterU16::begin_external_payload + oip_write_device_to_file_at) -- no
 // strip-sized heap copy, as the reference's cv::imwrite / GDAL paths make (imageop.h:316-328, preproc.h:167-185).  LZW: the
@@ -315,17 +370,7 @@ inline void write_tiff_from_device(const std::string &path, uint16_t *d_img, int
         Device::get().check(oip_write_device_to_file_at(ctx, d_img, (size_t)height * rowSamples * 2, path.c_str(), (size_t)at, mark));
         tw.end_external_payload();
     } else if (gpu_lzw()) {
-        // the strips are encoded where the image is (csrc/tifflzw.hip) and leave the device packed, as one block
-        const long rps = tw.rows_per_strip();
-        const size_t nstrips = (size_t)((height + rps - 1) / rps);
-        DevBuf<uint8_t> payload(oip_tiff_lzw_worst_bytes(height, width, spp, rps));
-        std::vector<uint64_t> off(nstrips), len(nstrips);
-        size_t bytes = 0;
-        // (the encoder runs on the compute stream: everything the image waits for is ahead of it there)
-        Device::get().check(oip_tiff_lzw_strips_u16(ctx, d_img, height, width, spp, rps, payload.p, payload.n, off.data(), len.data(), &bytes));
-        const uint64_t at = tw.begin_external_strips();
-        Device::get().check(oip_write_device_to_file_at(ctx, payload.p, (bytes + 1) & ~(size_t)1, path.c_str(), (size_t)at, 0));
-        tw.end_external_strips(off.data(), len.data(), nstrips, bytes);
+        tiff_lzw_from_device(tw, path, d_img, width, height, spp);
     } else {
         tiff_rows_from_device(tw, d_img, height, rowSamples, mark);
     }
@@ -1010,10 +1055,18 @@ public:
         const int comp = tiff_compression(TIFF_LZW);
         std::unique_ptr<TiffWriterU16> tiff(new TiffWriterU16(alignedPath, Wb, outRows, MSS_BANDS, false, comp));   // (declared before the writers: their jobs use it)
         productGuard.path = alignedPath;
+        std::unique_ptr<TiffLzwPrep> lzwPrep;              // (declared before the writers too)
         JobThread panWriter, productWriter;
         const size_t productBytes = (size_t)outRows * Wb * MSS_BANDS * 2;
         // (an empty transfer: the writer's download lane pins its two slots now, not when the product is waiting for them)
         productWriter.post([=] { Device::get().check(oip_download_staged_after(ctx, nullptr, nullptr, 0, 0)); });
+        if (comp == TIFF_LZW && gpu_lzw()) {
+            // likewise for the LZW product: device buffers of the strip encoder, the file reserved at its worst-case size
+            lzwPrep.reset(new TiffLzwPrep());
+            TiffWriterU16 *twp = tiff.get();
+            TiffLzwPrep *lp = lzwPrep.get();
+            productWriter.post([=] { lp->prepare(*twp, alignedPath, Wb, outRows, MSS_BANDS, true); });
+        }
         if (comp == TIFF_NONE) {
             // the writer thread has nothing to do until the fit is in: it prepares the product file -- header out, blocks
             // reserved, pages mapped and populated (oip_file_sink_open) -- so that the pixels, when they exist, are copied
@@ -1138,6 +1191,7 @@ public:
                 ck(oip_compute_mark(ctx, &mark));
                 TiffWriterU16 *tw = tiff.get();
                 ProductGuard *pg = &productGuard;
+                TiffLzwPrep *lp = lzwPrep.get();
                 const uint16_t *img = out.p;
                 const size_t rowSamples = (size_t)Wb * MSS_BANDS;
                 const long rows = outRows;
@@ -1152,6 +1206,8 @@ public:
                         pg->sink = nullptr;
                         Device::get().check(oip_file_sink_close(ctx, k));
                         tw->end_external_payload();
+                    } else if (gpu_lzw()) {
+                        tiff_lzw_from_device(*tw, alignedPath, img, Wb, rows, MSS_BANDS, lp);
                     } else {
                         tiff_rows_from_device(*tw, img, rows, rowSamples, mark);     // download || encode || write
                     }

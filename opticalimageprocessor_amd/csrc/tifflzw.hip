@@ -172,9 +172,32 @@ extern "C" size_t oip_tiff_lzw_worst_bytes(long rows, int width, int spp, long r
     return nstrips * (strip + strip / 2 + strip / 1024 + 64 + 2);
 }
 
+// device scratch of one call: the lanes' tables, their output slots, the strip lengths and offsets
+static void lzw_scratch_layout(long nstrips, size_t slot_bytes, size_t *tab, size_t *slots, size_t *len, size_t *off, size_t *total)
+{
+    const long per = nstrips < kStripsPerLaunch ? nstrips : kStripsPerLaunch;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    *tab = 0;
+    *slots = up((size_t)per * kSlots * sizeof(unsigned long long));
+    *len = *slots + up((size_t)per * slot_bytes);
+    *off = *len + up((size_t)nstrips * sizeof(unsigned));
+    *total = *off + up((size_t)nstrips * sizeof(unsigned long long));
+}
+
+extern "C" size_t oip_tiff_lzw_scratch_bytes(long rows, int width, int spp, long rows_per_strip)
+{
+    if (rows <= 0 || width <= 0 || spp <= 0 || rows_per_strip <= 0) return 0;
+    const long nstrips = (rows + rows_per_strip - 1) / rows_per_strip;
+    const size_t strip = (size_t)rows_per_strip * width * spp * 2;
+    const size_t slot_bytes = (strip + strip / 2 + strip / 1024 + 64 + 3) / 4 * 4;
+    size_t a, b, c, d, total;
+    lzw_scratch_layout(nstrips, slot_bytes, &a, &b, &c, &d, &total);
+    return total;
+}
+
 extern "C" int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long rows, int width, int spp, long rows_per_strip,
                                        uint8_t *d_payload, size_t payload_cap, uint64_t *strip_off, uint64_t *strip_len,
-                                       size_t *payload_bytes)
+                                       size_t *payload_bytes, void *d_scratch, size_t scratch_bytes)
 {
     OIP_CHECK_CTX(ctx);
     if (!d_img || !d_payload || !strip_off || !strip_len || !payload_bytes || rows <= 0 || width <= 0 || (spp != 1 && spp != 4) ||
@@ -187,15 +210,10 @@ extern "C" int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long
     if (strip > (1u << 30)) return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_strips_u16: strip larger than 1 GiB");
     const size_t slot_bytes = (strip + strip / 2 + strip / 1024 + 64 + 3) / 4 * 4;
     const long per = nstrips < kStripsPerLaunch ? nstrips : kStripsPerLaunch;
-    unsigned long long *d_tab = nullptr, *d_off = nullptr;
-    uint8_t *d_slots = nullptr;
-    unsigned *d_len = nullptr;
-    auto release = [&] {
-        if (d_tab) (void)hipFree(d_tab);
-        if (d_slots) (void)hipFree(d_slots);
-        if (d_len) (void)hipFree(d_len);
-        if (d_off) (void)hipFree(d_off);
-    };
+    size_t o_tab, o_slots, o_len, o_off, need;
+    lzw_scratch_layout(nstrips, slot_bytes, &o_tab, &o_slots, &o_len, &o_off, &need);
+    void *own = nullptr;                         // scratch of this call's own when the caller brought none
+    auto release = [&] { if (own) (void)hipFree(own); };
 #define OIP_LZW_HIP(call)                                                                                     \
     do {                                                                                                      \
         hipError_t e__ = (call);                                                                              \
@@ -204,10 +222,16 @@ extern "C" int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long
             return oip_fail(ctx, OIP_E_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
         }                                                                                                     \
     } while (0)
-    OIP_LZW_HIP(hipMalloc(&d_tab, (size_t)per * kSlots * sizeof(unsigned long long)));
-    OIP_LZW_HIP(hipMalloc(&d_slots, (size_t)per * slot_bytes));
-    OIP_LZW_HIP(hipMalloc(&d_len, (size_t)nstrips * sizeof(unsigned)));
-    OIP_LZW_HIP(hipMalloc(&d_off, (size_t)nstrips * sizeof(unsigned long long)));
+    if (d_scratch) {
+        if (scratch_bytes < need || (((uintptr_t)d_scratch) & 7)) return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_strips_u16: scratch too small or misaligned");
+    } else {
+        OIP_LZW_HIP(hipMalloc(&own, need));
+        d_scratch = own;
+    }
+    unsigned long long *d_tab = reinterpret_cast<unsigned long long *>((char *)d_scratch + o_tab);
+    uint8_t *d_slots = reinterpret_cast<uint8_t *>((char *)d_scratch + o_slots);
+    unsigned *d_len = reinterpret_cast<unsigned *>((char *)d_scratch + o_len);
+    unsigned long long *d_off = reinterpret_cast<unsigned long long *>((char *)d_scratch + o_off);
     std::vector<unsigned> len((size_t)nstrips);
     std::vector<unsigned long long> off((size_t)nstrips);
     size_t pos = 0;

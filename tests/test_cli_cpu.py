@@ -240,6 +240,19 @@ def test_task_subcommand_argument_errors(files):
     assert r.returncode == 109
 
 
+def test_tiff_external_strips_equal_write_rows(tmp_path):
+    """TiffWriterU16::begin_external_strips / end_external_strips (what the device LZW encoder feeds, csrc/tifflzw.hip): strips
+    encoded outside the writer and packed as oip_tiff_lzw_strips_u16 packs them give the file write_rows() gives, byte for byte
+    (seven geometries; ASan + UBSan); misuse is refused."""
+    src = os.path.join(ROOT, "tests", "cpp", "tiff_external_strips_test.cpp")
+    inc = os.path.join(ROOT, "opticalimageprocessor_amd", "csrc")
+    exe = tmp_path / "tiff_external"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + inc, src,
+                    "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "7 cases, 0 bad" in r.stdout, r.stdout + r.stderr
+
+
 def test_rank_failure_protocol_under_thread_sanitizer(tmp_path):
     """csrc/oip_rankguard.hpp (HostBarrier + CommGuard of the N-GPU host): a rank that fails right behind the pre-exchange barrier
     aborts every communicator while its peers are posting grouped sends / receives -- no peer may touch a communicator after

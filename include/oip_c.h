@@ -342,6 +342,15 @@ int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long rows, int 
                             uint8_t *d_payload, size_t payload_cap, uint64_t *strip_off, uint64_t *strip_len,
                             size_t *payload_bytes, void *d_scratch, size_t scratch_bytes);
 
+/* ... and read: the LZW strips of a TIFF file (cv::imread of the stitch inputs, imageop.h:380-388) decoded on the device.
+ * d_file: the file's bytes from some base offset on, already in HBM (oip_read_file_to_device); strip_off / strip_len (host):
+ * every strip's offset inside d_file and its size; chunky u16 samples, predictor 1 or 2.  d_img receives rows x width x spp
+ * samples in file order.  A stream that ends without EndOfInformation is tolerated (as libtiff does); a corrupt stream or a
+ * strip that does not decode to exactly its rows is OIP_E_RUNTIME with the strip named.  Synchronises the stream. */
+int oip_tiff_lzw_decode_u16(oip_ctx *ctx, const uint8_t *d_file, size_t file_bytes, const uint64_t *strip_off,
+                            const uint64_t *strip_len, long nstrips, long rows, int width, int spp, long rows_per_strip,
+                            int predictor, uint16_t *d_img);
+
 /* ---- instrumentation --------------------------------------------------------------- */
 /* name + accumulated device time of the kernels launched through this context since the
  * last reset, measured with HIP events on the context's stream (off by default). */

@@ -75,6 +75,7 @@ _SIGS = {
     "oip_permute_u16x4": ([_vp, _vp, _sz, C.POINTER(_i)], _i),
     "oip_tiff_lzw_worst_bytes": ([_l, _i, _i, _l], _sz),
     "oip_tiff_lzw_scratch_bytes": ([_l, _i, _i, _l], _sz),
+    "oip_tiff_lzw_decode_u16": ([_vp, _vp, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _l, _l, _i, _i, _l, _i, _vp], _i),
     "oip_tiff_lzw_strips_u16": ([_vp, _vp, _l, _i, _i, _l, _vp, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(_sz), _vp, _sz], _i),
     "oip_upload_staged": ([_vp, _vp, _vp, _sz, _lp], _i),
     "oip_upload_staged_2d": ([_vp, _vp, _sz, _vp, _sz, _sz, _sz, _lp], _i),
@@ -349,6 +350,14 @@ class Context:
                                                   _ptr(scratch) if scratch is not None else None,
                                                   scratch.numel() * scratch.element_size() if scratch is not None else 0))
         return np.array(off[:], dtype=np.uint64), np.array(ln[:], dtype=np.uint64), total.value
+
+    def tiff_lzw_decode(self, d_file, strip_off, strip_len, rows, width, spp, rows_per_strip, predictor, d_img):
+        """LZW strips in `d_file` (device, uint8; offsets relative to it) decoded into d_img (device, rows x width x spp u16)"""
+        n = len(strip_off)
+        off = (C.c_uint64 * n)(*[int(v) for v in strip_off])
+        ln = (C.c_uint64 * n)(*[int(v) for v in strip_len])
+        self._ck(self.lib.oip_tiff_lzw_decode_u16(self.h, _ptr(d_file), d_file.numel() * d_file.element_size(), off, ln, n, rows, width, spp,
+                                                  rows_per_strip, predictor, _ptr(d_img)))
 
     def tiff_lzw_scratch_bytes(self, rows, width, spp, rows_per_strip):
         return int(self.lib.oip_tiff_lzw_scratch_bytes(rows, width, spp, rows_per_strip))

@@ -378,6 +378,40 @@ inline void write_tiff_from_device(const std::string &path, uint16_t *d_img, int
 }
 
 
+// cv::imread of a 16-bit TIFF (imageop.h:380-388) with the image ending up in HBM.  LZW files -- what the reference's own
+// products are -- go from the file into device memory as they are and their strips are decoded there (csrc/tifflzw.hip: a
+// strip per lane); anything else, and OIP_TIFF_GPU_LZW=0, decodes on the host's threads (read_tiff_u16) and uploads.  Same
+// checks and error texts either way: the header is validated by the host reader in both.
+inline void read_tiff_to_device(const std::string &path, int *width, long *height, int *spp, DevBuf<uint16_t> &img)
+{
+    TiffLayout lay;
+    read_tiff_u16(path, width, height, spp, nullptr, &lay);
+    const size_t samples = (size_t)lay.width * lay.height * lay.spp;
+    bool device = gpu_lzw() && lay.compression == TIFF_LZW && (lay.spp == 1 || lay.spp == 4) &&
+                  lay.rows_per_strip * lay.width * lay.spp * 2 < ((uint64_t)1 << 32);
+    uint64_t lo = ~(uint64_t)0, hi = 0;
+    for (size_t k = 0; k < lay.offs.size(); ++k) { lo = std::min(lo, lay.offs[k]); hi = std::max(hi, lay.offs[k] + lay.lens[k]); }
+    if (device && hi - lo > 3 * samples + ((uint64_t)64 << 20)) device = false;       // strips scattered over a far larger file
+    if (!device) {
+        std::vector<uint16_t> host;
+        read_tiff_u16(path, width, height, spp, &host);
+        img.alloc(host.size());
+        img.upload(host.data(), host.size());
+        return;
+    }
+    oip_ctx *ctx = Device::get().ctx();
+    DevBuf<uint8_t> file((size_t)(hi - lo));
+    size_t got = 0;
+    Device::get().check(oip_read_file_to_device(ctx, path.c_str(), (size_t)lo, (size_t)(hi - lo), file.p, &got, nullptr));
+    if (got != (size_t)(hi - lo)) throw std::runtime_error("read TIFF [" + path + "]: truncated file");
+    Device::get().check(oip_stage_sync(ctx));
+    for (auto &o : lay.offs) o -= lo;
+    img.alloc(samples);
+    const int rc = oip_tiff_lzw_decode_u16(ctx, file.p, file.n, lay.offs.data(), lay.lens.data(), (long)lay.offs.size(), (long)lay.height,
+                                           (int)lay.width, (int)lay.spp, (long)lay.rows_per_strip, (int)lay.predictor, img.p);
+    if (rc != OIP_OK) throw std::runtime_error("read TIFF [" + path + "]: " + std::string(oip_last_error(ctx)));
+}
+
 // ---- ImageOperations (imageop.h:33-568, hot-path subset) -----------------------------------------
 struct RRCParam { double k; double b; };     // imageop.h:26-29
 
@@ -560,35 +594,32 @@ public:
             throw std::invalid_argument("Output file should be a tiff image");
         int wl, wr, sl, sr;
         long hl, hr;
-        std::vector<uint16_t> L, R;
+        DevBuf<uint16_t> dl, dr;
         OLOG("Reading tiff image from file `%s' ...", leftImagePath.c_str());
-        read_tiff_u16(leftImagePath, &wl, &hl, &sl, &L);
+        read_tiff_to_device(leftImagePath, &wl, &hl, &sl, dl);
         OLOG("Reading tiff image from file `%s' ...", rightImagePath.c_str());
-        read_tiff_u16(rightImagePath, &wr, &hr, &sr, &R);
+        read_tiff_to_device(rightImagePath, &wr, &hr, &sr, dr);
         if (hl != hr || wl != wr) throw std::runtime_error("images have different sizes");
         if (sl != MSS_BANDS || sr != MSS_BANDS) throw std::runtime_error("StitchTiff(): 4-channel 16-bit images expected");
         if (foldColPixels < 0 || foldColPixels >= wl) throw std::invalid_argument("fold columns exceed the image width");
         // the stitch itself: 4 interleaved samples per pixel are just 4x wider u16 lines
         const int W4 = wl * 4, fold4 = foldColPixels * 4;
         const size_t nin = (size_t)W4 * hl, nout = (size_t)2 * (W4 - fold4) * hl;
-        DevBuf<uint16_t> dl(nin), dr(nin), dout(nout);
-        dl.upload(L.data(), nin);
-        dr.upload(R.data(), nin);
+        (void)nin;
+        DevBuf<uint16_t> dout(nout);
         Device::get().check(oip_stitch_rows_u16(Device::get().ctx(), dl.p, dr.p, dout.p, W4, hl, fold4));
-        std::vector<uint16_t> out(nout);
-        dout.download(out.data(), nout);
         const int ow = 2 * (wl - foldColPixels);
         OLOG("Write stitched image to file '%s' ...", outputFilePath.c_str());
-        // file order is RGBA = (c2, c1, c0, c3) of the reference's Mat
+        // file order is RGBA = (c2, c1, c0, c3) of the reference's Mat.  The stitched image stays on the device: its samples are
+        // put in file order there and the product goes out like every other TIFF of the CLI (LZW strips encoded on the device)
         const size_t bytes = nout * 2;
         if (!useGDAL && bytes / 2 < 4000000000ull) {
-            int ident[4] = {0, 1, 2, 3};                       // same on-disk order in and out
-            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, ident, tiff_compression(TIFF_LZW));
+            write_tiff_from_device(outputFilePath, dout.p, ow, hl, MSS_BANDS, tiff_compression(TIFF_LZW), false);   // same on-disk order in and out
         } else {
             const int mat2file[4] = {2, 1, 0, 3};              // Mat channel c lives at file sample mat2file[c]
             int order[4];
             for (int b = 0; b < 4; ++b) order[b] = mat2file[bandMap ? bandMap[b] - 1 : b];
-            write_tiff_u16_mapped(outputFilePath, out.data(), ow, hl, order, tiff_compression(TIFF_LZW));
+            write_tiff_from_device(outputFilePath, dout.p, ow, hl, MSS_BANDS, tiff_compression(TIFF_LZW), false, order);
         }
         return outputFilePath;
     }

@@ -543,7 +543,14 @@ private:
 // Reader for little-endian, chunky, unsigned 16-bit strip TIFF / BigTIFF, uncompressed or LZW (predictor 1 or
 // 2): what the writer above, cv::imwrite and GDAL's GTiff driver (INTERLEAVE=PIXEL, untiled) produce.  Samples
 // are returned in file order.  Every header field is checked before it sizes an allocation or a read.
-inline void read_tiff_u16(const std::string &path, int *width, long *height, int *spp, std::vector<uint16_t> *out)
+// layout_only: the checked header alone -- geometry, encoding and strip table -- for a caller that brings the strips in itself
+// (the device decoder: oip_host.hpp::read_tiff_to_device)
+struct TiffLayout {
+    uint64_t width = 0, height = 0, spp = 0, compression = 1, predictor = 1, rows_per_strip = 0;
+    std::vector<uint64_t> offs, lens;
+};
+inline void read_tiff_u16(const std::string &path, int *width, long *height, int *spp, std::vector<uint16_t> *out,
+                          TiffLayout *layout_only = nullptr)
 {
     struct FileGuard {
         FILE *f;
@@ -626,6 +633,13 @@ inline void read_tiff_u16(const std::string &path, int *width, long *height, int
         uint64_t packed = 0;
         for (uint64_t l : lens) packed += l;
         if (row_bytes * H / 2560 > packed + 16) fail("image size is implausible for its compressed strips");
+    }
+    if (layout_only) {
+        layout_only->width = W; layout_only->height = H; layout_only->spp = S; layout_only->compression = comp;
+        layout_only->predictor = pred; layout_only->rows_per_strip = rps;
+        layout_only->offs = offs; layout_only->lens = lens;
+        *width = (int)W; *height = (long)H; *spp = (int)S;
+        return;
     }
     try {
         out->resize((size_t)(W * H * S));

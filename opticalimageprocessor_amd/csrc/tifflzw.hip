@@ -162,6 +162,105 @@ __global__ __launch_bounds__(256) void lzw_pack_kernel(const uint8_t *__restrict
     }
 }
 
+
+// ---- the other direction: the LZW strips of a TIFF file decoded on the device ------------------------------------------------
+// cv::imread of the two ALIGNED.TIFF inputs of the MSS stitch (imageop.h:380-388) decodes on the host; here the strips' bytes go
+// from the file into HBM as they are (oip_read_file_to_device) and a lane decodes a strip straight into the image.  An LZW
+// string is always a substring of what has already been decoded -- entry `next` is the previous string plus the first byte of
+// the current one, and those are adjacent in the output -- so a table entry is (position, length) in the lane's own output and
+// emitting a code is a forward byte copy inside the image (which also makes the KwKwK case, code == next, nothing special).
+// Same acceptance rules as tiffdetail::lzw_decode (oip_tiff.hpp): a stream that ends without EndOfInformation is tolerated, a
+// first code >= 256, a code beyond the table or a table that fills without ClearCode are corrupt; a strip must decode to
+// exactly its rows.  Predictor 2 is undone by the same lane afterwards (running sums along its rows).
+struct LzwDecJob {
+    const uint8_t *file;
+    const unsigned long long *off, *len;         // [nstrips]: strip offsets inside `file`, byte counts
+    long rows;
+    int width, spp;
+    long rps, nstrips, strip0;
+    int predictor;
+    uint16_t *img;
+    unsigned long long *tab;                     // per lane 4096 x (position | length << 32)
+    unsigned *got;                               // [nstrips] bytes a strip decoded to
+    int *status;                                 // [nstrips] 0 ok, 1 bad first code, 2 code beyond the table, 3 table full
+};
+
+__global__ __launch_bounds__(64) void lzw_decode_kernel(LzwDecJob j)
+{
+    const long local = (long)blockIdx.x * 64 + threadIdx.x;
+    const long k = j.strip0 + local;
+    if (k >= j.nstrips) return;
+    unsigned long long *tab = j.tab + (size_t)local * 4096;
+    const uint8_t *in = j.file + j.off[k];
+    const unsigned n = (unsigned)j.len[k];
+    const size_t rowBytes = (size_t)j.width * j.spp * 2;
+    const long r0 = k * j.rps;
+    long nr = j.rows - r0;
+    if (nr > j.rps) nr = j.rps;
+    uint8_t *out = reinterpret_cast<uint8_t *>(j.img) + (size_t)r0 * rowBytes;
+    const unsigned cap = (unsigned)((size_t)nr * rowBytes);
+    int width = 9, next = 258, status = 0;
+    bool have_old = false;
+    unsigned long long acc = 0;
+    int nbits = 0;
+    unsigned ip = 0, pos = 0, old_pos = 0, old_len = 0;
+    for (;;) {
+        while (nbits < width && ip < n) { acc = (acc << 8) | in[ip++]; nbits += 8; }
+        if (nbits < width) break;                                              // stream ends without EOI: tolerated, as libtiff does
+        const unsigned code = (unsigned)(acc >> (nbits - width)) & ((1u << width) - 1);
+        nbits -= width;
+        if (code == 257u) break;
+        if (code == 256u) { width = 9; next = 258; have_old = false; continue; }
+        if (!have_old) {
+            if (code >= 256u) { status = 1; break; }
+            if (pos < cap) out[pos] = (uint8_t)code;
+            old_pos = pos; old_len = 1; ++pos;
+            have_old = true;
+            continue;
+        }
+        if (next >= 4096) { status = 3; break; }
+        if (code > (unsigned)next) { status = 2; break; }
+        const unsigned long long fresh = (unsigned long long)old_pos | ((unsigned long long)(old_len + 1) << 32);
+        tab[next] = fresh;                                                     // previous string + this string's first byte
+        unsigned clen = 1;
+        if (code < 256u) {
+            if (pos < cap) out[pos] = (uint8_t)code;
+        } else {
+            const unsigned long long e = code == (unsigned)next ? fresh : tab[code];
+            const unsigned src = (unsigned)e;
+            clen = (unsigned)(e >> 32);
+            for (unsigned i = 0; i < clen; ++i)
+                if (pos + i < cap) out[pos + i] = out[src + i];               // src + i < pos + i: forward copy, overlap included
+        }
+        old_pos = pos; old_len = clen; pos += clen;
+        ++next;
+        if (next >= (1 << width) - 1 && width < 12) ++width;                   // early change
+        if (pos >= cap && ip >= n) break;
+    }
+    j.got[k] = pos;
+    j.status[k] = status;
+    if (status != 0 || pos != cap || j.predictor != 2) return;
+    // predictor 2: every sample plus the same channel of the previous pixel, modulo 2^16, row by row
+    if (j.spp == 4) {
+        for (long r = 0; r < nr; ++r) {
+            unsigned long long *row = reinterpret_cast<unsigned long long *>(out + (size_t)r * rowBytes);
+            unsigned long long prev = row[0];
+            for (int x = 1; x < j.width; ++x) {
+                const unsigned long long d = row[x];
+                // four 16-bit adds in one register: the low 15 bits of every lane carry on their own, the top bits by xor
+                const unsigned long long m = 0x7fff7fff7fff7fffull;
+                prev = ((prev & m) + (d & m)) ^ ((prev ^ d) & ~m);
+                row[x] = prev;
+            }
+        }
+    } else {
+        const int spp = j.spp;
+        for (long r = 0; r < nr; ++r) {
+            uint16_t *row = reinterpret_cast<uint16_t *>(out + (size_t)r * rowBytes);
+            for (long i = spp; i < (long)j.width * spp; ++i) row[i] = (uint16_t)(row[i] + row[i - spp]);
+        }
+    }
+}
 }  // namespace
 
 extern "C" size_t oip_tiff_lzw_worst_bytes(long rows, int width, int spp, long rows_per_strip)
@@ -266,5 +365,61 @@ extern "C" int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long
     release();
     for (long k = 0; k < nstrips; ++k) { strip_off[k] = off[(size_t)k]; strip_len[k] = len[(size_t)k]; }
     *payload_bytes = pos;
+    return OIP_OK;
+}
+
+extern "C" int oip_tiff_lzw_decode_u16(oip_ctx *ctx, const uint8_t *d_file, size_t file_bytes, const uint64_t *strip_off,
+                                       const uint64_t *strip_len, long nstrips, long rows, int width, int spp, long rows_per_strip,
+                                       int predictor, uint16_t *d_img)
+{
+    OIP_CHECK_CTX(ctx);
+    if (!d_file || !strip_off || !strip_len || !d_img || nstrips <= 0 || rows <= 0 || width <= 0 || spp <= 0 || spp > 16 || rows_per_strip <= 0 ||
+        (predictor != 1 && predictor != 2))
+        return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_decode_u16: bad argument");
+    if (nstrips != (rows + rows_per_strip - 1) / rows_per_strip) return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_decode_u16: strip count does not match RowsPerStrip");
+    const size_t rowBytes = (size_t)width * spp * 2;
+    if ((size_t)rows_per_strip * rowBytes >= ((size_t)1 << 32)) return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_decode_u16: strip of 4 GiB or more");
+    if (spp == 4 && predictor == 2 && (((uintptr_t)d_img) & 7)) return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_decode_u16: image not 8-byte aligned");
+    for (long k = 0; k < nstrips; ++k)
+        if (strip_off[k] > file_bytes || strip_len[k] > file_bytes - strip_off[k] || strip_len[k] >= ((uint64_t)1 << 32))
+            return oip_fail(ctx, OIP_E_INVALID, "oip_tiff_lzw_decode_u16: strip %ld outside the buffer", k);
+    const long per = nstrips < kStripsPerLaunch ? nstrips : kStripsPerLaunch;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_off = up((size_t)per * 4096 * 8), o_len = o_off + up((size_t)nstrips * 8), o_got = o_len + up((size_t)nstrips * 8),
+                 o_status = o_got + up((size_t)nstrips * 4), need = o_status + up((size_t)nstrips * 4);
+    void *scratch = nullptr;
+    OIP_HIP(ctx, hipMalloc(&scratch, need));
+    auto fail = [&](int rc) { (void)hipFree(scratch); return rc; };
+    unsigned long long *d_tab = reinterpret_cast<unsigned long long *>(scratch);
+    unsigned long long *d_off = reinterpret_cast<unsigned long long *>((char *)scratch + o_off);
+    unsigned long long *d_len = reinterpret_cast<unsigned long long *>((char *)scratch + o_len);
+    unsigned *d_got = reinterpret_cast<unsigned *>((char *)scratch + o_got);
+    int *d_status = reinterpret_cast<int *>((char *)scratch + o_status);
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "strip tables are copied as they are");
+    if (hipMemcpyAsync(d_off, strip_off, (size_t)nstrips * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_len, strip_len, (size_t)nstrips * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(oip_fail(ctx, OIP_E_DEVICE, "oip_tiff_lzw_decode_u16: copying the strip tables failed"));
+    for (long s0 = 0; s0 < nstrips; s0 += per) {
+        const long ns = nstrips - s0 < per ? nstrips - s0 : per;
+        LzwDecJob j{d_file, d_off, d_len, rows, width, spp, rows_per_strip, nstrips, s0, predictor, d_img, d_tab, d_got, d_status};
+        OipProfScope prof(ctx, "lzw_decode_kernel");
+        hipLaunchKernelGGL(lzw_decode_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, j);
+    }
+    std::vector<unsigned> got((size_t)nstrips);
+    std::vector<int> status((size_t)nstrips);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(got.data(), d_got, (size_t)nstrips * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(status.data(), d_status, (size_t)nstrips * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(oip_fail(ctx, OIP_E_DEVICE, "oip_tiff_lzw_decode_u16: decoding failed on the device"));
+    (void)hipFree(scratch);
+    for (long k = 0; k < nstrips; ++k) {
+        const long nr = rows - k * rows_per_strip < rows_per_strip ? rows - k * rows_per_strip : rows_per_strip;
+        const size_t want = (size_t)nr * rowBytes;
+        if (status[(size_t)k] == 1) return oip_fail(ctx, OIP_E_RUNTIME, "corrupt LZW stream (bad first code) in strip %ld", k);
+        if (status[(size_t)k] == 2) return oip_fail(ctx, OIP_E_RUNTIME, "corrupt LZW stream (code beyond the table) in strip %ld", k);
+        if (status[(size_t)k] == 3) return oip_fail(ctx, OIP_E_RUNTIME, "corrupt LZW stream (table full without ClearCode) in strip %ld", k);
+        if (got[(size_t)k] != want) return oip_fail(ctx, OIP_E_RUNTIME, "strip %ld decodes to %u bytes, %zu expected", k, got[(size_t)k], want);
+    }
     return OIP_OK;
 }

@@ -76,3 +76,85 @@ def test_device_lzw_rejects_bad_arguments(ctx):
         oip.tiff_lzw_strips(d_img, 1, 64, 3, 1, d_pay)               # spp 3
     with pytest.raises(ValueError):
         oip.tiff_lzw_strips(d_img, 1, 64, 4, 1, d_pay)               # payload too small
+
+
+def _pack(strips):
+    """strips one behind the other at even offsets, as a TIFF file holds them"""
+    blob, off, ln = bytearray(b"\x00" * 6), [], []              # some bytes in front: the strips need not start the buffer
+    for s in strips:
+        if len(blob) & 1:
+            blob.append(0)
+        off.append(len(blob)); ln.append(len(s))
+        blob += s
+    return np.frombuffer(bytes(blob), dtype=np.uint8).copy(), off, ln
+
+
+@pytest.mark.parametrize("rows,width,spp,rps,kind,pred", [
+    (40, 720, 4, 11, "noise12", 2),
+    (6, 7500, 4, 1, "scene", 2),
+    (6, 2048, 1, 3, "ramp", 2),
+    (5, 1000, 4, 2, "constant", 2),            # one long run: nothing but KwKwK-style growth
+    (2, 16384, 4, 1, "noise16", 1),            # no predictor; many table generations
+    (130, 64, 4, 1, "noise12", 2),
+    (4, 33, 1, 4, "scene", 1),
+])
+def test_device_lzw_decoder_reads_the_independent_coders_strips(ctx, rows, width, spp, rps, kind, pred):
+    """strips written by tests/_tiff.py::lzw_encode (an independent coder) decode on the device to the image, predictor undone"""
+    img = _image(kind, rows, width, spp, seed=rows * 17 + width)
+    strips = []
+    for k in range((rows + rps - 1) // rps):
+        block = img[k * rps:(k + 1) * rps]
+        strips.append(_tiff.lzw_encode(_predict(block, spp) if pred == 2 else block.astype("<u2").tobytes()))
+    blob, off, ln = _pack(strips)
+    d_file = torch.from_numpy(blob).cuda()
+    d_img = torch.full((rows, width * spp), -1, dtype=torch.int16, device="cuda")
+    ctx.tiff_lzw_decode(d_file, off, ln, rows, width, spp, rps, pred, d_img)
+    assert np.array_equal(d_img.cpu().numpy().view(np.uint16), img)
+
+
+def test_device_lzw_round_trip_at_product_width(ctx):
+    """the device encoder's strips through the device decoder: 300 rows of a 7500 x 4 product"""
+    rows, width, spp = 300, 7500, 4
+    img = _image("noise12", rows, width, spp, seed=5)
+    d_img = torch.from_numpy(img.view(np.int16)).cuda()
+    d_pay = torch.empty(ctx.tiff_lzw_worst_bytes(rows, width, spp, 1), dtype=torch.uint8, device="cuda")
+    off, ln, total = ctx.tiff_lzw_strips(d_img, rows, width, spp, 1, d_pay)
+    d_back = torch.zeros_like(d_img)
+    ctx.tiff_lzw_decode(d_pay, off, ln, rows, width, spp, 1, 2, d_back)
+    assert torch.equal(d_back, d_img) and total < img.nbytes * 1.2
+
+
+def test_device_lzw_decoder_rejects_corrupt_strips(ctx):
+    """the rules of the host decoder (csrc/oip_tiff.hpp::lzw_decode): a first code >= 256, a code beyond the table and a strip that
+    does not decode to its rows are errors that name the strip; a stream cut before EndOfInformation is read as far as it goes"""
+    rows, width, spp = 2, 64, 1
+    img = _image("ramp", rows, width, spp, seed=1)
+    good = [_tiff.lzw_encode(_predict(img[k:k + 1], spp)) for k in range(rows)]
+
+    def codes(vals, w=9):
+        acc, n, out = 0, 0, bytearray()
+        for v in vals:
+            acc = (acc << w) | v; n += w
+            while n >= 8:
+                out.append((acc >> (n - 8)) & 255); n -= 8
+        if n:
+            out.append((acc << (8 - n)) & 255)
+        return bytes(out)
+
+    d_img = torch.zeros((rows, width), dtype=torch.int16, device="cuda")
+    for bad, what in ((codes([256, 300, 257]), "bad first code"), (codes([256, 65, 400, 257]), "code beyond the table"),
+                      (good[1][:len(good[1]) // 2], "decodes to"), (codes([256, 65, 66, 257]), "decodes to")):
+        blob, off, ln = _pack([good[0], bad])
+        with pytest.raises(RuntimeError, match=what + ".*strip 1|strip 1.*" + what):
+            ctx.tiff_lzw_decode(torch.from_numpy(blob).cuda(), off, ln, rows, width, spp, 1, 2, d_img)
+    blob, off, ln = _pack(good)
+    with pytest.raises(ValueError):
+        ctx.tiff_lzw_decode(torch.from_numpy(blob).cuda(), off, [ln[0], len(blob)], rows, width, spp, 1, 2, d_img)     # strip outside the buffer
+    # a stream without EndOfInformation that carries all its bytes is fine (libtiff tolerates it)
+    full = _tiff.lzw_encode(_predict(img[1:2], spp))
+    blob, off, ln = _pack([good[0], full[:-1]])
+    try:
+        ctx.tiff_lzw_decode(torch.from_numpy(blob).cuda(), off, ln, rows, width, spp, 1, 2, d_img)
+        assert np.array_equal(d_img.cpu().numpy().view(np.uint16), img)
+    except RuntimeError as e:                      # (cutting the last byte may also cut the last code: then the strip is short)
+        assert "decodes to" in str(e)

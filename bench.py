@@ -515,8 +515,8 @@ def cli_default_action(env, d, kb_mss, threshold):
         subprocess.run([exe, "--version"], cwd=tmp, capture_output=True)
         startup_ms = (time.perf_counter() - t1) * 1e3
         plan = [("raw", {"OIP_TIFF_COMPRESS": "none"}, []), ("raw_again", {"OIP_TIFF_COMPRESS": "none"}, []),
-                ("raw_rrcpan", {"OIP_TIFF_COMPRESS": "none"}, ["--write-rrcpan"]), ("lzw", {}, []),
-                ("steps_raw", {"OIP_TIFF_COMPRESS": "none", "OIP_PIPELINE": "0"}, [])]
+                ("raw_rrcpan", {"OIP_TIFF_COMPRESS": "none"}, ["--write-rrcpan"]),
+                ("steps_raw", {"OIP_TIFF_COMPRESS": "none", "OIP_PIPELINE": "0"}, []), ("lzw", {}, [])]
         for name, extra_env, extra_args in plan:
             for f in ("B_MSS.ALIGNED.TIFF", "B_PAN.RRC.RAW"):
                 if os.path.exists(os.path.join(tmp, f)):
@@ -549,6 +549,23 @@ def cli_default_action(env, d, kb_mss, threshold):
                 same = bool(np.array_equal(got, want))
                 del got
             runs[name] = rec
+        # the reference's step 5 on that LZW product (imageop.h:365-457: cv::imread x 2, concat, cv::imwrite): `oip stitch` of the
+        # file with itself -- strips decoded and encoded on the device (csrc/tifflzw.hip)
+        prod = os.path.join(tmp, "B_MSS.ALIGNED.TIFF")
+        if runs.get("lzw", {}).get("exit") == 0 and os.path.exists(prod):
+            e = dict(os.environ, LOGFILE=os.path.join(tmp, "oip.log"))
+            e.pop("OIP_TIFF_COMPRESS", None)
+            t1 = time.perf_counter()
+            r = subprocess.run([exe, "stitch", "--image1", "B_MSS.ALIGNED.TIFF", "--image2", "B_MSS.ALIGNED.TIFF", "--fold-cols", "50", "-o",
+                                "B_STITCHED.TIFF"], cwd=tmp, env=e, capture_output=True, text=True)
+            rec = {"wall_ms": (time.perf_counter() - t1) * 1e3, "exit": r.returncode}
+            if r.returncode != 0:
+                rec["tail"] = (r.stdout + r.stderr)[-400:]
+            out_path = os.path.join(tmp, "B_STITCHED.TIFF")
+            if os.path.exists(out_path):
+                rec["product_bytes"] = os.path.getsize(out_path)
+                os.remove(out_path)
+            runs["stitch_tiff_lzw"] = rec
         best = min((runs[k] for k in ("raw", "raw_again") if runs[k]["exit"] == 0), key=lambda r_: r_["wall_ms"], default=None)
         out = {"runs": runs, "version_only_ms": startup_ms, "aligned_product_equals_resident_step": same, "inputs_written_s": t_inputs, "tmp": base,
                "bytes_in": int((pb + mb) * W * 2), "what": ("wall time of the `oip` executable (process start, HIP initialisation, file reads, "
@@ -901,7 +918,8 @@ def compact_line(line, full_path):
         cfg["cli_read_GBs"] = round(cli["read_GBs"], 1) if cli.get("read_GBs") else None
         cfg["cli_product_equals_resident_step"] = cli.get("aligned_product_equals_resident_step")
         cfg["cli_note"] = ("wall of the `oip` executable on files in tmpfs, ms per run: raw = uncompressed aligned product (two runs), "
-                           "raw_rrcpan = + <pan>.RRC.RAW, lzw = the reference's LZW product, steps_raw = the step-by-step flow; "
+                           "raw_rrcpan = + <pan>.RRC.RAW, lzw = the reference's LZW product (strips encoded on the device), steps_raw = the step-by-step "
+                           "flow, stitch_tiff_lzw = `oip stitch` of that LZW product with itself (device decode + encode); "
                            "cli_pipeline_ms = first byte read to products on disk (the log's own clock)")
     elif cli:
         cfg["cli_error"] = cli.get("error")

@@ -17,3 +17,10 @@ for rep in range(3):
     off, ln, total = c.tiff_lzw_strips(img, H, W, S, 1, pay)
     dt = time.time() - t0
     print("rows %d: %.1f ms for %.2f GB -> %.2f GB (%.3f)" % (H, dt * 1e3, H * W * S * 2 / 1e9, total / 1e9, total / (H * W * S * 2)))
+back = torch.zeros_like(img)
+for rep in range(3):
+    t0 = time.time()
+    c.tiff_lzw_decode(pay, off, ln, H, W, S, 1, 2, back)
+    dt = time.time() - t0
+    print("decode rows %d: %.1f ms" % (H, dt * 1e3))
+print("round trip equal:", bool(torch.equal(back, img)))

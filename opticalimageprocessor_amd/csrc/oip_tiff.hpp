@@ -45,13 +45,40 @@ enum TiffCompression { TIFF_NONE = 1, TIFF_LZW = 5 };
 
 namespace tiffdetail {
 
-// threads of the strip encoder / decoder: half the host's threads, at most 64 (OIP_TIFF_THREADS overrides, up to 128) -- LZW is
-// the one stage of a compressed product that stays on the CPU, ~100 MB/s per thread
+// CPUs this process may actually use: the cgroup's CPU quota where there is one (a container that shows all 256 hardware threads
+// of the host and grants 16 CPUs of time -- cpu.max = "1600000 100000" -- is the normal case for one rank of a GPU node), else
+// the hardware's count.  More runnable threads than the quota only get the whole group throttled.
+inline int cpu_budget()
+{
+    static const int n = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                  // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            if (fscanf(g, "%ld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%ld", &period) != 1) period = 0; fclose(h); }
+        }
+        if (quota > 0 && period > 0) {
+            const int c = (int)((quota + period - 1) / period);
+            if (c >= 1 && c < hw) hw = c;
+        }
+        return hw;
+    }();
+    return n;
+}
+
+// threads of the host strip encoder / decoder: the CPUs the process may use, at most 64 (OIP_TIFF_THREADS overrides, up to 128).
+// Device-resident products and LZW inputs do not come here: their strips are coded on the device (csrc/tifflzw.hip).
 inline int worker_count()
 {
     static const int n = [] {
         const char *e = getenv("OIP_TIFF_THREADS");
-        int v = e ? atoi(e) : (int)std::thread::hardware_concurrency() / 2;
+        int v = e ? atoi(e) : cpu_budget();
         const int cap = e ? 128 : 64;
         return v < 1 ? 1 : (v > cap ? cap : v);
     }();

@@ -286,6 +286,7 @@ public:
         if (mRowsPerStrip > height) mRowsPerStrip = height;
         const size_t nstrips = ((size_t)height + mRowsPerStrip - 1) / mRowsPerStrip;
         mBig = worst + nstrips * 16 + 16384 > 0xFFFFF000ull;                  // header, page-aligned payload, strip tables, directory
+        if (const char *e = getenv("OIP_TIFF_FORCE_BIG")) mBig = mBig || atoi(e) != 0;   // test hook: BigTIFF at any size
         mF = fopen(path.c_str(), "wb");
         if (!mF) throw std::runtime_error("open file [" + path + "] failed");
         if (mBig) {

@@ -108,6 +108,28 @@ def test_tiff_writer_roundtrip(tmp_path, comp):
                 assert np.array_equal(np.asarray(im), want)
 
 
+def test_tiff_writer_bigtiff_hook(tmp_path):
+    """BigTIFF layout (what products past 4 GiB get) at a small size through the OIP_TIFF_FORCE_BIG test hook: both encodings, read
+    by the independent Python reader and by the product's own reader"""
+    import numpy as np
+    import _tiff
+    exe = _tiff_tool(tmp_path)
+    env = dict(os.environ, OIP_TIFF_FORCE_BIG="1")
+    for comp in (1, 5):
+        w, h, spp = 301, 97, 4
+        out = tmp_path / ("big_%d.tiff" % comp)
+        subprocess.run([str(exe), "write", str(out), str(w), str(h), str(spp), str(comp)], check=True, env=env)
+        img, tags, big = _tiff.read_tiff_u16(str(out))
+        n = w * h * spp
+        want = (((np.arange(n, dtype=np.uint64) * 2654435761 % (1 << 32)) >> 7) & (0x0fff if comp == 5 else 0xffff)).astype(np.uint16)
+        want = want.reshape(h, w, spp)[:, :, [2, 1, 0, 3]]
+        assert big and tags[259] == [comp] and np.array_equal(img, want)
+        raw = tmp_path / "back.raw"
+        r = subprocess.run([str(exe), "read", str(out), str(raw)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.split() == [str(w), str(h), str(spp)]
+        assert np.array_equal(np.fromfile(str(raw), np.uint16).reshape(h, w, spp), want)
+
+
 def test_tiff_reader(tmp_path):
     """oip_tiff.hpp reader: its own files (both compressions), foreign uncompressed files, LZW files written by Pillow
     (libtiff; predictor 1 and 2) and by the independent Python encoder (4 samples, predictor 2, one row per strip

@@ -160,8 +160,9 @@ def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
             # tiff_rows_from_device runs over many blocks on this small image)
             # The step-by-step run encodes its LZW strips on the host's threads (OIP_TIFF_GPU_LZW=0), the pipelined one on the
             # device (csrc/tifflzw.hip): the byte comparison below is also the device encoder against the host encoder.
+            # OIP_TIFF_FORCE_BIG: the LZW products are BigTIFF files (64-bit offsets, as products past 4 GiB are), read back below.
             env = dict(os.environ, LOGFILE=os.path.join(d, "oip.log"), OIP_PIPELINE=pl, OIP_TIFF_COMPRESS=comp, OIP_TIFF_CHUNK_MB="1",
-                       OIP_TIFF_GPU_LZW=pl)
+                       OIP_TIFF_GPU_LZW=pl, OIP_TIFF_FORCE_BIG="1" if comp == "lzw" else "0")
             args = [OIP, "--width", str(W), "--pan", "T_PAN.RAW", "--mss", "T_MSS.RAW", "--do-rrc4pan", "--rrc-pan", "PAN.csv", "--write-rrcpan",
                     "--slices", "9", "--ibc-sections", "2", "--ibc-threshold", "0", "--lines-section", "3000", "--overlap-lines", "100"]
             for b in range(4):
@@ -184,6 +185,8 @@ def test_pipelined_default_action_equals_the_step_by_step_one(tmp_path):
     # re-written uncompressed, which the independent reader of tests/_tiff.py compares (its own LZW decoder needs minutes per MB)
     d = runs[("lzw", "pipe")][0]
     assert _tiff.read_tags(os.path.join(d, "T_MSS.ALIGNED.TIFF"))[259] == [5] and _tiff.read_tags(os.path.join(d, "T_MSS.ALIGNED.TIFF"))[317] == [2]
+    with open(os.path.join(d, "T_MSS.ALIGNED.TIFF"), "rb") as f:
+        assert f.read(4) == b"II+\x00"                                  # BigTIFF
     r = subprocess.run([OIP, "stitch", "--image1", "T_MSS.ALIGNED.TIFF", "--image2", "T_MSS.ALIGNED.TIFF", "--fold-cols", "2", "--tiff-compress", "none",
                         "-o", "roundtrip.TIFF"], cwd=d, env=dict(os.environ, LOGFILE=os.path.join(d, "oip.log")), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

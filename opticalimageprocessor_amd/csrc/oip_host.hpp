@@ -325,22 +325,50 @@ inline void tiff_lzw_from_device(TiffWriterU16 &tw, const std::string &path, con
     const long rps = tw.rows_per_strip();
     const size_t nstrips = (size_t)((height + rps - 1) / rps);
     TiffLzwPrep own;
-    if (!prep) { prep = &own; prep->payload.alloc(oip_tiff_lzw_worst_bytes(height, width, spp, rps)); }
+    std::future<int> reserving;
+    size_t reserved = 0;
+    if (!prep) {
+        // nothing was prepared: the product file is reserved and mapped by a helper thread WHILE the strips are being encoded
+        // -- at the size sensor data encodes to (raw + 3 %: LZW does not compress it); a payload that turns out larger goes
+        // the plain way.  (Writing a new file is bound by the allocation of its pages)
+        prep = &own;
+        const size_t worst = oip_tiff_lzw_worst_bytes(height, width, spp, rps);
+        prep->payload.alloc(worst);
+        const size_t raw = (size_t)height * width * spp * 2;
+        if (raw >= ((size_t)64 << 20)) {
+            reserved = std::min(worst, raw + raw / 32 + ((size_t)64 << 10));
+            own.payloadAt = tw.begin_external_strips();
+            TiffLzwPrep *op = &own;
+            reserving = std::async(std::launch::async, [=] { return oip_file_sink_open(ctx, path.c_str(), (size_t)op->payloadAt + reserved, &op->sink); });
+        }
+    } else if (prep->sink) {
+        reserved = prep->payload.n;
+    }
     std::vector<uint64_t> off(nstrips), len(nstrips);
     size_t bytes = 0;
     const double tAlloc = sw.tick();
-    Device::get().check(oip_tiff_lzw_strips_u16(ctx, d_img, height, width, spp, rps, prep->payload.p, prep->payload.n, off.data(), len.data(), &bytes,
-                                                prep->scratch.p, prep->scratch.n));
+    const int rcEncode = oip_tiff_lzw_strips_u16(ctx, d_img, height, width, spp, rps, prep->payload.p, prep->payload.n, off.data(), len.data(), &bytes,
+                                                 prep->scratch.p, prep->scratch.n);
+    if (reserving.valid() && reserving.get() != OIP_OK && prep->sink) { oip_file_sink_close(nullptr, prep->sink); prep->sink = nullptr; }
+    Device::get().check(rcEncode);
     const double tEncode = sw.tick();
     const size_t even = (bytes + 1) & ~(size_t)1;
-    if (prep->sink) {
+    if (prep->sink && even <= reserved) {
         Device::get().check(oip_file_sink_write(ctx, prep->sink, (size_t)prep->payloadAt, prep->payload.p, even, 0));
         oip_file_sink *k = prep->sink;
         prep->sink = nullptr;
         Device::get().check(oip_file_sink_close(ctx, k));
         if (::truncate(path.c_str(), (off_t)(prep->payloadAt + even)) != 0) throw errno_error("truncate() of the TIFF product failed");
     } else {
-        const uint64_t at = tw.begin_external_strips();
+        uint64_t at = prep->payloadAt;
+        if (prep->sink) {                                              // reserved too little: drop the reservation, write the plain way
+            oip_file_sink *k = prep->sink;
+            prep->sink = nullptr;
+            Device::get().check(oip_file_sink_close(ctx, k));
+            if (::truncate(path.c_str(), (off_t)at) != 0) throw errno_error("truncate() of the TIFF product failed");
+        } else if (!reserved) {
+            at = tw.begin_external_strips();
+        }
         Device::get().check(oip_write_device_to_file_at(ctx, prep->payload.p, even, path.c_str(), (size_t)at, 0));
     }
     tw.end_external_strips(off.data(), len.data(), nstrips, bytes);

@@ -38,10 +38,13 @@ struct LzwJob {
     size_t slot_bytes;                           // multiple of 4
     unsigned long long *tab;
     unsigned *len;                               // [nstrips]
+    int active;                                  // lanes of a wave that take a strip
 };
 
 struct LzwState {
     unsigned long long *tab;
+    unsigned *occ;                               // LDS: this lane's "slot holds an entry of the current generation" bits, word w at occ[w * stride]
+    int stride;
     uint8_t *out;
     unsigned long long acc;
     unsigned o;                                  // bytes written
@@ -61,25 +64,37 @@ __device__ __forceinline__ void lzw_put(LzwState &s, unsigned code)
     }
 }
 
+__device__ __forceinline__ void lzw_clear_occ(LzwState &s)
+{
+#pragma unroll 8
+    for (int w = 0; w < kSlots / 32; ++w) s.occ[w * s.stride] = 0u;
+}
+
+// One byte through the coder.  Three steps out of four of sensor data are misses, and a miss that lands on an EMPTY slot --
+// most of them: the table is at most half full -- does not need the slot's contents to know it: a bit per slot in LDS (1 KB per
+// lane, lane-interleaved: no bank conflicts) says so, and the step costs an LDS read and two stores nobody waits for instead
+// of a dependent load from HBM.  Only occupied slots are loaded (hits, and collisions with another string).
 __device__ __forceinline__ void lzw_byte(LzwState &s, unsigned c)
 {
     const unsigned key = ((unsigned)s.ent << 8) | c;                             // 20 bits
     const unsigned want = (s.gen << 20) | key;
     unsigned h = (key * 2654435761u) >> (32 - 13);
     for (;;) {
+        const unsigned bits = s.occ[(h >> 5) * s.stride];
+        if (!((bits >> (h & 31)) & 1u)) break;                                   // empty in this generation
         const unsigned long long slot = s.tab[h];
-        const unsigned hi = (unsigned)(slot >> 32);
-        if (hi == want) { s.ent = (int)(unsigned)slot; return; }
-        if ((hi >> 20) != s.gen) break;                                          // empty in this generation
+        if ((unsigned)(slot >> 32) == want) { s.ent = (int)(unsigned)slot; return; }
         h = (h + 1) & (kSlots - 1);
     }
     lzw_put(s, (unsigned)s.ent);
     s.ent = (int)c;
     s.tab[h] = ((unsigned long long)want << 32) | (unsigned)s.next;
+    s.occ[(h >> 5) * s.stride] |= 1u << (h & 31);
     ++s.next;
     if (s.next == 4094) {                        // table full: clear (libtiff: free_ent == CODE_MAX - 1)
         lzw_put(s, 256u);
         ++s.gen;
+        lzw_clear_occ(s);
         s.width = 9;
         s.next = 258;
     } else if (s.next == (1 << s.width) && s.width < 12) {
@@ -89,11 +104,16 @@ __device__ __forceinline__ void lzw_byte(LzwState &s, unsigned c)
 
 __global__ __launch_bounds__(64) void lzw_strips_kernel(LzwJob j)
 {
-    const long local = (long)blockIdx.x * 64 + threadIdx.x;
+    extern __shared__ unsigned occ[];                                            // kSlots / 32 words per active lane; a workgroup is one wave
+    if ((int)threadIdx.x >= j.active) return;
+    const long local = (long)blockIdx.x * j.active + threadIdx.x;
     const long k = j.strip0 + local;
     if (k >= j.nstrips) return;
     LzwState s;
     s.tab = j.tab + (size_t)local * kSlots;
+    s.occ = occ + threadIdx.x;
+    s.stride = j.active;
+    lzw_clear_occ(s);
     s.out = j.slots + (size_t)local * j.slot_bytes;
     s.acc = 0; s.o = 0; s.nbits = 0; s.width = 9; s.next = 258; s.ent = -1; s.gen = 1;
     lzw_put(s, 256u);
@@ -183,11 +203,13 @@ struct LzwDecJob {
     unsigned long long *tab;                     // per lane 4096 x (position | length << 32)
     unsigned *got;                               // [nstrips] bytes a strip decoded to
     int *status;                                 // [nstrips] 0 ok, 1 bad first code, 2 code beyond the table, 3 table full
+    int active;                                  // lanes of a wave that take a strip
 };
 
 __global__ __launch_bounds__(64) void lzw_decode_kernel(LzwDecJob j)
 {
-    const long local = (long)blockIdx.x * 64 + threadIdx.x;
+    if ((int)threadIdx.x >= j.active) return;
+    const long local = (long)blockIdx.x * j.active + threadIdx.x;
     const long k = j.strip0 + local;
     if (k >= j.nstrips) return;
     unsigned long long *tab = j.tab + (size_t)local * 4096;
@@ -336,12 +358,19 @@ extern "C" int oip_tiff_lzw_strips_u16(oip_ctx *ctx, const uint16_t *d_img, long
     size_t pos = 0;
     for (long s0 = 0; s0 < nstrips; s0 += per) {
         const long ns = nstrips - s0 < per ? nstrips - s0 : per;
-        LzwJob j{d_img, rows, width, spp, rows_per_strip, nstrips, s0, d_slots, slot_bytes, d_tab, d_len};
-        // generation 0 is never current: zeroed slots are empty
-        OIP_LZW_HIP(hipMemsetAsync(d_tab, 0, (size_t)ns * kSlots * sizeof(unsigned long long), ctx->stream));
+        static const char *env_active = getenv("OIP_LZW_LANES");
+        // Lanes of a wave that take a strip.  A wave steps at the pace of its slowest lane -- the longest probe chain, a code to
+        // flush -- so 64 coders in lockstep are slower than 4 (116 -> 86 ms at 25000 strips, 76 -> 45 ms at 2000: the vector ALU
+        // idles either way, and more, emptier waves give the memory system more independent chains to overlap).
+        const int active = env_active && atoi(env_active) > 0 && atoi(env_active) <= 64 ? atoi(env_active) : 4;
+        LzwJob j{d_img, rows, width, spp, rows_per_strip, nstrips, s0, d_slots, slot_bytes, d_tab, d_len, active};
+        // No slot is read before the lane's occupancy bit says it was written in the current generation, so the tables need no
+        // initial VALUE -- but memory fresh from hipMalloc is first touched far cheaper by a linear fill than by the kernel's
+        // scattered stores (a launch on untouched scratch: 250-350 ms instead of 90-120); tables and output slots alike.
+        if (s0 == 0) OIP_LZW_HIP(hipMemsetAsync(d_scratch, 0, o_len, ctx->stream));
         {
             OipProfScope prof(ctx, "lzw_strips_kernel");
-            hipLaunchKernelGGL(lzw_strips_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, j);
+            hipLaunchKernelGGL(lzw_strips_kernel, dim3((unsigned)((ns + active - 1) / active)), dim3(64), (size_t)active * (kSlots / 32) * 4, ctx->stream, j);
         }
         OIP_LZW_HIP(hipGetLastError());
         OIP_LZW_HIP(hipMemcpyAsync(len.data() + s0, d_len + s0, (size_t)ns * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -401,9 +430,12 @@ extern "C" int oip_tiff_lzw_decode_u16(oip_ctx *ctx, const uint8_t *d_file, size
         return fail(oip_fail(ctx, OIP_E_DEVICE, "oip_tiff_lzw_decode_u16: copying the strip tables failed"));
     for (long s0 = 0; s0 < nstrips; s0 += per) {
         const long ns = nstrips - s0 < per ? nstrips - s0 : per;
-        LzwDecJob j{d_file, d_off, d_len, rows, width, spp, rows_per_strip, nstrips, s0, predictor, d_img, d_tab, d_got, d_status};
+        // (the decoder does not gain from emptier waves as the encoder does: 64 / 16 / 8 / 4 lanes 98 / 102 / 115 / 120 ms)
+        static const char *env_active = getenv("OIP_LZW_DECODE_LANES");
+        const int active = env_active && atoi(env_active) > 0 && atoi(env_active) <= 64 ? atoi(env_active) : 64;
+        LzwDecJob j{d_file, d_off, d_len, rows, width, spp, rows_per_strip, nstrips, s0, predictor, d_img, d_tab, d_got, d_status, active};
         OipProfScope prof(ctx, "lzw_decode_kernel");
-        hipLaunchKernelGGL(lzw_decode_kernel, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, ctx->stream, j);
+        hipLaunchKernelGGL(lzw_decode_kernel, dim3((unsigned)((ns + active - 1) / active)), dim3(64), 0, ctx->stream, j);
     }
     std::vector<unsigned> got((size_t)nstrips);
     std::vector<int> status((size_t)nstrips);

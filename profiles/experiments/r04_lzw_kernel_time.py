@@ -10,11 +10,12 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 img = (torch.randn(H, W * S, device="cuda", generator=g) * 300 + 1800).clamp(64, 4095).to(torch.int16)
 cap = c.tiff_lzw_worst_bytes(H, W, S, 1)
 pay = torch.empty(cap, dtype=torch.uint8, device="cuda")
+scratch = torch.empty(c.tiff_lzw_scratch_bytes(H, W, S, 1), dtype=torch.uint8, device="cuda")     # prepared once, as the pipelined CLI does
 torch.cuda.synchronize()
 for rep in range(3):
     if hasattr(c, "profile_reset"): c.profile_reset()
     t0 = time.time()
-    off, ln, total = c.tiff_lzw_strips(img, H, W, S, 1, pay)
+    off, ln, total = c.tiff_lzw_strips(img, H, W, S, 1, pay, scratch)
     dt = time.time() - t0
     print("rows %d: %.1f ms for %.2f GB -> %.2f GB (%.3f)" % (H, dt * 1e3, H * W * S * 2 / 1e9, total / 1e9, total / (H * W * S * 2)))
 back = torch.zeros_like(img)
